@@ -1,0 +1,107 @@
+"""ctypes binding of ``libglowk.so`` (the C ABI declared in ``include/glowk.h``).
+
+The product path has no CPU fallback: if the HIP library has not been built (``__graft_entry__.build()``
+or ``python -m audiosourcesep_amd.build``) importing a compute entry point raises ``GlowkLibraryMissing``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libglowk.so")
+
+
+class GlowkLibraryMissing(RuntimeError):
+    pass
+
+
+class GlowkError(RuntimeError):
+    pass
+
+
+class GlowkConfigStruct(ctypes.Structure):
+    """``glowk_config`` of include/glowk.h (field order and types must match)."""
+    _fields_ = [
+        ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("C", ctypes.c_int32),
+        ("L", ctypes.c_int32), ("K", ctypes.c_int32), ("F", ctypes.c_int32),
+        ("learntop", ctypes.c_int32), ("use_logit", ctypes.c_int32),
+        ("minval", ctypes.c_float), ("maxval", ctypes.c_float), ("alpha", ctypes.c_float),
+        ("bn_eps", ctypes.c_float),
+    ]
+
+
+class GlowkProfile(ctypes.Structure):
+    """``glowk_profile`` of include/glowk.h."""
+    _fields_ = [("net_ms", ctypes.c_double * 4), ("net_launches", ctypes.c_int64 * 4)]
+
+
+# tensor ids (enum glowk_tensor_id) keyed by the flat parameter names used across the repo
+STEP_TENSOR_IDS = {
+    "actnorm/log_scale": 0, "actnorm/shift": 1,
+    "inv1x1/P": 2, "inv1x1/sign_S": 3, "inv1x1/L": 4, "inv1x1/log_S": 5, "inv1x1/U": 6,
+    "nn/conv1/kernel": 7, "nn/conv1/bias": 8,
+    "nn/bn1/gamma": 9, "nn/bn1/beta": 10, "nn/bn1/mean": 11, "nn/bn1/var": 12,
+    "nn/conv2/kernel": 13, "nn/conv2/bias": 14,
+    "nn/bn2/gamma": 15, "nn/bn2/beta": 16, "nn/bn2/mean": 17, "nn/bn2/var": 18,
+    "nn/conv3/kernel": 19, "nn/conv3/bias": 20,
+}
+PRIOR_TENSOR_IDS = {"prior/loc": 100, "prior/log_scale": 101}
+PREC_F32, PREC_F16X3 = 0, 1
+
+_vp, _i, _fp = ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float)
+
+# every symbol include/glowk.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "glowk_version": (_i, []),
+    "glowk_last_error": (ctypes.c_char_p, []),
+    "glowk_create": (_i, [ctypes.POINTER(GlowkConfigStruct), _i, ctypes.POINTER(_vp)]),
+    "glowk_destroy": (_i, [_vp]),
+    "glowk_tensor_size": (ctypes.c_size_t, [_vp, _i, _i]),
+    "glowk_set_tensor": (_i, [_vp, _i, _i, _i, _fp, ctypes.c_size_t]),
+    "glowk_get_tensor": (_i, [_vp, _i, _i, _i, _fp, ctypes.c_size_t]),
+    "glowk_finalize_weights": (_i, [_vp]),
+    "glowk_set_precision": (_i, [_vp, _i]),
+    "glowk_get_precision": (_i, [_vp]),
+    "glowk_workspace_bytes": (ctypes.c_size_t, [_vp, _i]),
+    "glowk_reserve": (_i, [_vp, _i]),
+    "glowk_forward": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "glowk_inverse": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "glowk_log_prob": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "glowk_log_prob_grad": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "glowk_sample": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "glowk_prior_log_prob": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "glowk_profile_begin": (_i, [_vp]),
+    "glowk_profile_end": (_i, [_vp, ctypes.POINTER(GlowkProfile)]),
+    "glowk_squeeze": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "glowk_unsqueeze": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "glowk_preprocess_forward": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "glowk_preprocess_inverse": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "glowk_step_forward": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "glowk_step_inverse": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
+    "glowk_coupling_net": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libglowk.so once and declare every prototype.  Fails loudly if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GlowkLibraryMissing(
+            "HIP library %s not found: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "There is no CPU fallback for the compute path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().glowk_last_error()
+        raise GlowkError(msg.decode() if msg else "glowk error %d" % rc)

@@ -1,0 +1,770 @@
+// glowk engine: weight store, host-side packing, launch sequencing and the C ABI of include/glowk.h.
+// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC glowk.hip -o libglowk.so   (see __graft_entry__.build)
+#include "../../include/glowk.h"
+#include "glowk_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string& m) {
+  g_err = m;
+  return 1;
+}
+
+#define HIPCHK(expr)                                                                           \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));      \
+  } while (0)
+
+#define LAUNCHCHK(name)                                                                        \
+  do {                                                                                         \
+    hipError_t e_ = hipGetLastError();                                                         \
+    if (e_ != hipSuccess) return fail(std::string("launch ") + name + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+struct StepDev {            // device pointers into the arena
+  const float* K1p = nullptr;
+  const float* ep = nullptr;
+  const float4* K2p = nullptr;
+  const float4* K3p = nullptr;
+  const float *Afwd = nullptr, *bfwd = nullptr, *Ainv = nullptr, *binv = nullptr, *b3 = nullptr;
+};
+
+struct Level {
+  int h, w, c;              // tensor the steps of this block act on
+  int z_off, z_width;       // channel slice of the latent this block contributes
+  int Cz;                   // channels per latent pixel of its factored-out half (0 for the last block)
+  std::vector<std::vector<float>> host[GLOWK_NUM_STEP_TENSORS];  // [tensor][step] -> values
+  std::vector<StepDev> dev;
+};
+
+}  // namespace
+
+struct glowk_handle {
+  glowk_config cfg;
+  int device = 0;
+  int precision = GLOWK_PREC_F32;
+  std::vector<Level> levels;
+  int Hl = 0, Wl = 0, Cl = 0;
+  std::vector<float> prior_loc, prior_log_scale;
+  bool finalized = false;
+  double ld_const = 0.0;        // sum over steps of h*w*(sum log_scale + sum log_S)
+  double ld_pre_const = 0.0;    // data-independent part of the preprocessing log-det
+  std::vector<double> ld_step;  // per (level*K + step) constant
+  float* arena = nullptr;       // packed weights
+  const float* d_loc = nullptr;
+  const float* d_log_scale = nullptr;
+  // workspace
+  int wsN = 0;
+  float *bufA = nullptr, *bufB = nullptr, *bufP = nullptr, *bufZ = nullptr;
+  double* bufLd = nullptr;
+  // HIP-event profiler of k_net
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  std::vector<int> ev_level;   // level of each (start, stop) pair
+};
+
+namespace {
+
+size_t step_tensor_size(const glowk_config& cfg, const Level& lv, int id) {
+  const size_t c = lv.c, F = cfg.F;
+  switch (id) {
+    case GLOWK_ACTNORM_LOG_SCALE: case GLOWK_ACTNORM_SHIFT: case GLOWK_INV1X1_SIGN_S: case GLOWK_INV1X1_LOG_S:
+    case GLOWK_CONV3_BIAS: return c;
+    case GLOWK_INV1X1_P: case GLOWK_INV1X1_L: case GLOWK_INV1X1_U: return c * c;
+    case GLOWK_CONV1_KERNEL: return 9 * (c / 2) * F;
+    case GLOWK_CONV2_KERNEL: return F * F;
+    case GLOWK_CONV3_KERNEL: return 9 * F * c;
+    case GLOWK_CONV1_BIAS: case GLOWK_CONV2_BIAS:
+    case GLOWK_BN1_GAMMA: case GLOWK_BN1_BETA: case GLOWK_BN1_MEAN: case GLOWK_BN1_VAR:
+    case GLOWK_BN2_GAMMA: case GLOWK_BN2_BETA: case GLOWK_BN2_MEAN: case GLOWK_BN2_VAR: return F;
+    default: return 0;
+  }
+}
+
+// ---- small dense helpers (double) --------------------------------------------------------------
+typedef std::vector<double> Mat;  // row-major c x c
+
+Mat matmul(const Mat& a, const Mat& b, int c) {
+  Mat r(c * c, 0.0);
+  for (int i = 0; i < c; ++i)
+    for (int k = 0; k < c; ++k) {
+      const double aik = a[i * c + k];
+      for (int j = 0; j < c; ++j) r[i * c + j] += aik * b[k * c + j];
+    }
+  return r;
+}
+
+bool invert(const Mat& m, int c, Mat& out) {  // Gauss-Jordan, partial pivoting
+  Mat a = m;
+  out.assign(c * c, 0.0);
+  for (int i = 0; i < c; ++i) out[i * c + i] = 1.0;
+  for (int col = 0; col < c; ++col) {
+    int piv = col;
+    for (int r = col + 1; r < c; ++r)
+      if (std::fabs(a[r * c + col]) > std::fabs(a[piv * c + col])) piv = r;
+    if (a[piv * c + col] == 0.0) return false;
+    if (piv != col)
+      for (int j = 0; j < c; ++j) {
+        std::swap(a[piv * c + j], a[col * c + j]);
+        std::swap(out[piv * c + j], out[col * c + j]);
+      }
+    const double d = 1.0 / a[col * c + col];
+    for (int j = 0; j < c; ++j) { a[col * c + j] *= d; out[col * c + j] *= d; }
+    for (int r = 0; r < c; ++r) {
+      if (r == col) continue;
+      const double f = a[r * c + col];
+      if (f == 0.0) continue;
+      for (int j = 0; j < c; ++j) { a[r * c + j] -= f * a[col * c + j]; out[r * c + j] -= f * out[col * c + j]; }
+    }
+  }
+  return true;
+}
+
+inline int rho(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+inline size_t pad4(size_t n) { return (n + 3) & ~size_t(3); }
+
+struct StepLayout {
+  size_t K1p, ep, K2p, K3p, Afwd, bfwd, Ainv, binv, b3, total;
+};
+
+StepLayout step_layout(int c, int F) {
+  const int CI = c / 2, NF = F / 32, KS1 = (9 * CI) / 2, NMT = (9 * c + 31) / 32;
+  StepLayout L;
+  size_t o = 0;
+  L.K1p = o; o += pad4((size_t)NF * KS1 * 64);
+  L.ep = o; o += pad4((size_t)6 * F);
+  L.K2p = o; o += (size_t)NF * NF * 1024;
+  L.K3p = o; o += (size_t)NMT * NF * 1024;
+  L.Afwd = o; o += pad4((size_t)c * c);
+  L.bfwd = o; o += pad4(c);
+  L.Ainv = o; o += pad4((size_t)c * c);
+  L.binv = o; o += pad4(c);
+  L.b3 = o; o += pad4(c);
+  L.total = o;
+  return L;
+}
+
+// pack one step into dst (host staging of the arena); returns false + message on a singular 1x1
+bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, double* ld_const_out, std::string* err) {
+  const int c = lv.c, F = cfg.F, CI = c / 2, CO = c, NF = F / 32, KS1 = (9 * CI) / 2, NMT = (9 * c + 31) / 32;
+  const StepLayout L = step_layout(c, F);
+  auto T = [&](int id) -> const float* { return lv.host[id][k].data(); };
+
+  // --- 1x1: W = P (L*mask + I) (U*mask^T + diag(sign*exp(log_S)))  (flow_tfp_bijectors.py:300-303) ---
+  Mat Pm(c * c), Lm(c * c), Um(c * c);
+  for (int i = 0; i < c; ++i)
+    for (int j = 0; j < c; ++j) {
+      Pm[i * c + j] = T(GLOWK_INV1X1_P)[i * c + j];
+      Lm[i * c + j] = (i > j) ? T(GLOWK_INV1X1_L)[i * c + j] : (i == j ? 1.0 : 0.0);
+      Um[i * c + j] = (i < j) ? T(GLOWK_INV1X1_U)[i * c + j]
+                              : (i == j ? (double)T(GLOWK_INV1X1_SIGN_S)[i] * std::exp((double)T(GLOWK_INV1X1_LOG_S)[i]) : 0.0);
+    }
+  const Mat Wm = matmul(Pm, matmul(Lm, Um, c), c);
+  Mat Pi, Li, Ui;
+  if (!invert(Pm, c, Pi) || !invert(Lm, c, Li) || !invert(Um, c, Ui)) {
+    *err = "singular 1x1 convolution factor";
+    return false;
+  }
+  const Mat Winv = matmul(Ui, matmul(Li, Pi, c), c);  // :309-315
+  const float* ls = T(GLOWK_ACTNORM_LOG_SCALE);
+  const float* sh = T(GLOWK_ACTNORM_SHIFT);
+  double sum_ls = 0, sum_lS = 0;
+  for (int i = 0; i < c; ++i) { sum_ls += ls[i]; sum_lS += T(GLOWK_INV1X1_LOG_S)[i]; }
+  *ld_const_out = (double)lv.h * lv.w * (sum_ls + sum_lS);  // :250-253, :319-322
+  for (int ci = 0; ci < c; ++ci)
+    for (int co = 0; co < c; ++co) {
+      dst[L.Afwd + ci * c + co] = (float)(std::exp((double)ls[ci]) * Wm[ci * c + co]);      // actnorm then 1x1
+      dst[L.Ainv + ci * c + co] = (float)(Winv[ci * c + co] * std::exp(-(double)ls[co]));    // 1x1^-1 then actnorm^-1
+    }
+  for (int co = 0; co < c; ++co) {
+    double s = 0;
+    for (int ci = 0; ci < c; ++ci) s += (double)sh[ci] * Wm[ci * c + co];
+    dst[L.bfwd + co] = (float)s;
+    dst[L.binv + co] = (float)(-(double)sh[co] * std::exp(-(double)ls[co]));
+    dst[L.b3 + co] = T(GLOWK_CONV3_BIAS)[co];
+  }
+
+  // --- BN (inference) folded to y = g*x + d, applied after bias+ReLU (flow_tfk_layers.py:75-78) ---
+  const int bn[2][4] = {{GLOWK_BN1_GAMMA, GLOWK_BN1_BETA, GLOWK_BN1_MEAN, GLOWK_BN1_VAR},
+                        {GLOWK_BN2_GAMMA, GLOWK_BN2_BETA, GLOWK_BN2_MEAN, GLOWK_BN2_VAR}};
+  const int bias_id[2] = {GLOWK_CONV1_BIAS, GLOWK_CONV2_BIAS};
+  for (int s = 0; s < 2; ++s)
+    for (int f = 0; f < F; ++f) {
+      const double g = (double)T(bn[s][0])[f] / std::sqrt((double)T(bn[s][3])[f] + (double)cfg.bn_eps);
+      const double d = (double)T(bn[s][1])[f] - (double)T(bn[s][2])[f] * g;
+      dst[L.ep + (3 * s + 0) * F + f] = T(bias_id[s])[f];
+      dst[L.ep + (3 * s + 1) * F + f] = (float)g;
+      dst[L.ep + (3 * s + 2) * F + f] = (float)d;
+    }
+
+  // --- conv kernels in MFMA A-operand lane order (see glowk_kernels.h) ---
+  const float* K1 = T(GLOWK_CONV1_KERNEL);  // [9*CI][F]
+  for (int fi = 0; fi < NF; ++fi)
+    for (int ks = 0; ks < KS1; ++ks)
+      for (int l = 0; l < 64; ++l) {
+        const int i = l & 31, hh = l >> 5, kk = 2 * ks + hh;
+        dst[L.K1p + ((size_t)fi * KS1 + ks) * 64 + l] = (kk < 9 * CI) ? K1[(size_t)kk * F + fi * 32 + i] : 0.0f;
+      }
+  const float* K2 = T(GLOWK_CONV2_KERNEL);  // [f_in][f_out]
+  for (int fi = 0; fi < NF; ++fi)
+    for (int r = 0; r < 16; ++r)
+      for (int g = 0; g < NF / 4; ++g)
+        for (int l = 0; l < 64; ++l)
+          for (int e = 0; e < 4; ++e) {
+            const int i = l & 31, hh = l >> 5, fo = 4 * g + e;
+            const size_t idx = ((((size_t)fi * 16 + r) * (NF / 4) + g) * 64 + l) * 4 + e;
+            dst[L.K2p + idx] = K2[(size_t)(fi * 32 + rho(r, hh)) * F + fo * 32 + i];
+          }
+  const float* K3 = T(GLOWK_CONV3_KERNEL);  // [tap][f][co]
+  for (int mt = 0; mt < NMT; ++mt)
+    for (int fo = 0; fo < NF; ++fo)
+      for (int r4 = 0; r4 < 4; ++r4)
+        for (int l = 0; l < 64; ++l)
+          for (int e = 0; e < 4; ++e) {
+            const int i = l & 31, hh = l >> 5, r = 4 * r4 + e;
+            const int m = mt * 32 + i, f = fo * 32 + rho(r, hh);
+            const size_t idx = ((((size_t)mt * NF + fo) * 4 + r4) * 64 + l) * 4 + e;
+            float v = 0.0f;
+            if (m < 9 * CO) {
+              const int tap = m / CO, co = m % CO;
+              v = K3[((size_t)tap * F + f) * CO + co];
+            }
+            dst[L.K3p + idx] = v;
+          }
+  return true;
+}
+
+// ---- launch helpers ------------------------------------------------------------------------------
+template <int CI, int NF>
+int launch_net_t(const NetArgs& a, hipStream_t s) {
+  constexpr int F = NF * 32;
+  constexpr size_t lds = (size_t)2 * NF * 256 * 16 + (size_t)6 * F * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_net_f32<CI, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  const int grid = (a.Q + 127) / 128;
+  hipLaunchKernelGGL((k_net_f32<CI, NF>), dim3(grid), dim3(256), lds, s, a);
+  LAUNCHCHK("k_net_f32");
+  return 0;
+}
+
+int launch_net_raw(int c, int F, const NetArgs& a, hipStream_t s) {
+#define NETCASE(CI_, NF_) if (c == 2 * CI_ && F == 32 * NF_) return launch_net_t<CI_, NF_>(a, s);
+  NETCASE(2, 16) NETCASE(4, 16) NETCASE(8, 16) NETCASE(16, 16)
+  NETCASE(2, 4) NETCASE(4, 4) NETCASE(8, 4) NETCASE(16, 4)
+#undef NETCASE
+  return fail("unsupported (channels, n_filters) combination: c=" + std::to_string(c) + " F=" + std::to_string(F));
+}
+
+int launch_net(glowk_handle* h, int level, int c, int F, const NetArgs& a, hipStream_t s) {
+  if (!h->profiling) return launch_net_raw(c, F, a, s);
+  while (h->ev_pool.size() < h->ev_used + 2) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    h->ev_pool.push_back(e);
+  }
+  hipEvent_t e0 = h->ev_pool[h->ev_used], e1 = h->ev_pool[h->ev_used + 1];
+  HIPCHK(hipEventRecord(e0, s));
+  const int rc = launch_net_raw(c, F, a, s);
+  HIPCHK(hipEventRecord(e1, s));
+  h->ev_used += 2;
+  h->ev_level.push_back(level);
+  return rc;
+}
+
+#define CDISPATCH(c, CALL)                                                                     \
+  switch (c) {                                                                                 \
+    case 4: { constexpr int CC = 4; CALL; } break;                                             \
+    case 8: { constexpr int CC = 8; CALL; } break;                                             \
+    case 16: { constexpr int CC = 16; CALL; } break;                                           \
+    case 32: { constexpr int CC = 32; CALL; } break;                                           \
+    default: return fail("unsupported channel count " + std::to_string(c));                    \
+  }
+
+int launch_couple(int c, const CoupleArgs& a, int N, hipStream_t s) {
+  CDISPATCH(c, hipLaunchKernelGGL((k_couple<CC>), dim3(N), dim3(256), 0, s, a));
+  LAUNCHCHK("k_couple");
+  return 0;
+}
+
+PreArgs pre_args(const glowk_config& cfg) {
+  PreArgs p;
+  p.minval = cfg.minval; p.maxval = cfg.maxval; p.alpha = cfg.alpha; p.use_logit = cfg.use_logit;
+  return p;
+}
+
+int ensure_ws(glowk_handle* h, int N) {
+  if (N <= h->wsN) return 0;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipDeviceSynchronize());
+  if (h->bufA) { hipFree(h->bufA); hipFree(h->bufB); hipFree(h->bufP); hipFree(h->bufZ); hipFree(h->bufLd); }
+  h->bufA = h->bufB = h->bufP = h->bufZ = nullptr; h->bufLd = nullptr; h->wsN = 0;
+  const size_t E = (size_t)h->cfg.H * h->cfg.W * h->cfg.C;
+  HIPCHK(hipMalloc(&h->bufA, (size_t)N * E * 4));
+  HIPCHK(hipMalloc(&h->bufB, (size_t)N * E * 4));
+  HIPCHK(hipMalloc(&h->bufP, (size_t)N * E * 9 * 4));
+  HIPCHK(hipMalloc(&h->bufZ, (size_t)N * E * 4));
+  HIPCHK(hipMalloc(&h->bufLd, (size_t)N * 8));
+  h->wsN = N;
+  return 0;
+}
+
+int check_ready(glowk_handle* h, int N) {
+  if (!h) return fail("null handle");
+  if (!h->finalized) return fail("glowk_finalize_weights has not been called");
+  if (N <= 0) return fail("batch size must be positive");
+  if (h->precision != GLOWK_PREC_F32) return fail("precision mode not built");
+  return ensure_ws(h, N);
+}
+
+NetArgs net_args(glowk_handle* h, const Level& lv, const StepDev& sd, const float* vin, int in_stride, int in_off, int N) {
+  NetArgs a;
+  a.vin = vin; a.in_stride = in_stride; a.in_off = in_off;
+  a.Q = N * lv.h * lv.w; a.h = lv.h; a.w = lv.w;
+  a.K1p = sd.K1p; a.ep = sd.ep; a.K2p = sd.K2p; a.K3p = sd.K3p; a.P = h->bufP;
+  return a;
+}
+
+// data -> latent (+ log-det accumulated in h->bufLd); z_dst [N,Hl,Wl,Cl]
+int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_t s) {
+  const glowk_config& cfg = h->cfg;
+  const int K = cfg.K, L = cfg.L;
+  float* cur = h->bufA;
+  float* oth = h->bufB;
+  {
+    const Level& lv = h->levels[0];
+    const StepDev& first = lv.dev[K - 1];
+    CDISPATCH(lv.c, hipLaunchKernelGGL((k_in<CC>), dim3(N), dim3(256), 0, s, x, cfg.H, cfg.W, pre_args(cfg), 1,
+                                       first.Afwd, first.bfwd, cur, h->bufLd, h->ld_const + h->ld_pre_const));
+    LAUNCHCHK("k_in");
+  }
+  for (int lvl = 0; lvl < L; ++lvl) {
+    const Level& lv = h->levels[lvl];
+    for (int k = K - 1; k >= 0; --k) {   // tfb.Chain applies right to left: step K-1 first (flow_glow.py:51-52)
+      const StepDev& sd = lv.dev[k];
+      if (int rc = launch_net(h, lvl, lv.c, cfg.F, net_args(h, lv, sd, cur, lv.c, lv.c / 2, N), s)) return rc;
+      CoupleArgs ca;
+      ca.vin = cur; ca.P = h->bufP; ca.b3 = sd.b3; ca.logdet = h->bufLd; ca.log_s_out = nullptr; ca.t_out = nullptr;
+      ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0;
+      if (k > 0) {
+        ca.A = lv.dev[k - 1].Afwd; ca.b = lv.dev[k - 1].bfwd;
+        ca.out = oth; ca.out_stride = lv.c; ca.out_off = 0;
+      } else if (lvl < L - 1) {
+        ca.A = nullptr; ca.b = nullptr; ca.out = oth; ca.out_stride = lv.c; ca.out_off = 0;
+      } else {
+        ca.A = nullptr; ca.b = nullptr; ca.out = z_dst; ca.out_stride = h->Cl; ca.out_off = lv.z_off;
+      }
+      if (int rc = launch_couple(lv.c, ca, N, s)) return rc;
+      if (k > 0 || lvl < L - 1) std::swap(cur, oth);
+    }
+    if (lvl < L - 1) {
+      const StepDev& nfirst = h->levels[lvl + 1].dev[K - 1];
+      CDISPATCH(lv.c, hipLaunchKernelGGL((k_split<CC>), dim3(N), dim3(256), 0, s, cur, lv.h, lv.w, z_dst, h->Hl * h->Wl, h->Cl,
+                                         lv.z_off, lv.Cz, nfirst.Afwd, nfirst.bfwd, oth));
+      LAUNCHCHK("k_split");
+      std::swap(cur, oth);
+    }
+  }
+  return 0;
+}
+
+// latent -> data
+int run_inverse(glowk_handle* h, const float* z, int N, float* x, hipStream_t s) {
+  const glowk_config& cfg = h->cfg;
+  const int K = cfg.K, L = cfg.L;
+  float* cur = h->bufA;
+  float* oth = h->bufB;
+  for (int lvl = L - 1; lvl >= 0; --lvl) {
+    const Level& lv = h->levels[lvl];
+    const float* unext = (lvl == L - 1) ? nullptr : cur;
+    CDISPATCH(lv.c, hipLaunchKernelGGL((k_unsplit<CC>), dim3(N), dim3(256), 0, s, z, h->Hl * h->Wl, h->Cl, lv.z_off, lv.Cz, unext,
+                                       lv.h, lv.w, oth));
+    LAUNCHCHK("k_unsplit");
+    std::swap(cur, oth);
+    for (int k = 0; k < K; ++k) {   // Chain.inverse: step 0 first
+      const StepDev& sd = lv.dev[k];
+      if (int rc = launch_net(h, lvl, lv.c, cfg.F, net_args(h, lv, sd, cur, lv.c, lv.c / 2, N), s)) return rc;
+      CoupleArgs ca;
+      ca.vin = cur; ca.P = h->bufP; ca.b3 = sd.b3; ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
+      ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 1;
+      ca.A = sd.Ainv; ca.b = sd.binv; ca.out = oth; ca.out_stride = lv.c; ca.out_off = 0;
+      if (int rc = launch_couple(lv.c, ca, N, s)) return rc;
+      std::swap(cur, oth);
+    }
+  }
+  const Level& l0 = h->levels[0];
+  CDISPATCH(l0.c, hipLaunchKernelGGL((k_out<CC>), dim3(N), dim3(256), 0, s, cur, l0.h, l0.w, pre_args(cfg), 1, x));
+  LAUNCHCHK("k_out");
+  return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int glowk_version(void) { return GLOWK_VERSION; }
+const char* glowk_last_error(void) { return g_err.c_str(); }
+
+int glowk_create(const glowk_config* cfg, int device, glowk_handle** out) {
+  if (!cfg || !out) return fail("null argument");
+  if (cfg->L < 2 || cfg->L > 4) return fail("L should be 2, 3 or 4");  // flow_builder.py:76-77
+  const int s = 1 << cfg->L;
+  if (cfg->H <= 0 || cfg->W <= 0 || cfg->C <= 0 || cfg->H % s || cfg->W % s) return fail("H and W must be positive multiples of 2^L");
+  if (cfg->K <= 0) return fail("K must be positive");
+  if (cfg->F % 128 || cfg->F <= 0 || cfg->F > 512) return fail("n_filters must be a multiple of 128, at most 512");
+  glowk_handle* h = new glowk_handle();
+  h->cfg = *cfg;
+  h->device = device;
+  h->Hl = cfg->H / s; h->Wl = cfg->W / s; h->Cl = cfg->C * s * s;
+  int hh = cfg->H, ww = cfg->W, cc = cfg->C, off = 0, rem = h->Cl;
+  for (int l = 0; l < cfg->L; ++l) {
+    Level lv;
+    hh /= 2; ww /= 2; cc *= 4;
+    lv.h = hh; lv.w = ww; lv.c = cc;
+    if (l < cfg->L - 1) {
+      lv.z_width = rem / 2; lv.z_off = off; off += lv.z_width; rem -= lv.z_width;
+      lv.Cz = (hh * ww * (cc / 2)) / (h->Hl * h->Wl);
+    } else {
+      lv.z_width = rem; lv.z_off = off; lv.Cz = 0;
+    }
+    for (int t = 0; t < GLOWK_NUM_STEP_TENSORS; ++t) {
+      lv.host[t].resize(cfg->K);
+      for (int k = 0; k < cfg->K; ++k) lv.host[t][k].assign(step_tensor_size(*cfg, lv, t), 0.0f);
+    }
+    lv.dev.resize(cfg->K);
+    h->levels.push_back(std::move(lv));
+    cc /= 2;
+  }
+  const size_t E = (size_t)h->Hl * h->Wl * h->Cl;
+  h->prior_loc.assign(E, 0.0f);
+  h->prior_log_scale.assign(E, 0.0f);
+  *out = h;
+  return 0;
+}
+
+int glowk_destroy(glowk_handle* h) {
+  if (!h) return 0;
+  hipSetDevice(h->device);
+  if (h->arena) hipFree(h->arena);
+  if (h->bufA) { hipFree(h->bufA); hipFree(h->bufB); hipFree(h->bufP); hipFree(h->bufZ); hipFree(h->bufLd); }
+  for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+  delete h;
+  return 0;
+}
+
+size_t glowk_tensor_size(const glowk_handle* h, int level, int tensor_id) {
+  if (!h) return 0;
+  if (tensor_id == GLOWK_PRIOR_LOC || tensor_id == GLOWK_PRIOR_LOG_SCALE) return h->prior_loc.size();
+  if (level < 0 || level >= (int)h->levels.size() || tensor_id < 0 || tensor_id >= GLOWK_NUM_STEP_TENSORS) return 0;
+  return step_tensor_size(h->cfg, h->levels[level], tensor_id);
+}
+
+static std::vector<float>* locate(glowk_handle* h, int level, int step, int id) {
+  if (id == GLOWK_PRIOR_LOC) return &h->prior_loc;
+  if (id == GLOWK_PRIOR_LOG_SCALE) return &h->prior_log_scale;
+  if (level < 0 || level >= (int)h->levels.size() || id < 0 || id >= GLOWK_NUM_STEP_TENSORS) return nullptr;
+  if (step < 0 || step >= h->cfg.K) return nullptr;
+  return &h->levels[level].host[id][step];
+}
+
+int glowk_set_tensor(glowk_handle* h, int level, int step, int tensor_id, const float* host, size_t n) {
+  if (!h || !host) return fail("null argument");
+  std::vector<float>* v = locate(h, level, step, tensor_id);
+  if (!v) return fail("no such tensor");
+  if (v->size() != n) return fail("tensor size mismatch: expected " + std::to_string(v->size()) + ", got " + std::to_string(n));
+  std::memcpy(v->data(), host, n * sizeof(float));
+  h->finalized = false;
+  return 0;
+}
+
+int glowk_get_tensor(const glowk_handle* h, int level, int step, int tensor_id, float* host, size_t n) {
+  if (!h || !host) return fail("null argument");
+  const std::vector<float>* v = locate(const_cast<glowk_handle*>(h), level, step, tensor_id);
+  if (!v) return fail("no such tensor");
+  if (v->size() != n) return fail("tensor size mismatch");
+  std::memcpy(host, v->data(), n * sizeof(float));
+  return 0;
+}
+
+int glowk_finalize_weights(glowk_handle* h) {
+  if (!h) return fail("null handle");
+  const glowk_config& cfg = h->cfg;
+  for (const Level& lv : h->levels)
+    if (lv.c != 4 && lv.c != 8 && lv.c != 16 && lv.c != 32)
+      return fail("unsupported channel count " + std::to_string(lv.c) + " (this build: 4, 8, 16, 32)");
+  if (cfg.F != 128 && cfg.F != 512) return fail("this build instantiates n_filters 128 and 512 only");
+  size_t total = 0;
+  for (const Level& lv : h->levels) total += step_layout(lv.c, cfg.F).total * cfg.K;
+  const size_t E = h->prior_loc.size();
+  const size_t prior_off = total;
+  total += 2 * pad4(E);
+  std::vector<float> stage(total, 0.0f);
+  h->ld_step.assign((size_t)cfg.L * cfg.K, 0.0);
+  h->ld_const = 0.0;
+  size_t o = 0;
+  std::vector<size_t> offs;
+  for (size_t l = 0; l < h->levels.size(); ++l) {
+    const Level& lv = h->levels[l];
+    for (int k = 0; k < cfg.K; ++k) {
+      std::string err;
+      double ldc = 0;
+      if (!pack_step(cfg, lv, k, stage.data() + o, &ldc, &err))
+        return fail("level " + std::to_string(l) + " step " + std::to_string(k) + ": " + err);
+      h->ld_step[l * cfg.K + k] = ldc;
+      h->ld_const += ldc;
+      offs.push_back(o);
+      o += step_layout(lv.c, cfg.F).total;
+    }
+  }
+  std::memcpy(stage.data() + prior_off, h->prior_loc.data(), E * 4);
+  std::memcpy(stage.data() + prior_off + pad4(E), h->prior_log_scale.data(), E * 4);
+  // data-independent preprocessing log-det (flow_tfp_bijectors.py:390-396)
+  const double npx = (double)cfg.H * cfg.W * cfg.C;
+  h->ld_pre_const = -npx * std::log((double)cfg.maxval - (double)cfg.minval);
+  if (cfg.use_logit) h->ld_pre_const += npx * std::log(1.0 - 2.0 * (double)cfg.alpha);
+
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipDeviceSynchronize());
+  if (h->arena) { hipFree(h->arena); h->arena = nullptr; }
+  HIPCHK(hipMalloc(&h->arena, total * 4));
+  HIPCHK(hipMemcpy(h->arena, stage.data(), total * 4, hipMemcpyHostToDevice));
+  size_t idx = 0;
+  for (Level& lv : h->levels) {
+    const StepLayout SL = step_layout(lv.c, cfg.F);
+    for (int k = 0; k < cfg.K; ++k) {
+      const float* base = h->arena + offs[idx++];
+      StepDev& d = lv.dev[k];
+      d.K1p = base + SL.K1p; d.ep = base + SL.ep;
+      d.K2p = reinterpret_cast<const float4*>(base + SL.K2p);
+      d.K3p = reinterpret_cast<const float4*>(base + SL.K3p);
+      d.Afwd = base + SL.Afwd; d.bfwd = base + SL.bfwd; d.Ainv = base + SL.Ainv; d.binv = base + SL.binv; d.b3 = base + SL.b3;
+    }
+  }
+  h->d_loc = cfg.learntop ? h->arena + prior_off : nullptr;
+  h->d_log_scale = cfg.learntop ? h->arena + prior_off + pad4(E) : nullptr;
+  h->finalized = true;
+  return 0;
+}
+
+int glowk_set_precision(glowk_handle* h, int precision) {
+  if (!h) return fail("null handle");
+  if (precision != GLOWK_PREC_F32) return fail("precision mode not available in this build");
+  h->precision = precision;
+  return 0;
+}
+
+int glowk_get_precision(const glowk_handle* h) { return h ? h->precision : -1; }
+
+size_t glowk_workspace_bytes(const glowk_handle* h, int N) {
+  if (!h || N <= 0) return 0;
+  const size_t E = (size_t)h->cfg.H * h->cfg.W * h->cfg.C;
+  return (size_t)N * E * 4 * 12 + (size_t)N * 8;
+}
+
+int glowk_reserve(glowk_handle* h, int N) {
+  if (!h) return fail("null handle");
+  if (N <= 0) return fail("batch size must be positive");
+  return ensure_ws(h, N);
+}
+
+int glowk_forward(glowk_handle* h, const float* x_dev, int N, float* z_dev, float* logdet_dev, void* stream) {
+  if (int rc = check_ready(h, N)) return rc;
+  if (!x_dev || !z_dev) return fail("null tensor");
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = run_forward(h, x_dev, N, z_dev, s)) return rc;
+  if (logdet_dev) {
+    hipLaunchKernelGGL(k_prior, dim3(N), dim3(256), 0, s, (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr,
+                       (const double*)h->bufLd, (float*)nullptr, logdet_dev);
+    LAUNCHCHK("k_prior(logdet)");
+  }
+  return 0;
+}
+
+int glowk_inverse(glowk_handle* h, const float* z_dev, int N, float* x_dev, void* stream) {
+  if (int rc = check_ready(h, N)) return rc;
+  if (!x_dev || !z_dev) return fail("null tensor");
+  return run_inverse(h, z_dev, N, x_dev, (hipStream_t)stream);
+}
+
+int glowk_log_prob(glowk_handle* h, const float* x_dev, int N, float* logp_dev, float* z_dev, void* stream) {
+  if (int rc = check_ready(h, N)) return rc;
+  if (!x_dev || !logp_dev) return fail("null tensor");
+  hipStream_t s = (hipStream_t)stream;
+  float* z = z_dev ? z_dev : h->bufZ;
+  if (int rc = run_forward(h, x_dev, N, z, s)) return rc;
+  hipLaunchKernelGGL(k_prior, dim3(N), dim3(256), 0, s, (const float*)z, h->Hl * h->Wl * h->Cl, h->d_loc, h->d_log_scale,
+                     (const double*)h->bufLd, logp_dev, (float*)nullptr);
+  LAUNCHCHK("k_prior");
+  return 0;
+}
+
+int glowk_log_prob_grad(glowk_handle* h, const float* x_dev, int N, float* logp_dev, float* dx_dev, void* stream) {
+  (void)h; (void)x_dev; (void)N; (void)logp_dev; (void)dx_dev; (void)stream;
+  return fail("glowk_log_prob_grad: input-gradient path not built yet");
+}
+
+int glowk_sample(glowk_handle* h, const float* eps_dev, int N, float* x_dev, void* stream) {
+  if (int rc = check_ready(h, N)) return rc;
+  if (!eps_dev || !x_dev) return fail("null tensor");
+  hipStream_t s = (hipStream_t)stream;
+  const int E = h->Hl * h->Wl * h->Cl;
+  const size_t total = (size_t)N * E;
+  hipLaunchKernelGGL(k_prior_sample, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, eps_dev, total, E, h->d_loc, h->d_log_scale,
+                     h->bufZ);
+  LAUNCHCHK("k_prior_sample");
+  return run_inverse(h, h->bufZ, N, x_dev, s);
+}
+
+int glowk_prior_log_prob(glowk_handle* h, const float* z_dev, int N, float* logp_dev, void* stream) {
+  if (int rc = check_ready(h, N)) return rc;
+  if (!z_dev || !logp_dev) return fail("null tensor");
+  hipLaunchKernelGGL(k_prior, dim3(N), dim3(256), 0, (hipStream_t)stream, z_dev, h->Hl * h->Wl * h->Cl, h->d_loc, h->d_log_scale,
+                     (const double*)nullptr, logp_dev, (float*)nullptr);
+  LAUNCHCHK("k_prior");
+  return 0;
+}
+
+int glowk_profile_begin(glowk_handle* h) {
+  if (!h) return fail("null handle");
+  h->profiling = true;
+  h->ev_used = 0;
+  h->ev_level.clear();
+  return 0;
+}
+
+int glowk_profile_end(glowk_handle* h, glowk_profile* out) {
+  if (!h || !out) return fail("null argument");
+  std::memset(out, 0, sizeof(*out));
+  h->profiling = false;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipDeviceSynchronize());
+  for (size_t i = 0; i < h->ev_level.size(); ++i) {
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]));
+    const int l = h->ev_level[i];
+    if (l >= 0 && l < 4) { out->net_ms[l] += ms; out->net_launches[l] += 1; }
+  }
+  h->ev_used = 0;
+  h->ev_level.clear();
+  return 0;
+}
+
+int glowk_squeeze(const float* x_dev, int N, int H, int W, int C, float* y_dev, void* stream) {
+  if (!x_dev || !y_dev) return fail("null tensor");
+  if (N <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2) return fail("squeeze needs even H and W");  // flow_tfp_bijectors.py:165-166
+  PreArgs p = {0, 1, 0, 0};
+  const int c = 4 * C;
+  CDISPATCH(c, hipLaunchKernelGGL((k_in<CC>), dim3(N), dim3(256), 0, (hipStream_t)stream, x_dev, H, W, p, 0, (const float*)nullptr,
+                                  (const float*)nullptr, y_dev, (double*)nullptr, 0.0));
+  LAUNCHCHK("k_in(squeeze)");
+  return 0;
+}
+
+int glowk_unsqueeze(const float* y_dev, int N, int hh, int ww, int c4, float* x_dev, void* stream) {
+  if (!x_dev || !y_dev) return fail("null tensor");
+  if (N <= 0 || hh <= 0 || ww <= 0 || c4 % 4) return fail("unsqueeze needs a channel count divisible by 4");
+  PreArgs p = {0, 1, 0, 0};
+  CDISPATCH(c4, hipLaunchKernelGGL((k_out<CC>), dim3(N), dim3(256), 0, (hipStream_t)stream, y_dev, hh, ww, p, 0, x_dev));
+  LAUNCHCHK("k_out(unsqueeze)");
+  return 0;
+}
+
+int glowk_preprocess_forward(glowk_handle* h, const float* x_dev, int N, float* y_dev, float* logdet_dev, void* stream) {
+  if (!h || !x_dev || !y_dev) return fail("null argument");
+  if (N <= 0) return fail("batch size must be positive");
+  const int E = h->cfg.H * h->cfg.W * h->cfg.C;
+  double ldc = -(double)E * std::log((double)h->cfg.maxval - (double)h->cfg.minval);
+  if (h->cfg.use_logit) ldc += (double)E * std::log(1.0 - 2.0 * (double)h->cfg.alpha);
+  hipLaunchKernelGGL(k_pre_only, dim3(N), dim3(256), 0, (hipStream_t)stream, x_dev, E, pre_args(h->cfg), 0, y_dev, logdet_dev, ldc);
+  LAUNCHCHK("k_pre_only");
+  return 0;
+}
+
+int glowk_preprocess_inverse(glowk_handle* h, const float* y_dev, int N, float* x_dev, void* stream) {
+  if (!h || !x_dev || !y_dev) return fail("null argument");
+  if (N <= 0) return fail("batch size must be positive");
+  const int E = h->cfg.H * h->cfg.W * h->cfg.C;
+  hipLaunchKernelGGL(k_pre_only, dim3(N), dim3(256), 0, (hipStream_t)stream, y_dev, E, pre_args(h->cfg), 1, x_dev, (float*)nullptr, 0.0);
+  LAUNCHCHK("k_pre_only");
+  return 0;
+}
+
+int glowk_step_forward(glowk_handle* h, int level, int step, const float* u_dev, int N, float* y_dev, float* logdet_dev, void* stream) {
+  if (int rc = check_ready(h, N)) return rc;
+  if (level < 0 || level >= h->cfg.L || step < 0 || step >= h->cfg.K) return fail("no such step");
+  if (!u_dev || !y_dev) return fail("null tensor");
+  hipStream_t s = (hipStream_t)stream;
+  const Level& lv = h->levels[level];
+  const StepDev& sd = lv.dev[step];
+  const int Q = N * lv.h * lv.w;
+  CDISPATCH(lv.c, hipLaunchKernelGGL((k_affine<CC>), dim3((Q + 255) / 256), dim3(256), 0, s, u_dev, Q, sd.Afwd, sd.bfwd, h->bufA));
+  LAUNCHCHK("k_affine");
+  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, h->bufA, lv.c, lv.c / 2, N), s)) return rc;
+  if (logdet_dev) {
+    // logdet accumulator starts at the step's constant h*w*(sum log_scale + sum log_S)
+    PreArgs p = {0, 1, 0, 0};
+    (void)p;
+    std::vector<double> init(N, h->ld_step[(size_t)level * h->cfg.K + step]);
+    HIPCHK(hipMemcpyAsync(h->bufLd, init.data(), (size_t)N * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  CoupleArgs ca;
+  ca.vin = h->bufA; ca.P = h->bufP; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
+  ca.out = y_dev; ca.out_stride = lv.c; ca.out_off = 0;
+  ca.logdet = logdet_dev ? h->bufLd : nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
+  ca.Q = Q; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0;
+  if (int rc = launch_couple(lv.c, ca, N, s)) return rc;
+  if (logdet_dev) {
+    hipLaunchKernelGGL(k_prior, dim3(N), dim3(256), 0, s, (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr,
+                       (const double*)h->bufLd, (float*)nullptr, logdet_dev);
+    LAUNCHCHK("k_prior(logdet)");
+  }
+  return 0;
+}
+
+int glowk_step_inverse(glowk_handle* h, int level, int step, const float* y_dev, int N, float* u_dev, void* stream) {
+  if (int rc = check_ready(h, N)) return rc;
+  if (level < 0 || level >= h->cfg.L || step < 0 || step >= h->cfg.K) return fail("no such step");
+  if (!u_dev || !y_dev) return fail("null tensor");
+  hipStream_t s = (hipStream_t)stream;
+  const Level& lv = h->levels[level];
+  const StepDev& sd = lv.dev[step];
+  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, y_dev, lv.c, lv.c / 2, N), s)) return rc;
+  CoupleArgs ca;
+  ca.vin = y_dev; ca.P = h->bufP; ca.b3 = sd.b3; ca.A = sd.Ainv; ca.b = sd.binv;
+  ca.out = u_dev; ca.out_stride = lv.c; ca.out_off = 0;
+  ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
+  ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 1;
+  return launch_couple(lv.c, ca, N, s);
+}
+
+int glowk_coupling_net(glowk_handle* h, int level, int step, const float* xb_dev, int N, float* log_s_dev, float* t_dev, void* stream) {
+  if (int rc = check_ready(h, N)) return rc;
+  if (level < 0 || level >= h->cfg.L || step < 0 || step >= h->cfg.K) return fail("no such step");
+  if (!xb_dev || !log_s_dev || !t_dev) return fail("null tensor");
+  hipStream_t s = (hipStream_t)stream;
+  const Level& lv = h->levels[level];
+  const StepDev& sd = lv.dev[step];
+  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, xb_dev, lv.c / 2, 0, N), s)) return rc;
+  CoupleArgs ca;
+  ca.vin = nullptr; ca.P = h->bufP; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
+  ca.out = nullptr; ca.out_stride = 0; ca.out_off = 0;
+  ca.logdet = nullptr; ca.log_s_out = log_s_dev; ca.t_out = t_dev;
+  ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0;
+  return launch_couple(lv.c, ca, N, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,210 @@
+"""Thin Python owner of one ``glowk_handle`` (one per GPU / process).
+
+PyTorch-ROCm is used for storage and streams only: tensors are ``torch.cuda`` float32 NHWC buffers whose
+``data_ptr()`` is handed to the C ABI together with the current HIP stream; all arithmetic happens in
+``libglowk.so``.  No CPU fallback: construction raises if the library is missing or no GPU is present.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import GlowConfig
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class GlowEngine:
+    def __init__(self, cfg: GlowConfig, device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("glowk needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
+        self.cfg = cfg
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        c = _lib.GlowkConfigStruct(cfg.H, cfg.W, cfg.C, cfg.L, cfg.K, cfg.F, int(cfg.learntop), int(cfg.use_logit),
+                                   cfg.minval, cfg.maxval, cfg.alpha, cfg.bn_eps)
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.glowk_create(ctypes.byref(c), self.device.index, ctypes.byref(h)))
+        self.h = h
+        self._finalized = False
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.glowk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters -------------------------------------------------------------------------------
+    @staticmethod
+    def _split_name(name):
+        if name in _lib.PRIOR_TENSOR_IDS:
+            return -1, 0, _lib.PRIOR_TENSOR_IDS[name]
+        lvl, stp, rest = name.split("/", 2)
+        return int(lvl[1:]), int(stp[1:]), _lib.STEP_TENSOR_IDS[rest]
+
+    def set_tensor(self, name, value):
+        level, step, tid = self._split_name(name)
+        a = np.ascontiguousarray(np.asarray(value, dtype=np.float32)).ravel()
+        _lib.check(self.lib.glowk_set_tensor(self.h, level, step, tid, a.ctypes.data_as(_lib._fp), a.size))
+        self._finalized = False
+
+    def get_tensor(self, name):
+        level, step, tid = self._split_name(name)
+        n = self.lib.glowk_tensor_size(self.h, level, tid)
+        a = np.empty(n, dtype=np.float32)
+        _lib.check(self.lib.glowk_get_tensor(self.h, level, step, tid, a.ctypes.data_as(_lib._fp), a.size))
+        return a
+
+    def load_params(self, params):
+        """``params``: flat dict (see audiosourcesep_amd.synthetic) in the reference's tensor layouts."""
+        for name, value in params.items():
+            self.set_tensor(name, value)
+        self.finalize()
+
+    def finalize(self):
+        _lib.check(self.lib.glowk_finalize_weights(self.h))
+        self._finalized = True
+
+    def set_precision(self, mode):
+        _lib.check(self.lib.glowk_set_precision(self.h, int(mode)))
+
+    def reserve(self, n):
+        _lib.check(self.lib.glowk_reserve(self.h, int(n)))
+
+    def workspace_bytes(self, n):
+        return int(self.lib.glowk_workspace_bytes(self.h, int(n)))
+
+    def profile_begin(self):
+        _lib.check(self.lib.glowk_profile_begin(self.h))
+
+    def profile_end(self):
+        """-> [(summed k_net milliseconds, launches)] per level, from HIP events on the launch stream."""
+        p = _lib.GlowkProfile()
+        _lib.check(self.lib.glowk_profile_end(self.h, ctypes.byref(p)))
+        return [(p.net_ms[i], int(p.net_launches[i])) for i in range(self.cfg.L)]
+
+    # ---- helpers ----------------------------------------------------------------------------------
+    def _in(self, x, shape_tail):
+        if not torch.is_tensor(x):
+            x = torch.as_tensor(np.asarray(x, dtype=np.float32))
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        if tuple(x.shape[1:]) != tuple(shape_tail):
+            raise ValueError("expected a [N, %s] tensor, got %s" % (", ".join(map(str, shape_tail)), tuple(x.shape)))
+        if not self._finalized:
+            self.finalize()
+        return x
+
+    def _new(self, *shape):
+        return torch.empty(shape, device=self.device, dtype=torch.float32)
+
+    @property
+    def data_shape(self):
+        return (self.cfg.H, self.cfg.W, self.cfg.C)
+
+    # ---- hot path ---------------------------------------------------------------------------------
+    def forward(self, x, with_logdet=True):
+        x = self._in(x, self.data_shape)
+        n = x.shape[0]
+        z = self._new(n, *self.cfg.latent_shape())
+        ld = self._new(n) if with_logdet else None
+        _lib.check(self.lib.glowk_forward(self.h, _ptr(x), n, _ptr(z), _ptr(ld), _stream_ptr()))
+        return (z, ld) if with_logdet else z
+
+    def inverse(self, z):
+        z = self._in(z, self.cfg.latent_shape())
+        n = z.shape[0]
+        x = self._new(n, *self.data_shape)
+        _lib.check(self.lib.glowk_inverse(self.h, _ptr(z), n, _ptr(x), _stream_ptr()))
+        return x
+
+    def log_prob(self, x, return_latent=False, out=None):
+        x = self._in(x, self.data_shape)
+        n = x.shape[0]
+        lp = out if out is not None else self._new(n)
+        z = self._new(n, *self.cfg.latent_shape()) if return_latent else None
+        _lib.check(self.lib.glowk_log_prob(self.h, _ptr(x), n, _ptr(lp), _ptr(z), _stream_ptr()))
+        return (lp, z) if return_latent else lp
+
+    def log_prob_grad(self, x):
+        x = self._in(x, self.data_shape)
+        n = x.shape[0]
+        lp, dx = self._new(n), torch.empty_like(x)
+        _lib.check(self.lib.glowk_log_prob_grad(self.h, _ptr(x), n, _ptr(lp), _ptr(dx), _stream_ptr()))
+        return lp, dx
+
+    def sample_from_eps(self, eps):
+        eps = self._in(eps, self.cfg.latent_shape())
+        n = eps.shape[0]
+        x = self._new(n, *self.data_shape)
+        _lib.check(self.lib.glowk_sample(self.h, _ptr(eps), n, _ptr(x), _stream_ptr()))
+        return x
+
+    def prior_log_prob(self, z):
+        z = self._in(z, self.cfg.latent_shape())
+        lp = self._new(z.shape[0])
+        _lib.check(self.lib.glowk_prior_log_prob(self.h, _ptr(z), z.shape[0], _ptr(lp), _stream_ptr()))
+        return lp
+
+    # ---- sub-bijectors ----------------------------------------------------------------------------
+    def preprocess_forward(self, x):
+        x = self._in(x, self.data_shape)
+        y, ld = torch.empty_like(x), self._new(x.shape[0])
+        _lib.check(self.lib.glowk_preprocess_forward(self.h, _ptr(x), x.shape[0], _ptr(y), _ptr(ld), _stream_ptr()))
+        return y, ld
+
+    def preprocess_inverse(self, y):
+        y = self._in(y, self.data_shape)
+        x = torch.empty_like(y)
+        _lib.check(self.lib.glowk_preprocess_inverse(self.h, _ptr(y), y.shape[0], _ptr(x), _stream_ptr()))
+        return x
+
+    def step_forward(self, level, step, u):
+        u = self._in(u, self.cfg.level_shapes()[level])
+        y, ld = torch.empty_like(u), self._new(u.shape[0])
+        _lib.check(self.lib.glowk_step_forward(self.h, level, step, _ptr(u), u.shape[0], _ptr(y), _ptr(ld), _stream_ptr()))
+        return y, ld
+
+    def step_inverse(self, level, step, y):
+        y = self._in(y, self.cfg.level_shapes()[level])
+        u = torch.empty_like(y)
+        _lib.check(self.lib.glowk_step_inverse(self.h, level, step, _ptr(y), y.shape[0], _ptr(u), _stream_ptr()))
+        return u
+
+    def coupling_net(self, level, step, xb):
+        h, w, c = self.cfg.level_shapes()[level]
+        xb = self._in(xb, (h, w, c // 2))
+        log_s, t = torch.empty_like(xb), torch.empty_like(xb)
+        _lib.check(self.lib.glowk_coupling_net(self.h, level, step, _ptr(xb), xb.shape[0], _ptr(log_s), _ptr(t), _stream_ptr()))
+        return log_s, t
+
+
+def squeeze(x):
+    """Squeeze._forward (flow_tfp_bijectors.py:170-174) on the GPU: [N,H,W,C] -> [N,H/2,W/2,4C]."""
+    lib = _lib.load()
+    x = x.contiguous()
+    n, H, W, C = x.shape
+    y = torch.empty((n, H // 2, W // 2, 4 * C), device=x.device, dtype=torch.float32)
+    _lib.check(lib.glowk_squeeze(_ptr(x), n, H, W, C, _ptr(y), _stream_ptr()))
+    return y
+
+
+def unsqueeze(y):
+    """Squeeze._inverse (flow_tfp_bijectors.py:176-180)."""
+    lib = _lib.load()
+    y = y.contiguous()
+    n, h, w, c4 = y.shape
+    x = torch.empty((n, 2 * h, 2 * w, c4 // 4), device=y.device, dtype=torch.float32)
+    _lib.check(lib.glowk_unsqueeze(_ptr(y), n, h, w, c4, _ptr(x), _stream_ptr()))
+    return x

@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Glow forward + log-det (= log_prob) passes/s on 64x64x1 mel tiles (K=32, L=3, F=512).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one log_prob pass of the hot path over one resident batch of synthetic tiles (``--batch`` per
+GPU, default 1024).  Tiles are independent, so N ranks each own a shard (weak scaling); the only collective is
+the all-reduce (RCCL) of the summed log-likelihood, once per step.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line
+  roofline      dominant kernel = k_net_f32 at level 0 (32x32x4 tensors, 77 % of the FLOPs): algorithmic FLOP per
+                launch (conv1+conv2+conv3 of the coupling network at 2 FLOP/MAC) divided by
+                its average duration from HIP events recorded on the launch stream inside the timed region,
+                against the fp32-input MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md:42).
+  cpu_baseline  the CPU oracle (torch-CPU restatement, oracle/glowref_torch.py -- a port, not TensorFlow) timed
+                on this host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from audiosourcesep_amd.config import GlowConfig, CONFIG_A, CONFIG_B, CONFIG_YAML  # noqa: E402
+from audiosourcesep_amd.synthetic import synthetic_params, synthetic_mel_tiles  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md:42
+PEAK_HBM_GBS = 8000.0          # :36
+
+
+def baseline_metric():
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "Glow fwd+logdet passes/sec on 64x64x1 mel tiles (K=32,L=3), 1->8 MI355X"
+
+
+def net_flop_per_pixel(c, F):
+    """conv1 3x3 (c/2 -> F) + conv2 1x1 (F -> F) + conv3 3x3 (F -> c), 2 FLOP per MAC."""
+    return 2 * (9 * (c // 2) * F + F * F + 9 * F * c)
+
+
+def cpu_baseline(cfg, params, sample_tiles, passes):
+    """Oracle port on the host cores: torch-CPU fp32, one network evaluation per step (deduplicated graph)."""
+    from oracle import glowref_torch as RT
+    torch.set_num_threads(os.cpu_count() or 1)
+    p = RT.to_torch(params, torch.float32)
+    x = torch.from_numpy(synthetic_mel_tiles(sample_tiles, cfg, seed=4321))
+    with torch.no_grad():
+        RT.log_prob(x[:1], p, cfg.as_dict())  # warm-up (oneDNN primitive creation)
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            RT.log_prob(x, p, cfg.as_dict())
+        dt = time.perf_counter() - t0
+    return {
+        "value": sample_tiles * passes / dt, "unit": "passes/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": "%d tiles x %d passes of the same config, torch-CPU fp32 restatement (oracle/glowref_torch.py), %.1f s"
+                  % (sample_tiles, passes, dt),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1024, help="tiles per GPU per step")
+    ap.add_argument("--config", default="B", choices=["A", "B", "YAML"])
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tiles", type=int, default=8)
+    ap.add_argument("--cpu-passes", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    cfg = {"A": CONFIG_A, "B": CONFIG_B, "YAML": CONFIG_YAML}[args.config]
+    from audiosourcesep_amd.engine import GlowEngine
+    from audiosourcesep_amd import _lib
+    params = synthetic_params(cfg)
+    eng = GlowEngine(cfg, device=local_rank)
+    eng.load_params(params)
+    eng.set_precision(_lib.PREC_F32 if args.precision == "f32" else _lib.PREC_F16X3)
+    n = args.batch
+    eng.reserve(n)
+    x = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=1234 + rank)).cuda()   # resident in HBM before timing
+    lp = torch.empty(n, device="cuda", dtype=torch.float32)
+    total = torch.zeros(1, device="cuda", dtype=torch.float64)
+
+    def step():
+        eng.log_prob(x, out=lp)
+        total.copy_(lp.sum(dtype=torch.float64))
+        if dist is not None:
+            dist.all_reduce(total)   # summed log-likelihood over all shards (RCCL over xGMI)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    eng.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_end()
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(total).all(), "non-finite log-likelihood"
+
+    if rank == 0:
+        passes = n * world * args.steps
+        value = passes / elapsed
+        h0, w0, c0 = cfg.level_shapes()[0]
+        ms0, launches0 = prof[0]
+        flop_launch = net_flop_per_pixel(c0, cfg.F) * n * h0 * w0
+        avg_ms = ms0 / max(launches0, 1)
+        achieved = flop_launch / (avg_ms * 1e-3) / 1e12 if launches0 else None
+        net_ms_total = sum(m for m, _ in prof)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_net_level0_hbm_bytes_per_launch_per_tile")
+                traffic = traffic * n if traffic is not None else None
+            except Exception:
+                traffic = None
+        out = {
+            "metric": baseline_metric() if args.config == "B" else "Glow fwd+logdet passes/sec (config %s)" % args.config,
+            "value": value, "unit": "passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f16x3->f32",
+            "data": "synthetic",
+            "config": {"workload": "Glow log_prob, %dx%dx%d mel tiles, L=%d K=%d n_filters=%d, %d tiles/GPU/step"
+                                   % (cfg.H, cfg.W, cfg.C, cfg.L, cfg.K, cfg.F, n),
+                       "tiles_per_gpu": n, "sharding": "batch shards, 1 all-reduce(sum log-lik)/step"},
+            "gflop_per_pass": cfg.flop_per_tile() / 1e9,
+            "whole_path_tflops": value / world * cfg.flop_per_tile() / 1e12,
+            "whole_path_frac_of_f32_mfma_peak": value / world * cfg.flop_per_tile() / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "hbm_frac_activations": value / world * cfg.act_bytes_per_tile() / 1e9 / PEAK_HBM_GBS,
+            "k_net_share_of_step_time": net_ms_total * 1e-3 / elapsed,
+            "roofline": {
+                "kernel": "k_net_f32<CI=%d,NF=%d> (level 0)" % (c0 // 2, cfg.F // 32),
+                "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": traffic,
+                "avg_launch_ms": avg_ms, "launches": launches0, "flop_per_launch": flop_launch,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, params, args.cpu_tiles, args.cpu_passes)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

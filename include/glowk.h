@@ -1,0 +1,147 @@
+/* glowk -- C ABI of the MI355X (gfx950) Glow forward / inverse / log-prob engine.
+ *
+ * The reference (SamArgt/AudioSourceSep) has no native boundary: its "operator API" for this path is
+ * the Python duck type of tfd.TransformedDistribution / tfb.Bijector returned by
+ * flow_models/flow_builder.py:60-146 (build_glow).  Each entry point below names the reference
+ * interface it replaces; audiosourcesep_amd/flow_models/ binds them with ctypes and re-creates that
+ * duck type (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - every tensor is NHWC, float32, contiguous; "dev" pointers are device (HBM) addresses owned by the
+ *     caller (e.g. torch storages), "host" pointers are ordinary host memory;
+ *   - every compute call is asynchronous on the hipStream_t passed as `stream` (void*, 0 = null stream);
+ *   - return value: 0 = OK, non-zero = error; glowk_last_error() returns a thread-local message;
+ *   - one handle per device; a handle is not thread safe; the engine owns packed weights + workspace.
+ *   - `level` counts blocks from 0 (glowBlock1 = 0); `step` is the creation index k of glowStep_k
+ *     (flow_glow.py:44-49).  The forward pass applies steps K-1 ... 0 (tfb.Chain order, :51-52).
+ */
+#ifndef GLOWK_H
+#define GLOWK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLOWK_VERSION 100
+
+/* Arguments of build_glow (flow_builder.py:60-61) + SpecPreprocessing kwargs (flow_tfp_bijectors.py:365). */
+typedef struct glowk_config {
+  int32_t H, W, C;     /* data_shape */
+  int32_t L, K, F;     /* L in {2,3,4}; K steps per block; F = n_filters (multiple of 128, <= 512) */
+  int32_t learntop;    /* 1: learnable diagonal Gaussian prior (flow_builder.py:131-141), 0: N(0,1) (:142-144) */
+  int32_t use_logit;   /* SpecPreprocessing(use_logit=...) */
+  float minval, maxval, alpha;
+  float bn_eps;        /* Keras BatchNormalization epsilon (1e-3) */
+} glowk_config;
+
+typedef struct glowk_handle glowk_handle;
+
+/* Tensors of one flow step in the reference's own layouts (creation order of SURVEY appendix A.3). */
+enum glowk_tensor_id {
+  GLOWK_ACTNORM_LOG_SCALE = 0, /* [c]          ActNorm.log_scale   flow_tfp_bijectors.py:236 */
+  GLOWK_ACTNORM_SHIFT = 1,     /* [c]          ActNorm.shift       :239 */
+  GLOWK_INV1X1_P = 2,          /* [c,c]        Invertible1x1Conv.P :281 */
+  GLOWK_INV1X1_SIGN_S = 3,     /* [c]          sign_S              :285 */
+  GLOWK_INV1X1_L = 4,          /* [c,c]        L                   :289 */
+  GLOWK_INV1X1_LOG_S = 5,      /* [c]          log_S               :291 */
+  GLOWK_INV1X1_U = 6,          /* [c,c]        U                   :293 */
+  GLOWK_CONV1_KERNEL = 7,      /* [3,3,c/2,F]  HWIO                flow_tfk_layers.py:56-60 */
+  GLOWK_CONV1_BIAS = 8,        /* [F] */
+  GLOWK_BN1_GAMMA = 9,         /* [F]          batch_norm_1        :61 */
+  GLOWK_BN1_BETA = 10,
+  GLOWK_BN1_MEAN = 11,
+  GLOWK_BN1_VAR = 12,
+  GLOWK_CONV2_KERNEL = 13,     /* [1,1,F,F]                        :63-65 */
+  GLOWK_CONV2_BIAS = 14,       /* [F] */
+  GLOWK_BN2_GAMMA = 15,        /* [F]          batch_norm_2        :66 */
+  GLOWK_BN2_BETA = 16,
+  GLOWK_BN2_MEAN = 17,
+  GLOWK_BN2_VAR = 18,
+  GLOWK_CONV3_KERNEL = 19,     /* [3,3,F,c]                        :68-70 */
+  GLOWK_CONV3_BIAS = 20,       /* [c] */
+  GLOWK_NUM_STEP_TENSORS = 21,
+  /* prior (level = -1, step = 0), flow_builder.py:131-139 */
+  GLOWK_PRIOR_LOC = 100,       /* [H/2^L, W/2^L, C*4^L] */
+  GLOWK_PRIOR_LOG_SCALE = 101  /* same shape: log of scale_diag (TransformedVariable(.., Exp())) */
+};
+
+/* Arithmetic of the coupling-network contractions (the >95 % of the FLOPs). */
+enum glowk_precision {
+  GLOWK_PREC_F32 = 0,     /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate */
+  GLOWK_PREC_F16X3 = 1    /* error-compensated split: x = hi + lo in fp16, 3 fp16 MFMAs, fp32 accumulate */
+};
+
+int glowk_version(void);
+const char* glowk_last_error(void);
+
+/* --- construction: replaces build_glow (flow_builder.py:60-146) --------------------------------- */
+int glowk_create(const glowk_config* cfg, int device, glowk_handle** out);
+int glowk_destroy(glowk_handle* h);
+/* number of elements tensor `id` of (level, step) holds, or 0 if the id/level is invalid */
+size_t glowk_tensor_size(const glowk_handle* h, int level, int tensor_id);
+/* copy one tensor host -> engine / engine -> host: replaces assigning / reading flow.variables
+ * (train_utils.py:67-68 uses them as the checkpoint root) */
+int glowk_set_tensor(glowk_handle* h, int level, int step, int tensor_id, const float* host, size_t n);
+int glowk_get_tensor(const glowk_handle* h, int level, int step, int tensor_id, float* host, size_t n);
+/* assemble W = P L U and W^-1 (flow_tfp_bijectors.py:300-303,309-315), fold ActNorm into the 1x1,
+ * fold BN into per-channel affines, pack the conv kernels into MFMA operand order, upload. Must be
+ * called after the last glowk_set_tensor and before any compute call. Synchronous. */
+int glowk_finalize_weights(glowk_handle* h);
+int glowk_set_precision(glowk_handle* h, int precision);
+int glowk_get_precision(const glowk_handle* h);
+/* workspace the engine needs for batch N (bytes); glowk_reserve allocates it up front so that no
+ * compute call allocates (required before hipGraph capture) */
+size_t glowk_workspace_bytes(const glowk_handle* h, int N);
+int glowk_reserve(glowk_handle* h, int N);
+
+/* --- the hot path ------------------------------------------------------------------------------- */
+/* Chain([glow, prepro]).forward(x) and its forward_log_det_jacobian (flow_builder.py:127;
+ * flow_glow.py:102-108,119-126 / 176-185,198-209 / 268-282,298-313): x [N,H,W,C] -> z [N,Hl,Wl,Cl],
+ * logdet [N] (may be NULL). */
+int glowk_forward(glowk_handle* h, const float* x_dev, int N, float* z_dev, float* logdet_dev, void* stream);
+/* Chain.inverse(z): z -> x (flow_glow.py:110-117 / 187-196 / 284-296) */
+int glowk_inverse(glowk_handle* h, const float* z_dev, int N, float* x_dev, void* stream);
+/* TransformedDistribution.log_prob(x) (train_glow.py:30, run_basis_sep.py:77): logp [N];
+ * z_dev may be NULL or receives the latent */
+int glowk_log_prob(glowk_handle* h, const float* x_dev, int N, float* logp_dev, float* z_dev, void* stream);
+/* compute_grad_logprob (run_basis_sep.py:73-79): logp [N] and d sum(logp) / dx [N,H,W,C] */
+int glowk_log_prob_grad(glowk_handle* h, const float* x_dev, int N, float* logp_dev, float* dx_dev, void* stream);
+/* TransformedDistribution.sample(n) (train_glow.py:74) with the standard-normal draw supplied by the
+ * caller: eps [N,Hl,Wl,Cl] -> x = chain.inverse(loc + exp(log_scale) * eps) */
+int glowk_sample(glowk_handle* h, const float* eps_dev, int N, float* x_dev, void* stream);
+/* prior.log_prob(z) alone: [N] */
+int glowk_prior_log_prob(glowk_handle* h, const float* z_dev, int N, float* logp_dev, void* stream);
+
+/* --- measurement ---------------------------------------------------------------------------------- */
+/* Per-kernel HIP-event timing of the coupling-network kernel (k_net), recorded on the stream each launch
+ * goes to.  glowk_profile_begin arms it, every later compute call brackets its k_net launches with
+ * events, glowk_profile_end synchronises, sums the elapsed times per level and disarms.  Used by bench.py
+ * for the roofline object; off by default (no events, no overhead). */
+typedef struct glowk_profile {
+  double net_ms[4];          /* summed k_net duration per level */
+  int64_t net_launches[4];
+} glowk_profile;
+int glowk_profile_begin(glowk_handle* h);
+int glowk_profile_end(glowk_handle* h, glowk_profile* out);
+
+/* --- sub-bijectors, as exercised one by one by unittest_flow_models.py:124-186 --------------------- */
+/* Squeeze._forward / _inverse (flow_tfp_bijectors.py:170-180); no handle needed */
+int glowk_squeeze(const float* x_dev, int N, int H, int W, int C, float* y_dev, void* stream);
+int glowk_unsqueeze(const float* y_dev, int N, int h, int w, int c4, float* x_dev, void* stream);
+/* SpecPreprocessing forward / inverse / fldj (flow_tfp_bijectors.py:372-396) */
+int glowk_preprocess_forward(glowk_handle* h, const float* x_dev, int N, float* y_dev, float* logdet_dev, void* stream);
+int glowk_preprocess_inverse(glowk_handle* h, const float* y_dev, int N, float* x_dev, void* stream);
+/* GlowStep forward (+fldj) / inverse (flow_glow.py:24-31) of step `step` of block `level`:
+ * u, y are [N,h,w,c] of that level; logdet [N] may be NULL */
+int glowk_step_forward(glowk_handle* h, int level, int step, const float* u_dev, int N, float* y_dev, float* logdet_dev, void* stream);
+int glowk_step_inverse(glowk_handle* h, int level, int step, const float* y_dev, int N, float* u_dev, void* stream);
+/* ShiftAndLogScaleConvNet.call (flow_tfk_layers.py:73-84) of one step: xb [N,h,w,c/2] -> log_s, t [N,h,w,c/2] */
+int glowk_coupling_net(glowk_handle* h, int level, int step, const float* xb_dev, int N, float* log_s_dev, float* t_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLOWK_H */

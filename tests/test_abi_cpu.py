@@ -1,0 +1,118 @@
+"""CPU-side checks of the drop-in boundary: the library builds for gfx950, loads without a GPU and exports every
+symbol include/glowk.h declares; host-only entry points (create / set / get / destroy) validate their arguments
+the way the reference constructor does.  No compute call is made here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as graft
+from audiosourcesep_amd import _lib
+from audiosourcesep_amd.config import GlowConfig, CONFIG_A, CONFIG_B, CONFIG_YAML
+
+
+@pytest.fixture(scope="module")
+def lib():
+    graft.build()
+    return _lib.load()
+
+
+def header_functions(repo_root):
+    text = open(os.path.join(repo_root, "include", "glowk.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(glowk_[a-z0-9_]+)\s*\(", text))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib, repo_root):
+    declared = header_functions(repo_root)
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.glowk_version() == 100
+
+
+def test_config_struct_matches_header(repo_root):
+    text = open(os.path.join(repo_root, "include", "glowk.h")).read()
+    body = re.search(r"typedef struct glowk_config \{(.*?)\} glowk_config;", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names += [n.strip() for n in decl.split(None, 1)[1].split(",")]
+    assert names == [f[0] for f in _lib.GlowkConfigStruct._fields_]
+    assert ctypes.sizeof(_lib.GlowkConfigStruct) == 12 * 4
+
+
+def test_tensor_ids_match_header(repo_root):
+    text = open(os.path.join(repo_root, "include", "glowk.h")).read()
+    enum = dict((k, int(v)) for k, v in re.findall(r"(GLOWK_[A-Z0-9_]+) = (\d+)", text))
+    for name, tid in _lib.STEP_TENSOR_IDS.items():
+        key = "GLOWK_" + name.replace("nn/", "").replace("/", "_").upper()
+        assert enum[key] == tid, name
+    assert enum["GLOWK_PRIOR_LOC"] == 100 and enum["GLOWK_PRIOR_LOG_SCALE"] == 101
+    assert enum["GLOWK_NUM_STEP_TENSORS"] == len(_lib.STEP_TENSOR_IDS)
+
+
+def _create(lib, cfg_kwargs):
+    c = _lib.GlowkConfigStruct(**cfg_kwargs)
+    h = ctypes.c_void_p()
+    rc = lib.glowk_create(ctypes.byref(c), 0, ctypes.byref(h))
+    return rc, h
+
+
+BASE = dict(H=64, W=64, C=1, L=3, K=2, F=512, learntop=1, use_logit=0, minval=-100.0, maxval=20.0, alpha=1e-10, bn_eps=1e-3)
+
+
+def test_create_validates_like_build_glow(lib):
+    rc, h = _create(lib, dict(BASE, L=5))
+    assert rc != 0 and b"L should be 2, 3 or 4" in lib.glowk_last_error()   # flow_builder.py:76-77
+    rc, h = _create(lib, dict(BASE, H=60))
+    assert rc != 0                                                            # Squeeze asserts even sizes, :165-166
+    rc, h = _create(lib, dict(BASE, F=100))
+    assert rc != 0
+    rc, h = _create(lib, BASE)
+    assert rc == 0
+    # tensor sizes follow the reference's variable shapes for c = 4, 8, 16
+    for level, c in enumerate([4, 8, 16]):
+        assert lib.glowk_tensor_size(h, level, _lib.STEP_TENSOR_IDS["actnorm/log_scale"]) == c
+        assert lib.glowk_tensor_size(h, level, _lib.STEP_TENSOR_IDS["inv1x1/L"]) == c * c
+        assert lib.glowk_tensor_size(h, level, _lib.STEP_TENSOR_IDS["nn/conv1/kernel"]) == 9 * (c // 2) * 512
+        assert lib.glowk_tensor_size(h, level, _lib.STEP_TENSOR_IDS["nn/conv2/kernel"]) == 512 * 512
+        assert lib.glowk_tensor_size(h, level, _lib.STEP_TENSOR_IDS["nn/conv3/kernel"]) == 9 * 512 * c
+    assert lib.glowk_tensor_size(h, -1, 100) == 8 * 8 * 64
+    # host round trip of a tensor; wrong size is refused
+    a = np.arange(16, dtype=np.float32)
+    assert lib.glowk_set_tensor(h, 0, 1, 4, a.ctypes.data_as(_lib._fp), 16) == 0
+    b = np.zeros(16, np.float32)
+    assert lib.glowk_get_tensor(h, 0, 1, 4, b.ctypes.data_as(_lib._fp), 16) == 0
+    np.testing.assert_array_equal(a, b)
+    assert lib.glowk_set_tensor(h, 0, 1, 4, a.ctypes.data_as(_lib._fp), 15) != 0
+    assert lib.glowk_set_tensor(h, 0, 7, 4, a.ctypes.data_as(_lib._fp), 16) != 0   # no such step
+    # compute before finalize is refused (and never silently falls back)
+    assert lib.glowk_log_prob(h, None, 1, None, None, None) != 0
+    assert lib.glowk_workspace_bytes(h, 4) > 0
+    assert lib.glowk_destroy(h) == 0
+
+
+def test_config_shapes_and_flop_model():
+    assert CONFIG_A.level_shapes() == [(16, 16, 4), (8, 8, 8)] and CONFIG_A.latent_shape() == (8, 8, 16)
+    assert CONFIG_B.level_shapes() == [(32, 32, 4), (16, 16, 8), (8, 8, 16)] and CONFIG_B.latent_shape() == (8, 8, 64)
+    assert CONFIG_YAML.level_shapes() == [(48, 32, 4), (24, 16, 8), (12, 8, 16)]
+    # 3.024 / 25.72 / 48.23 GFLOP per tile, 0.1966 / 1.835 / 3.441 MB of activations
+    assert abs(CONFIG_A.flop_per_tile() / 1e9 - 3.024) < 0.01
+    assert abs(CONFIG_B.flop_per_tile() / 1e9 - 25.72) < 0.01
+    assert abs(CONFIG_YAML.flop_per_tile() / 1e9 - 48.23) < 0.02
+    assert abs(CONFIG_B.act_bytes_per_tile() / 1e6 - 1.835) < 0.001
+    with pytest.raises(ValueError):
+        GlowConfig(L=1)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libglowk.so"))
+    with pytest.raises(_lib.GlowkLibraryMissing):
+        _lib.load()

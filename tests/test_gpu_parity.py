@@ -1,0 +1,182 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): index permutations bit exact; fp32 log-prob within 1e-4 relative of the
+fp64 oracle.  The tolerances actually asserted are tighter and written next to each check.
+"""
+import numpy as np
+import pytest
+import torch
+
+from audiosourcesep_amd.config import GlowConfig, CONFIG_A, CONFIG_B
+from audiosourcesep_amd.synthetic import synthetic_params, synthetic_mel_tiles
+from oracle import glowref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from audiosourcesep_amd import engine
+    return engine
+
+
+def make_engine(gpu, cfg, params=None):
+    params = synthetic_params(cfg) if params is None else params
+    eng = gpu.GlowEngine(cfg, device=0)
+    eng.load_params(params)
+    return eng, params
+
+
+def p64(params):
+    return R.cast_params(params, np.float64)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 4, 6, 1), (3, 8, 8, 2), (1, 64, 64, 1), (2, 6, 10, 4)])
+def test_squeeze_unsqueeze_bit_exact(gpu, shape):
+    x = np.arange(np.prod(shape), dtype=np.float32).reshape(shape)
+    y = gpu.squeeze(dev(x)).cpu().numpy()
+    np.testing.assert_array_equal(y, R.squeeze(x))
+    np.testing.assert_array_equal(gpu.unsqueeze(dev(y)).cpu().numpy(), x)
+
+
+@pytest.mark.parametrize("use_logit", [False, True])
+def test_spec_preprocessing(gpu, use_logit):
+    cfg = GlowConfig(H=8, W=8, C=1, L=2, K=1, F=128, use_logit=use_logit, alpha=1e-4)
+    eng, _ = make_engine(gpu, cfg)
+    x = synthetic_mel_tiles(3, cfg)
+    y, ld = eng.preprocess_forward(dev(x))
+    yr = R.spec_pre_forward(x.astype(np.float64), cfg.as_dict())
+    np.testing.assert_allclose(y.cpu().numpy(), yr, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(ld.cpu().numpy(), R.spec_pre_fldj(x.astype(np.float64), cfg.as_dict()), rtol=1e-6)
+    xr = eng.preprocess_inverse(y).cpu().numpy()
+    np.testing.assert_allclose(xr, x, atol=1e-3 if use_logit else 2e-5)
+
+
+@pytest.mark.parametrize("F", [128, 512])
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_coupling_network_per_level(gpu, F, level):
+    """ShiftAndLogScaleConvNet of one step at c = 4 / 8 / 16 against the oracle's convnet (fp64)."""
+    cfg = GlowConfig(H=16, W=32, C=1, L=3, K=1, F=F)
+    eng, params = make_engine(gpu, cfg)
+    h, w, c = cfg.level_shapes()[level]
+    rng = np.random.default_rng(7 + level)
+    xb = rng.standard_normal((3, h, w, c // 2)).astype(np.float32)
+    log_s, t = eng.coupling_net(level, 0, dev(xb))
+    ls_ref, t_ref = R.convnet(xb.astype(np.float64), p64(params), "b%d/s0/" % level, cfg.bn_eps)
+    # fp32 MFMA (k-ordered fmaf chain) vs fp64: ~1e-6 absolute on O(0.1) outputs
+    np.testing.assert_allclose(log_s.cpu().numpy(), ls_ref, atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(t.cpu().numpy(), t_ref, atol=2e-5, rtol=1e-4)
+
+
+def test_coupling_network_ragged_pixel_count(gpu):
+    """Q = N*h*w not a multiple of the 128-pixel workgroup tile nor of the 32-pixel wave tile."""
+    cfg = GlowConfig(H=4, W=12, C=1, L=2, K=1, F=128)   # level 0: 2 x 6 = 12 pixels per sample
+    eng, params = make_engine(gpu, cfg)
+    xb = np.random.default_rng(3).standard_normal((7, 2, 6, 2)).astype(np.float32)   # Q = 84
+    log_s, t = eng.coupling_net(0, 0, dev(xb))
+    ls_ref, t_ref = R.convnet(xb.astype(np.float64), p64(params), "b0/s0/", cfg.bn_eps)
+    np.testing.assert_allclose(log_s.cpu().numpy(), ls_ref, atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(t.cpu().numpy(), t_ref, atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("level", [0, 1])
+def test_glow_step_forward_inverse_logdet(gpu, level):
+    """TestGlowStep (unittest_flow_models.py:164-168) with the real network: y, fldj, and inverse(forward(x))."""
+    cfg = GlowConfig(H=16, W=16, C=1, L=2, K=2, F=128)
+    eng, params = make_engine(gpu, cfg)
+    h, w, c = cfg.level_shapes()[level]
+    u = np.random.default_rng(11).standard_normal((2, h, w, c)).astype(np.float32)
+    for k in range(cfg.K):
+        y, ld = eng.step_forward(level, k, dev(u))
+        y_ref, ld_ref = R.step_forward(u.astype(np.float64), p64(params), "b%d/s%d/" % (level, k), cfg.as_dict())
+        np.testing.assert_allclose(y.cpu().numpy(), y_ref, atol=1e-5, rtol=1e-5)
+        np.testing.assert_allclose(ld.cpu().numpy(), ld_ref, atol=1e-4, rtol=1e-5)
+        ur = eng.step_inverse(level, k, y).cpu().numpy()
+        np.testing.assert_allclose(ur, u, atol=2e-5)
+
+
+CASES = {
+    "tiny_L2": GlowConfig(H=8, W=8, C=1, L=2, K=2, F=128),
+    "tiny_L3_rect": GlowConfig(H=16, W=8, C=1, L=3, K=3, F=128),
+    "L4": GlowConfig(H=16, W=16, C=1, L=4, K=2, F=128),
+    "notop_logit": GlowConfig(H=8, W=8, C=1, L=2, K=2, F=128, learntop=False, use_logit=True, alpha=1e-4),
+    "config_A": CONFIG_A,
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_log_prob_forward_inverse_vs_oracle(gpu, name):
+    cfg = CASES[name]
+    eng, params = make_engine(gpu, cfg)
+    n = 3 if cfg.F == 128 else 2
+    x = synthetic_mel_tiles(n, cfg)
+    pr = p64(params)
+    z_ref, ld_ref = R.bijector_forward(x.astype(np.float64), pr, cfg.as_dict())
+    lp_ref = R.prior_log_prob(z_ref, pr, cfg.as_dict()) + ld_ref
+    z, ld = eng.forward(dev(x))
+    np.testing.assert_allclose(z.cpu().numpy(), z_ref, atol=5e-5, rtol=5e-5)
+    np.testing.assert_allclose(ld.cpu().numpy(), ld_ref, rtol=1e-6)
+    lp, z2 = eng.log_prob(dev(x), return_latent=True)
+    np.testing.assert_array_equal(z2.cpu().numpy(), z.cpu().numpy())
+    # the north-star bar is 1e-4 relative; exact-fp32 MFMA lands several orders below it
+    np.testing.assert_allclose(lp.cpu().numpy(), lp_ref, rtol=1e-6)
+    # Chain.inverse(Chain.forward(x)) == x (unittest_flow_models.py:33-37, with a tolerance: dB range is 120)
+    xr = eng.inverse(z).cpu().numpy()
+    np.testing.assert_allclose(xr, x, atol=5e-3)
+    # and against the oracle's inverse of the oracle's latent
+    np.testing.assert_allclose(eng.inverse(dev(z_ref)).cpu().numpy(), R.bijector_inverse(z_ref, pr, cfg.as_dict()), atol=5e-3)
+    # prior alone
+    np.testing.assert_allclose(eng.prior_log_prob(dev(z_ref)).cpu().numpy(), R.prior_log_prob(z_ref, pr, cfg.as_dict()), rtol=1e-6)
+
+
+def test_sample_round_trip(gpu):
+    cfg = GlowConfig(H=16, W=16, C=1, L=3, K=2, F=128)
+    eng, params = make_engine(gpu, cfg)
+    eps = np.random.default_rng(5).standard_normal((4,) + cfg.latent_shape()).astype(np.float32)
+    xs = eng.sample_from_eps(dev(eps))
+    x_ref = R.sample_from_eps(eps.astype(np.float64), p64(params), cfg.as_dict())
+    np.testing.assert_allclose(xs.cpu().numpy(), x_ref, atol=5e-3)
+    z, _ = eng.forward(xs)
+    np.testing.assert_allclose(z.cpu().numpy(), params["prior/loc"] + np.exp(params["prior/log_scale"]) * eps, atol=2e-4)
+
+
+def test_config_B_full_size_properties(gpu):
+    """BASELINE.json's metric config (64x64, L3, K32, F512): oracle parity at N=2 plus size-independent
+    properties at a larger batch (batch-order equivariance, round trip, determinism)."""
+    cfg = CONFIG_B
+    eng, params = make_engine(gpu, cfg)
+    x = synthetic_mel_tiles(2, cfg)
+    lp_ref = R.log_prob(x.astype(np.float64), p64(params), cfg.as_dict())
+    lp = eng.log_prob(dev(x)).cpu().numpy()
+    np.testing.assert_allclose(lp, lp_ref, rtol=1e-6)
+    xb = synthetic_mel_tiles(37, cfg, seed=99)   # ragged batch: 37 tiles
+    xb[:2] = x
+    lpb, zb = eng.log_prob(dev(xb), return_latent=True)
+    lpb = lpb.cpu().numpy()
+    assert np.all(np.isfinite(lpb))
+    np.testing.assert_array_equal(lpb[:2], lp)                       # a tile's result does not depend on its batch
+    perm = np.random.default_rng(0).permutation(37)
+    np.testing.assert_array_equal(eng.log_prob(dev(xb[perm])).cpu().numpy(), lpb[perm])
+    np.testing.assert_array_equal(eng.log_prob(dev(xb)).cpu().numpy(), lpb)   # deterministic (no atomics)
+    np.testing.assert_allclose(eng.inverse(zb).cpu().numpy(), xb, atol=2e-2)
+
+
+def test_error_behaviour(gpu):
+    from audiosourcesep_amd import _lib
+    with pytest.raises(ValueError):
+        GlowConfig(L=5)                                            # "L should be 2, 3 or 4", flow_builder.py:76-77
+    cfg = GlowConfig(H=8, W=8, C=1, L=2, K=1, F=128)
+    eng, _ = make_engine(gpu, cfg)
+    with pytest.raises(ValueError):
+        eng.log_prob(torch.zeros(2, 8, 4, 1))                      # wrong event shape
+    with pytest.raises(_lib.GlowkError):
+        eng.set_tensor("b0/s0/nn/conv2/kernel", np.zeros(5, np.float32))
+    eng.set_tensor("b0/s0/inv1x1/P", np.zeros((4, 4), np.float32))  # singular permutation
+    with pytest.raises(_lib.GlowkError):
+        eng.finalize()
