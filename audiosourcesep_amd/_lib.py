@@ -59,6 +59,7 @@ SYMBOLS = {
     "glowk_set_tensor": (_i, [_vp, _i, _i, _i, _fp, ctypes.c_size_t]),
     "glowk_get_tensor": (_i, [_vp, _i, _i, _i, _fp, ctypes.c_size_t]),
     "glowk_finalize_weights": (_i, [_vp]),
+    "glowk_actnorm_data_init": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "glowk_set_precision": (_i, [_vp, _i]),
     "glowk_get_precision": (_i, [_vp]),
     "glowk_workspace_bytes": (ctypes.c_size_t, [_vp, _i]),

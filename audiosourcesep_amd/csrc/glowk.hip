@@ -36,6 +36,7 @@ struct StepDev {            // device pointers into the arena
   const float4* K2p = nullptr;
   const float4* K3p = nullptr;
   const float *Afwd = nullptr, *bfwd = nullptr, *Ainv = nullptr, *binv = nullptr, *b3 = nullptr;
+  size_t arena_off = 0;     // offset (floats) of this step's block in the arena
 };
 
 struct Level {
@@ -64,8 +65,9 @@ struct glowk_handle {
   const float* d_log_scale = nullptr;
   // workspace
   int wsN = 0;
-  float *bufA = nullptr, *bufB = nullptr, *bufP = nullptr, *bufZ = nullptr;
+  float *bufA = nullptr, *bufB = nullptr, *bufP = nullptr, *bufZ = nullptr, *bufC = nullptr;
   double* bufLd = nullptr;
+  double* bufStat = nullptr;    // [STAT_BLOCKS][32] partial sums + [32] means
   // HIP-event profiler of k_net
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
@@ -154,9 +156,10 @@ StepLayout step_layout(int c, int F) {
   return L;
 }
 
-// pack one step into dst (host staging of the arena); returns false + message on a singular 1x1
-bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, double* ld_const_out, std::string* err) {
-  const int c = lv.c, F = cfg.F, CI = c / 2, CO = c, NF = F / 32, KS1 = (9 * CI) / 2, NMT = (9 * c + 31) / 32;
+// ActNorm + 1x1 of one step folded into per-pixel affines (forward and inverse), conv3 bias, log-det constant.
+// dst is the step's block of the arena staging; returns false + message on a singular 1x1
+bool pack_affine(const glowk_config& cfg, const Level& lv, int k, float* dst, double* ld_const_out, std::string* err) {
+  const int c = lv.c, F = cfg.F;
   const StepLayout L = step_layout(c, F);
   auto T = [&](int id) -> const float* { return lv.host[id][k].data(); };
 
@@ -193,6 +196,15 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
     dst[L.binv + co] = (float)(-(double)sh[co] * std::exp(-(double)ls[co]));
     dst[L.b3 + co] = T(GLOWK_CONV3_BIAS)[co];
   }
+  return true;
+}
+
+// pack one step into dst (host staging of the arena)
+bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, double* ld_const_out, std::string* err) {
+  const int c = lv.c, F = cfg.F, CI = c / 2, CO = c, NF = F / 32, KS1 = (9 * CI) / 2, NMT = (9 * c + 31) / 32;
+  const StepLayout L = step_layout(c, F);
+  auto T = [&](int id) -> const float* { return lv.host[id][k].data(); };
+  if (!pack_affine(cfg, lv, k, dst, ld_const_out, err)) return false;
 
   // --- BN (inference) folded to y = g*x + d, applied after bias+ReLU (flow_tfk_layers.py:75-78) ---
   const int bn[2][4] = {{GLOWK_BN1_GAMMA, GLOWK_BN1_BETA, GLOWK_BN1_MEAN, GLOWK_BN1_VAR},
@@ -310,7 +322,8 @@ int ensure_ws(glowk_handle* h, int N) {
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipDeviceSynchronize());
   if (h->bufA) { hipFree(h->bufA); hipFree(h->bufB); hipFree(h->bufP); hipFree(h->bufZ); hipFree(h->bufLd); }
-  h->bufA = h->bufB = h->bufP = h->bufZ = nullptr; h->bufLd = nullptr; h->wsN = 0;
+  if (h->bufC) hipFree(h->bufC);
+  h->bufA = h->bufB = h->bufP = h->bufZ = h->bufC = nullptr; h->bufLd = nullptr; h->wsN = 0;
   const size_t E = (size_t)h->cfg.H * h->cfg.W * h->cfg.C;
   HIPCHK(hipMalloc(&h->bufA, (size_t)N * E * 4));
   HIPCHK(hipMalloc(&h->bufB, (size_t)N * E * 4));
@@ -460,6 +473,8 @@ int glowk_destroy(glowk_handle* h) {
   hipSetDevice(h->device);
   if (h->arena) hipFree(h->arena);
   if (h->bufA) { hipFree(h->bufA); hipFree(h->bufB); hipFree(h->bufP); hipFree(h->bufZ); hipFree(h->bufLd); }
+  if (h->bufC) hipFree(h->bufC);
+  if (h->bufStat) hipFree(h->bufStat);
   for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
   delete h;
   return 0;
@@ -545,8 +560,9 @@ int glowk_finalize_weights(glowk_handle* h) {
   for (Level& lv : h->levels) {
     const StepLayout SL = step_layout(lv.c, cfg.F);
     for (int k = 0; k < cfg.K; ++k) {
-      const float* base = h->arena + offs[idx++];
       StepDev& d = lv.dev[k];
+      d.arena_off = offs[idx];
+      const float* base = h->arena + offs[idx++];
       d.K1p = base + SL.K1p; d.ep = base + SL.ep;
       d.K2p = reinterpret_cast<const float4*>(base + SL.K2p);
       d.K3p = reinterpret_cast<const float4*>(base + SL.K3p);
@@ -556,6 +572,120 @@ int glowk_finalize_weights(glowk_handle* h) {
   h->d_loc = cfg.learntop ? h->arena + prior_off : nullptr;
   h->d_log_scale = cfg.learntop ? h->arena + prior_off + pad4(E) : nullptr;
   h->finalized = true;
+  return 0;
+}
+
+namespace {
+constexpr int STAT_BLOCKS = 256;
+
+// one flow step on a materialised tensor: u (cur) -> ActNorm+1x1 -> tmp; network; coupling -> cur
+int run_step_inplace(glowk_handle* h, int lvl, int k, float* cur, float* tmp, int Nl, hipStream_t s) {
+  const Level& lv = h->levels[lvl];
+  const StepDev& sd = lv.dev[k];
+  const int Q = Nl * lv.h * lv.w;
+  CDISPATCH(lv.c, hipLaunchKernelGGL((k_affine<CC>), dim3((Q + 255) / 256), dim3(256), 0, s, (const float*)cur, Q, sd.Afwd, sd.bfwd, tmp));
+  LAUNCHCHK("k_affine");
+  NetArgs na = net_args(h, lv, sd, tmp, lv.c, lv.c / 2, Nl);
+  if (int rc = launch_net(h, lvl, lv.c, h->cfg.F, na, s)) return rc;
+  CoupleArgs ca;
+  ca.vin = tmp; ca.P = h->bufP; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
+  ca.out = cur; ca.out_stride = lv.c; ca.out_off = 0;
+  ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
+  ca.Q = Q; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0;
+  return launch_couple(lv.c, ca, Nl, s);
+}
+
+// re-fold ActNorm+1x1 of one step after its ActNorm tensors changed and upload the small affine block
+int refresh_step_affine(glowk_handle* h, int lvl, int k, hipStream_t s) {
+  Level& lv = h->levels[lvl];
+  const StepLayout SL = step_layout(lv.c, h->cfg.F);
+  std::vector<float> tmp(SL.total - SL.Afwd + SL.Afwd, 0.0f);   // pack_affine indexes from the block start
+  std::string err;
+  double ldc = 0;
+  if (!pack_affine(h->cfg, lv, k, tmp.data(), &ldc, &err)) return fail(err);
+  h->ld_step[(size_t)lvl * h->cfg.K + k] = ldc;
+  HIPCHK(hipMemcpyAsync(h->arena + lv.dev[k].arena_off + SL.Afwd, tmp.data() + SL.Afwd, (SL.total - SL.Afwd) * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+}  // namespace
+
+int glowk_actnorm_data_init(glowk_handle* h, const float* x_dev, int N, int runtime_order, int raw_minibatch_quirk, void* stream) {
+  if (int rc = check_ready(h, N)) return rc;
+  if (!x_dev) return fail("null tensor");
+  hipStream_t s = (hipStream_t)stream;
+  const glowk_config& cfg = h->cfg;
+  const int K = cfg.K, L = cfg.L;
+  const size_t E = (size_t)cfg.H * cfg.W * cfg.C;
+  if (!h->bufC) HIPCHK(hipMalloc(&h->bufC, (size_t)h->wsN * E * 4));
+  if (!h->bufStat) HIPCHK(hipMalloc(&h->bufStat, (size_t)(STAT_BLOCKS + 1) * 32 * 8));
+  // y = SpecPreprocessing.forward(minibatch) (flow_builder.py:121), kept in bufZ
+  hipLaunchKernelGGL(k_pre_only, dim3(N), dim3(256), 0, s, x_dev, (int)E, pre_args(cfg), 0, h->bufZ, (float*)nullptr, 0.0);
+  LAUNCHCHK("k_pre_only");
+  PreArgs nopre = {0, 1, 0, 0};
+  float* blk_in = h->bufC;      // input of the current block (squeezed), kept for the block forward
+  float* cur = h->bufA;
+  float* tmp = h->bufB;
+  const bool quirk = raw_minibatch_quirk && L > 2;
+  std::vector<double> part((size_t)STAT_BLOCKS * 32), mean(32), var(32);
+  for (int lvl = 0; lvl < L; ++lvl) {
+    Level& lv = h->levels[lvl];
+    int Nl = N;
+    if (lvl == 0) {
+      CDISPATCH(lv.c, hipLaunchKernelGGL((k_in<CC>), dim3(N), dim3(256), 0, s, (const float*)h->bufZ, cfg.H, cfg.W, nopre, 0,
+                                         (const float*)nullptr, (const float*)nullptr, blk_in, (double*)nullptr, 0.0));
+      LAUNCHCHK("k_in");
+    } else if (quirk) {
+      // Squeeze([2h,2w,c/4]).forward(raw minibatch): reshape(-1, ...) reinterprets it as more, smaller samples
+      Nl = (int)((size_t)N * E / ((size_t)lv.h * lv.w * lv.c));
+      CDISPATCH(lv.c, hipLaunchKernelGGL((k_in<CC>), dim3(Nl), dim3(256), 0, s, (const float*)h->bufZ, 2 * lv.h, 2 * lv.w, nopre, 0,
+                                         (const float*)nullptr, (const float*)nullptr, blk_in, (double*)nullptr, 0.0));
+      LAUNCHCHK("k_in");
+    } else {
+      // second half of the previous block's output (held in cur), squeezed (flow_glow.py:96-97)
+      const Level& pv = h->levels[lvl - 1];
+      CDISPATCH(pv.c, hipLaunchKernelGGL((k_split<CC>), dim3(N), dim3(256), 0, s, (const float*)cur, pv.h, pv.w, (float*)nullptr, 0, 0, 0, 1,
+                                         (const float*)nullptr, (const float*)nullptr, blk_in));
+      LAUNCHCHK("k_split");
+    }
+    const int Q = Nl * lv.h * lv.w;
+    HIPCHK(hipMemcpyAsync(cur, blk_in, (size_t)Q * lv.c * 4, hipMemcpyDeviceToDevice, s));
+    for (int idx = 0; idx < K; ++idx) {
+      const int k = runtime_order ? K - 1 - idx : idx;
+      double* d_part = h->bufStat;
+      double* d_mean = h->bufStat + (size_t)STAT_BLOCKS * 32;
+      for (int pass = 0; pass < 2; ++pass) {
+        CDISPATCH(lv.c, hipLaunchKernelGGL((k_chan_stats<CC>), dim3(STAT_BLOCKS), dim3(256), 0, s, (const float*)cur, Q,
+                                           pass ? (const double*)d_mean : (const double*)nullptr, d_part));
+        LAUNCHCHK("k_chan_stats");
+        HIPCHK(hipMemcpyAsync(part.data(), d_part, (size_t)STAT_BLOCKS * lv.c * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (int c = 0; c < lv.c; ++c) {
+          double t = 0;
+          for (int b = 0; b < STAT_BLOCKS; ++b) t += part[(size_t)b * lv.c + c];
+          (pass ? var : mean)[c] = t / Q;
+        }
+        if (!pass) HIPCHK(hipMemcpyAsync(d_mean, mean.data(), lv.c * 8, hipMemcpyHostToDevice, s));
+      }
+      for (int c = 0; c < lv.c; ++c) {
+        // std_init = reduce_std + 1e-8 (the reference adds it in fp32); scale = 1/std; shift = -mean/std
+        const double sd_ = (double)((float)std::sqrt(var[c]) + 1e-8f);
+        lv.host[GLOWK_ACTNORM_LOG_SCALE][k][c] = (float)std::log(1.0 / sd_);
+        lv.host[GLOWK_ACTNORM_SHIFT][k][c] = (float)(-mean[c] / sd_);
+      }
+      if (int rc = refresh_step_affine(h, lvl, k, s)) return rc;
+      if (int rc = run_step_inplace(h, lvl, k, cur, tmp, Nl, s)) return rc;   // minibatch_updated = step.forward(...)
+    }
+    if (lvl < L - 1 && !quirk && !runtime_order) {
+      // glow_block.forward(minibatch): the block as tfb.Chain applies it (K-1 .. 0) on the block's own input
+      HIPCHK(hipMemcpyAsync(cur, blk_in, (size_t)Q * lv.c * 4, hipMemcpyDeviceToDevice, s));
+      for (int k = K - 1; k >= 0; --k)
+        if (int rc = run_step_inplace(h, lvl, k, cur, tmp, Nl, s)) return rc;
+    }
+  }
+  h->ld_const = 0.0;
+  for (double v : h->ld_step) h->ld_const += v;
+  HIPCHK(hipStreamSynchronize(s));
   return 0;
 }
 

@@ -493,3 +493,30 @@ __global__ __launch_bounds__(256) void k_prior_sample(const float* __restrict__ 
   const int e = (int)(idx % E);
   z[idx] = loc ? loc[e] + expf(log_scale[e]) * eps[idx] : eps[idx];
 }
+
+// per-channel partial sums for ActNorm's data-dependent init (flow_tfp_bijectors.py:222-234):
+// part[block][c] = sum over this block's pixels of x (mean == null) or (x - mean[c])^2
+template <int C>
+__global__ __launch_bounds__(256) void k_chan_stats(const float* __restrict__ x, int Q, const double* __restrict__ mean,
+                                                   double* __restrict__ part) {
+  __shared__ double red[4][C];
+  double acc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = 0.0;
+  for (int q = blockIdx.x * 256 + threadIdx.x; q < Q; q += gridDim.x * 256) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const double v = (double)x[(size_t)q * C + c];
+      if (mean) { const double d = v - mean[c]; acc[c] += d * d; } else acc[c] += v;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    double v = acc[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < C) part[(size_t)blockIdx.x * C + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}

@@ -77,6 +77,22 @@ class GlowEngine:
         _lib.check(self.lib.glowk_finalize_weights(self.h))
         self._finalized = True
 
+    def actnorm_data_init(self, minibatch, runtime_order=False, raw_minibatch_quirk=True):
+        """ActNorm data-dependent init on the GPU (flow_tfp_bijectors.py:222-234 driven as flow_glow.py:40-49)."""
+        x = self._in(minibatch, self.data_shape)
+        _lib.check(self.lib.glowk_actnorm_data_init(self.h, _ptr(x), x.shape[0], int(runtime_order), int(raw_minibatch_quirk),
+                                                    _stream_ptr()))
+
+    def actnorm_params(self):
+        """{name: ndarray} of every step's ActNorm tensors as the engine currently holds them."""
+        out = {}
+        for lvl in range(self.cfg.L):
+            for k in range(self.cfg.K):
+                for t in ("actnorm/log_scale", "actnorm/shift"):
+                    name = "b%d/s%d/%s" % (lvl, k, t)
+                    out[name] = self.get_tensor(name)
+        return out
+
     def set_precision(self, mode):
         _lib.check(self.lib.glowk_set_precision(self.h, int(mode)))
 

@@ -54,6 +54,23 @@ def synthetic_params(cfg: GlowConfig, seed=2024, dtype=np.float32):
     return {k: np.ascontiguousarray(v, dtype=dtype) for k, v in p.items()}
 
 
+def calibrated_engine(cfg: GlowConfig, device=None, init_tiles=8, seed=2024, init_seed=77):
+    """Engine with the synthetic weights and ActNorm set by data-dependent init on the GPU.
+
+    Random ActNorm tensors make a K=32 flow numerically meaningless (activations grow ~5 % per step and
+    saturate tanh by the third level), so -- like any real Glow -- the benchmark weights get their ActNorm from
+    the reference's own mechanism (flow_tfp_bijectors.py:222-234) on a synthetic minibatch, visiting the steps
+    in the order the forward pass applies them so every step's input is normalised at run time.
+    Returns (engine, params) with params holding the ActNorm values the engine computed (for the oracle)."""
+    from .engine import GlowEngine
+    params = synthetic_params(cfg, seed=seed)
+    eng = GlowEngine(cfg, device=device)
+    eng.load_params(params)
+    eng.actnorm_data_init(synthetic_mel_tiles(init_tiles, cfg, seed=init_seed), runtime_order=True, raw_minibatch_quirk=False)
+    params.update(eng.actnorm_params())
+    return eng, params
+
+
 def synthetic_mel_tiles(n, cfg: GlowConfig, seed=1234, dtype=np.float32):
     """dB mel tiles ``clip(-45 + 18 g, minval, maxval)`` with g unit-variance Gaussian noise AR(1)-smoothed
     (rho 0.96 along time/W, 0.79 along mel/H) -- the statistics of the shipped real tiles

@@ -96,11 +96,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     cfg = {"A": CONFIG_A, "B": CONFIG_B, "YAML": CONFIG_YAML}[args.config]
-    from audiosourcesep_amd.engine import GlowEngine
     from audiosourcesep_amd import _lib
-    params = synthetic_params(cfg)
-    eng = GlowEngine(cfg, device=local_rank)
-    eng.load_params(params)
+    from audiosourcesep_amd.synthetic import calibrated_engine
+    eng, params = calibrated_engine(cfg, device=local_rank)   # synthetic weights + ActNorm data-dependent init
     eng.set_precision(_lib.PREC_F32 if args.precision == "f32" else _lib.PREC_F16X3)
     n = args.batch
     eng.reserve(n)

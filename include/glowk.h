@@ -90,6 +90,20 @@ int glowk_get_tensor(const glowk_handle* h, int level, int step, int tensor_id, 
  * fold BN into per-channel affines, pack the conv kernels into MFMA operand order, upload. Must be
  * called after the last glowk_set_tensor and before any compute call. Synchronous. */
 int glowk_finalize_weights(glowk_handle* h);
+/* ActNorm data-dependent initialisation (flow_tfp_bijectors.py:222-234) as build_glow drives it: the
+ * minibatch x [N,H,W,C] is preprocessed, squeezed and pushed through the steps one by one; before each
+ * step its ActNorm log_scale/shift are set from the per-channel mean / population std (+1e-8) of the
+ * tensor reaching it (GlowBlock.__init__, flow_glow.py:40-49).  All other tensors must be set and
+ * glowk_finalize_weights called first; the new ActNorm tensors can be read back with glowk_get_tensor.
+ *   runtime_order = 0: steps are visited in creation order 0..K-1 exactly like the reference constructor
+ *                      (although tfb.Chain later applies them K-1..0);
+ *   runtime_order = 1: steps are visited in the order the forward pass applies them (K-1..0), which keeps
+ *                      every step's input normalised at run time (used for the synthetic benchmark weights);
+ *   raw_minibatch_quirk = 1: blocks 2+ of the 3- and 4-level graphs are initialised from the RAW preprocessed
+ *                      minibatch reinterpreted by Squeeze's reshape, as GlowBijector_3blocks/_4blocks do
+ *                      (flow_glow.py:162-165,171-174); 0: from the propagated second half.
+ * Synchronous (reads statistics back per step). */
+int glowk_actnorm_data_init(glowk_handle* h, const float* x_dev, int N, int runtime_order, int raw_minibatch_quirk, void* stream);
 int glowk_set_precision(glowk_handle* h, int precision);
 int glowk_get_precision(const glowk_handle* h);
 /* workspace the engine needs for batch N (bytes); glowk_reserve allocates it up front so that no

@@ -409,29 +409,53 @@ def _glorot_uniform(rng, shape):
     return rng.uniform(-lim, lim, size=shape)
 
 
-def init_params(minibatch, cfg, rng, dtype=np.float64):
-    """What build_glow leaves in flow.variables right after construction: ActNorm initialised from the
-    minibatch as it is propagated through the (identity-coupling) steps, QR/LU 1x1 weights, Keras
-    default conv init with conv3 zero (flow_tfk_layers.py:68-70), BN (1,0,0,1), prior (0, log 1).
-    Quirk kept: GlowBijector_3blocks/4blocks hand the *raw* preprocessed minibatch to
-    blocks 2+ (flow_glow.py:162-165,171-174); the reshape in Squeeze reinterprets it as more, smaller
-    samples.  GlowBijector_2blocks propagates properly (:96-99)."""
-    p = {}
-    F, K, L = cfg["F"], cfg["K"], cfg["L"]
-    mb0 = spec_pre_forward(np.asarray(minibatch, dtype=dtype), cfg)
+def actnorm_data_init(p, minibatch, cfg, runtime_order=False, raw_minibatch_quirk=True):
+    """Fill every step's ActNorm tensors of ``p`` (in place) the way the reference constructors do
+    (flow_builder.py:121-125, flow_glow.py:40-49,93-99,153-174): the preprocessed minibatch is squeezed and
+    pushed through the steps; each ActNorm is initialised (flow_tfp_bijectors.py:222-234) from the tensor that
+    reaches it, then ``minibatch_updated = glow_step.forward(minibatch_updated)`` (:48).
+    runtime_order=False visits steps in creation order 0..K-1 like the reference; True visits them in the
+    order tfb.Chain applies them (K-1..0).  Quirk kept when raw_minibatch_quirk:
+    GlowBijector_3blocks/4blocks hand the *raw* preprocessed minibatch to blocks 2+
+    (flow_glow.py:162-165,171-174); Squeeze's reshape(-1, ...) reinterprets it as more, smaller samples.
+    GlowBijector_2blocks propagates properly (:96-99)."""
+    K, L = cfg["K"], cfg["L"]
+    dt = p["b0/s0/inv1x1/P"].dtype
+    mb0 = spec_pre_forward(np.asarray(minibatch, dtype=dt), cfg)
     shapes = level_shapes(cfg)
-    mb_prop = mb0
+    quirk = raw_minibatch_quirk and L > 2
+    prev_out = None
     for lvl in range(L):
         h, w, c = shapes[lvl]
-        if lvl == 0 or L == 2:
-            src = mb_prop
+        if lvl == 0:
+            src = mb0
+        elif quirk:
+            src = mb0.reshape(-1, h * 2, w * 2, c // 4)
         else:
-            src = mb0.reshape(-1, h * 2, w * 2, c // 4)  # raw minibatch reinterpreted by Squeeze's reshape(-1, ...)
+            src = prev_out[..., prev_out.shape[-1] // 2:]
         u = squeeze(src)
+        for idx in range(K):
+            k = K - 1 - idx if runtime_order else idx
+            pre = "b%d/s%d/" % (lvl, k)
+            p[pre + "actnorm/log_scale"], p[pre + "actnorm/shift"] = actnorm_init(u)
+            u, _ = step_forward(u, p, pre, cfg)
+        if lvl < L - 1 and not quirk:
+            if runtime_order:
+                prev_out = u
+            else:
+                prev_out, _ = block_forward(src, p, lvl, cfg)   # block.forward(minibatch) (flow_glow.py:96,159)
+    return p
+
+
+def init_params(minibatch, cfg, rng, dtype=np.float64):
+    """What build_glow leaves in flow.variables right after construction: QR/LU 1x1 weights, Keras default
+    conv init with conv3 zero (flow_tfk_layers.py:68-70), BN (1,0,0,1), prior (0, log 1), and ActNorm
+    initialised from the minibatch (actnorm_data_init, reference order and quirk)."""
+    p = {}
+    F, K, L = cfg["F"], cfg["K"], cfg["L"]
+    for lvl, (h, w, c) in enumerate(level_shapes(cfg)):
         for k in range(K):
             pre = "b%d/s%d/" % (lvl, k)
-            ls, sh = actnorm_init(u)
-            p[pre + "actnorm/log_scale"], p[pre + "actnorm/shift"] = ls, sh
             w1 = inv1x1_init(c, rng)
             for name in ("P", "sign_S", "L", "log_S", "U"):
                 p[pre + "inv1x1/" + name] = w1[name].astype(dtype)
@@ -447,14 +471,7 @@ def init_params(minibatch, cfg, rng, dtype=np.float64):
                 p[pre + "nn/%s/beta" % bn] = np.zeros(F, dtype)
                 p[pre + "nn/%s/mean" % bn] = np.zeros(F, dtype)
                 p[pre + "nn/%s/var" % bn] = np.ones(F, dtype)
-            # minibatch_updated = glow_step.forward(minibatch_updated) (flow_glow.py:48); coupling is the
-            # identity at init (conv3 zero => log_s = tanh(0) = 0, t = 0)
-            u, _ = step_forward(u, p, pre, cfg)
-        if lvl < L - 1:
-            # block.forward(minibatch) then keep the second half (flow_glow.py:96-97,159-160,168-169)
-            o, _ = block_forward(mb_prop, p, lvl, cfg)
-            mb_prop = o[..., o.shape[-1] // 2:]
     Hl, Wl, Cl = latent_shape(cfg)
     p["prior/loc"] = np.zeros((Hl, Wl, Cl), dtype)
     p["prior/log_scale"] = np.zeros((Hl, Wl, Cl), dtype)
-    return p
+    return actnorm_data_init(p, minibatch, cfg, runtime_order=False, raw_minibatch_quirk=True)

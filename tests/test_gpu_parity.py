@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from audiosourcesep_amd.config import GlowConfig, CONFIG_A, CONFIG_B
-from audiosourcesep_amd.synthetic import synthetic_params, synthetic_mel_tiles
+from audiosourcesep_amd.synthetic import synthetic_params, synthetic_mel_tiles, calibrated_engine
 from oracle import glowref as R
 
 pytestmark = pytest.mark.gpu
@@ -21,8 +21,12 @@ def gpu():
     return engine
 
 
-def make_engine(gpu, cfg, params=None):
-    params = synthetic_params(cfg) if params is None else params
+def make_engine(gpu, cfg, calibrate=True):
+    """Engine + the parameter dict the oracle must use.  calibrate: ActNorm from GPU data-dependent init
+    (runtime order), read back from the engine so that the oracle runs on identical weights."""
+    if calibrate:
+        return calibrated_engine(cfg, device=0)
+    params = synthetic_params(cfg)
     eng = gpu.GlowEngine(cfg, device=0)
     eng.load_params(params)
     return eng, params
@@ -99,6 +103,49 @@ def test_glow_step_forward_inverse_logdet(gpu, level):
         np.testing.assert_allclose(ld.cpu().numpy(), ld_ref, atol=1e-4, rtol=1e-5)
         ur = eng.step_inverse(level, k, y).cpu().numpy()
         np.testing.assert_allclose(ur, u, atol=2e-5)
+
+
+@pytest.mark.parametrize("L,runtime_order,quirk", [(2, False, True), (3, False, True), (3, True, False), (3, False, False),
+                                                   (4, False, True)])
+def test_actnorm_data_dependent_init(gpu, L, runtime_order, quirk):
+    """ActNorm init on the GPU == the oracle's restatement of GlowBlock.__init__ / GlowBijector_*blocks.__init__
+    (flow_glow.py:40-49,93-99,153-174), reference order + raw-minibatch quirk included."""
+    s = 2 ** L
+    cfg = GlowConfig(H=2 * s, W=4 * s, C=1, L=L, K=3, F=128)
+    params = synthetic_params(cfg)
+    eng = gpu.GlowEngine(cfg, device=0)
+    eng.load_params(params)
+    mb = synthetic_mel_tiles(6, cfg, seed=5)
+    eng.actnorm_data_init(dev(mb), runtime_order=runtime_order, raw_minibatch_quirk=quirk)
+    got = eng.actnorm_params()
+    ref = R.actnorm_data_init(p64(params), mb.astype(np.float64), cfg.as_dict(), runtime_order=runtime_order,
+                              raw_minibatch_quirk=quirk)
+    for name, val in got.items():
+        np.testing.assert_allclose(val, ref[name], rtol=2e-4, atol=2e-4, err_msg=name)
+    # the engine then evaluates with the tensors it reports
+    params.update(got)
+    x = synthetic_mel_tiles(2, cfg)
+    np.testing.assert_allclose(eng.log_prob(dev(x)).cpu().numpy(), R.log_prob(x.astype(np.float64), p64(params), cfg.as_dict()),
+                               rtol=1e-6)
+
+
+def test_build_time_init_normalises(gpu):
+    """Reference-order init with zero conv3 (what build_glow does): the first-created ActNorm of block 1 sees the
+    squeezed minibatch and normalises it to zero mean / unit variance per channel."""
+    cfg = GlowConfig(H=16, W=16, C=1, L=2, K=2, F=128)
+    params = synthetic_params(cfg)
+    for k in list(params):
+        if "conv3" in k:
+            params[k] = np.zeros_like(params[k])
+    eng = gpu.GlowEngine(cfg, device=0)
+    eng.load_params(params)
+    mb = synthetic_mel_tiles(8, cfg, seed=6)
+    eng.actnorm_data_init(dev(mb))
+    got = eng.actnorm_params()
+    u = R.squeeze(R.spec_pre_forward(mb.astype(np.float64), cfg.as_dict()))
+    a = R.actnorm_forward(u, got["b0/s0/actnorm/log_scale"].astype(np.float64), got["b0/s0/actnorm/shift"].astype(np.float64))
+    np.testing.assert_allclose(a.mean(axis=(0, 1, 2)), 0, atol=1e-5)
+    np.testing.assert_allclose(a.std(axis=(0, 1, 2)), 1, atol=1e-5)
 
 
 CASES = {
