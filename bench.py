@@ -49,22 +49,35 @@ def net_flop_per_pixel(c, F):
     return 2 * (9 * (c // 2) * F + F * F + 9 * F * c)
 
 
-def cpu_baseline(cfg, params, sample_tiles, passes):
-    """Oracle port on the host cores: torch-CPU fp32, one network evaluation per step (deduplicated graph)."""
+def host_threads():
+    """Threads the CPU baseline may use: the cgroup/affinity share, capped at 16 (one GPU's share of the host)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
+def cpu_baseline(cfg, params, budget_s=20.0):
+    """Oracle port on the host cores: torch-CPU fp32, one network evaluation per step (deduplicated graph).
+    Bounded sample: one tile is timed first, then as many tiles as fit the time budget (1..16)."""
     from oracle import glowref_torch as RT
-    torch.set_num_threads(os.cpu_count() or 1)
+    threads = host_threads()
+    torch.set_num_threads(threads)
     p = RT.to_torch(params, torch.float32)
-    x = torch.from_numpy(synthetic_mel_tiles(sample_tiles, cfg, seed=4321))
+    x = torch.from_numpy(synthetic_mel_tiles(16, cfg, seed=4321))
     with torch.no_grad():
-        RT.log_prob(x[:1], p, cfg.as_dict())  # warm-up (oneDNN primitive creation)
         t0 = time.perf_counter()
-        for _ in range(passes):
-            RT.log_prob(x, p, cfg.as_dict())
+        RT.log_prob(x[:1], p, cfg.as_dict())          # also warms up primitive creation
+        t1 = time.perf_counter() - t0
+        tiles = int(max(1, min(16, budget_s / max(t1, 1e-3))))
+        t0 = time.perf_counter()
+        RT.log_prob(x[:tiles], p, cfg.as_dict())
         dt = time.perf_counter() - t0
     return {
-        "value": sample_tiles * passes / dt, "unit": "passes/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": "%d tiles x %d passes of the same config, torch-CPU fp32 restatement (oracle/glowref_torch.py), %.1f s"
-                  % (sample_tiles, passes, dt),
+        "value": tiles / dt, "unit": "passes/s", "cores": threads, "kind": "port",
+        "sample": "%d tiles x 1 pass of the same config, torch-CPU fp32 restatement of the reference graph "
+                  "(oracle/glowref_torch.py; not TensorFlow), %.1f s after a %.1f s one-tile warm-up" % (tiles, dt, t1),
     }
 
 
@@ -77,8 +90,7 @@ def main():
     ap.add_argument("--config", default="B", choices=["A", "B", "YAML"])
     ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tiles", type=int, default=8)
-    ap.add_argument("--cpu-passes", type=int, default=2)
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline sample")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,7 +185,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, params, args.cpu_tiles, args.cpu_passes)
+            out["cpu_baseline"] = cpu_baseline(cfg, params, args.cpu_budget)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

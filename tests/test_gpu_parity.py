@@ -125,8 +125,10 @@ def test_actnorm_data_dependent_init(gpu, L, runtime_order, quirk):
     # the engine then evaluates with the tensors it reports
     params.update(got)
     x = synthetic_mel_tiles(2, cfg)
+    # reference-order / quirk inits leave the run-time flow un-normalised (|log_prob| ~ 1e10, ill conditioned):
+    # the north-star bar (1e-4 relative) applies, the runtime-order case is held to 1e-6
     np.testing.assert_allclose(eng.log_prob(dev(x)).cpu().numpy(), R.log_prob(x.astype(np.float64), p64(params), cfg.as_dict()),
-                               rtol=1e-6)
+                               rtol=1e-6 if runtime_order else 1e-4)
 
 
 def test_build_time_init_normalises(gpu):
