@@ -1,0 +1,228 @@
+"""Host-side mirror of the objects ``build_glow`` hands back in the reference.
+
+``GlowFlow``            <-> ``tfd.TransformedDistribution(prior, tfb.Invert(tfb.Chain([glow, prepro])))``
+                             (flow_builder.py:127-144): ``log_prob``, ``sample``, ``bijector``, ``variables``.
+``ChainBijector``       <-> ``tfb.Chain([GlowBijector_{2,3,4}blocks, SpecPreprocessing])`` (data -> latent).
+``InvertedBijector``    <-> ``tfb.Invert(chain)``: what ``flow.bijector`` is in the reference (latent -> data).
+``GlowStepView``        <-> one ``GlowStep`` (flow_glow.py:9-31), addressed as ``chain.glow.blocks[l].steps[k]``.
+
+Nothing here computes: every method forwards to the C ABI through :class:`audiosourcesep_amd.engine.GlowEngine`.
+"""
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+class Variable:
+    """Named view of one engine tensor (stands in for ``tf.Variable``: ``.name``, ``.numpy()``, ``.assign()``)."""
+
+    def __init__(self, engine, name, shape, trainable):
+        self._engine, self.name, self.shape, self.trainable = engine, name, tuple(shape), trainable
+
+    def numpy(self):
+        return self._engine.get_tensor(self.name).reshape(self.shape)
+
+    def assign(self, value):
+        value = np.asarray(value, dtype=np.float32)
+        if value.shape != self.shape:
+            raise ValueError("%s: expected shape %s, got %s" % (self.name, self.shape, value.shape))
+        self._engine.set_tensor(self.name, value)   # re-packed lazily before the next compute call
+        return self
+
+    def __repr__(self):
+        return "<Variable %s shape=%s trainable=%s>" % (self.name, self.shape, self.trainable)
+
+
+def _step_variable_shapes(c, F):
+    """Creation order inside GlowStep.__init__ (flow_glow.py:15-20)."""
+    ci = c // 2
+    return [
+        ("actnorm/log_scale", (c,), True), ("actnorm/shift", (c,), True),
+        ("inv1x1/P", (c, c), False), ("inv1x1/sign_S", (c,), False),
+        ("inv1x1/L", (c, c), True), ("inv1x1/log_S", (c,), True), ("inv1x1/U", (c, c), True),
+        ("nn/conv1/kernel", (3, 3, ci, F), True), ("nn/conv1/bias", (F,), True),
+        ("nn/bn1/gamma", (F,), True), ("nn/bn1/beta", (F,), True), ("nn/bn1/mean", (F,), False), ("nn/bn1/var", (F,), False),
+        ("nn/conv2/kernel", (1, 1, F, F), True), ("nn/conv2/bias", (F,), True),
+        ("nn/bn2/gamma", (F,), True), ("nn/bn2/beta", (F,), True), ("nn/bn2/mean", (F,), False), ("nn/bn2/var", (F,), False),
+        ("nn/conv3/kernel", (3, 3, F, c), True), ("nn/conv3/bias", (c,), True),
+    ]
+
+
+class _LogProbFn(torch.autograd.Function):
+    """``log_prob`` with reverse mode wrt the input: what ``tf.GradientTape`` gives compute_grad_logprob
+    (run_basis_sep.py:73-79).  Forward and input gradient both come from ``glowk_log_prob_grad``."""
+
+    @staticmethod
+    def forward(ctx, x, engine):
+        lp, dx = engine.log_prob_grad(x.detach())
+        ctx.save_for_backward(dx)
+        return lp
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (dx,) = ctx.saved_tensors
+        return dx * grad_out.reshape(-1, 1, 1, 1), None
+
+
+class CouplingNetView:
+    """``AffineCouplingLayerSplit.shift_and_log_scale_fn`` of one step (flow_tfp_bijectors.py:132)."""
+
+    def __init__(self, engine, level, step):
+        self._e, self._l, self._k = engine, level, step
+
+    def __call__(self, xb):
+        return self._e.coupling_net(self._l, self._k, xb)
+
+
+class GlowStepView:
+    """One GlowStep: ActNorm -> Invertible1x1Conv -> AffineCouplingLayerSplit (flow_glow.py:21-22)."""
+
+    def __init__(self, engine, level, step):
+        self._e, self.level, self.step = engine, level, step
+        self.shift_and_log_scale_fn = CouplingNetView(engine, level, step)
+
+    def forward(self, x):
+        return self._e.step_forward(self.level, self.step, x)[0]
+
+    def inverse(self, y):
+        return self._e.step_inverse(self.level, self.step, y)
+
+    def forward_log_det_jacobian(self, x, event_ndims=3):
+        return self._e.step_forward(self.level, self.step, x)[1]
+
+    def inverse_log_det_jacobian(self, y, event_ndims=3):
+        return -self._e.step_forward(self.level, self.step, self.inverse(y))[1]
+
+
+class GlowBlockView:
+    """One GlowBlock (flow_glow.py:34-77): squeeze + K steps; ``steps[k]`` is ``glowStep_k``."""
+
+    def __init__(self, engine, level):
+        self.level = level
+        self.steps = [GlowStepView(engine, level, k) for k in range(engine.cfg.K)]
+        h, w, c = engine.cfg.level_shapes()[level]
+        self.event_shape_out = (h, w, c)
+
+
+class GlowView:
+    def __init__(self, engine):
+        self.blocks = [GlowBlockView(engine, l) for l in range(engine.cfg.L)]
+
+
+class ChainBijector:
+    """data -> latent: ``tfb.Chain([glow, prepro])`` (flow_builder.py:127)."""
+
+    def __init__(self, engine):
+        self._e = engine
+        self.glow = GlowView(engine)
+
+    def forward(self, x):
+        return self._e.forward(x, with_logdet=False)
+
+    def inverse(self, z):
+        return self._e.inverse(z)
+
+    def forward_log_det_jacobian(self, x, event_ndims=3):
+        return self._e.forward(x)[1]
+
+    def inverse_log_det_jacobian(self, z, event_ndims=3):
+        return -self._e.forward(self._e.inverse(z))[1]
+
+    def forward_event_shape(self, input_shape):
+        H, W, C = input_shape
+        s = 2 ** self._e.cfg.L
+        return (H // s, W // s, C * s * s)       # flow_glow.py:128-134,211-217,315-321
+
+    def inverse_event_shape(self, output_shape):
+        H, W, C = output_shape
+        s = 2 ** self._e.cfg.L
+        return (H * s, W * s, C // (s * s))
+
+
+class InvertedBijector:
+    """``tfb.Invert(chain)`` (flow_builder.py:129): forward is latent -> data."""
+
+    def __init__(self, chain):
+        self.bijector = chain
+
+    def forward(self, z):
+        return self.bijector.inverse(z)
+
+    def inverse(self, x):
+        return self.bijector.forward(x)
+
+    def forward_log_det_jacobian(self, z, event_ndims=3):
+        return self.bijector.inverse_log_det_jacobian(z, event_ndims)
+
+    def inverse_log_det_jacobian(self, x, event_ndims=3):
+        return self.bijector.forward_log_det_jacobian(x, event_ndims)
+
+    def forward_event_shape(self, s):
+        return self.bijector.inverse_event_shape(s)
+
+    def inverse_event_shape(self, s):
+        return self.bijector.forward_event_shape(s)
+
+
+class GlowFlow:
+    """The distribution object the reference's scripts hold (``flow``)."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        self.cfg = engine.cfg
+        self.chain = ChainBijector(engine)
+        self.bijector = InvertedBijector(self.chain)
+        self.event_shape = engine.data_shape
+        cfg = self.cfg
+        vs = []
+        for lvl, (h, w, c) in enumerate(cfg.level_shapes()):
+            for k in range(cfg.K):
+                for name, shape, trainable in _step_variable_shapes(c, cfg.F):
+                    vs.append(Variable(engine, "b%d/s%d/%s" % (lvl, k, name), shape, trainable))
+        if cfg.learntop:
+            vs.append(Variable(engine, "prior/loc", cfg.latent_shape(), True))
+            vs.append(Variable(engine, "prior/log_scale", cfg.latent_shape(), True))
+        self._variables = tuple(vs)
+
+    # --- tfd.Distribution surface ------------------------------------------------------------------
+    def log_prob(self, x):
+        """[N,H,W,C] -> [N] (train_glow.py:30; run_basis_sep.py:77).  If ``x.requires_grad`` the result carries the
+        input gradient (BASIS contract)."""
+        if torch.is_tensor(x) and x.requires_grad:
+            return _LogProbFn.apply(x, self.engine)
+        return self.engine.log_prob(x)
+
+    def sample(self, n, seed=None):
+        """n -> [n,H,W,C] (train_glow.py:74): prior draw on the GPU (torch generator), chain.inverse in the engine."""
+        g = None
+        if seed is not None:
+            g = torch.Generator(device=self.engine.device)
+            g.manual_seed(int(seed))
+        eps = torch.randn((int(n),) + tuple(self.cfg.latent_shape()), device=self.engine.device, dtype=torch.float32, generator=g)
+        return self.engine.sample_from_eps(eps)
+
+    @property
+    def variables(self):
+        return self._variables
+
+    @property
+    def trainable_variables(self):
+        return tuple(v for v in self._variables if v.trainable)
+
+    # --- checkpoint: own container (TF-checkpoint import is section 8(f-2)) ------------
+    def state_dict(self):
+        return {v.name: v.numpy() for v in self._variables}
+
+    def load_state_dict(self, state):
+        for v in self._variables:
+            if v.name in state:
+                v.assign(np.asarray(state[v.name]).reshape(v.shape))
+        self.engine.finalize()
+
+    def save(self, path):
+        np.savez(path, **self.state_dict())
+
+    def restore(self, path):
+        with np.load(path) as f:
+            self.load_state_dict({k: f[k] for k in f.files})
