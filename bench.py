@@ -120,11 +120,12 @@ def main():
     lp = torch.empty(n, device="cuda", dtype=torch.float32)
     total = torch.zeros(1, device="cuda", dtype=torch.float64)
 
+    from audiosourcesep_amd.distributed import sharded_log_prob
+
     def step():
-        eng.log_prob(x, out=lp)
-        total.copy_(lp.sum(dtype=torch.float64))
-        if dist is not None:
-            dist.all_reduce(total)   # summed log-likelihood over all shards (RCCL over xGMI)
+        # local shard on this GPU, then ONE all-reduce of the fp64 summed log-likelihood (RCCL over xGMI)
+        _, tot = sharded_log_prob(lambda xx: eng.log_prob(xx, out=lp), x)
+        total.copy_(tot)
 
     for _ in range(args.warmup):
         step()
