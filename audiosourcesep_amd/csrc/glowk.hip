@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -35,6 +36,7 @@ struct StepDev {            // device pointers into the arena
   const float* ep = nullptr;
   const float4* K2p = nullptr;
   const float4* K3p = nullptr;
+  const float4* R0p = nullptr;
   const float *Afwd = nullptr, *bfwd = nullptr, *Ainv = nullptr, *binv = nullptr, *b3 = nullptr;
   size_t arena_off = 0;     // offset (floats) of this step's block in the arena
 };
@@ -136,7 +138,8 @@ inline int rho(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 inline size_t pad4(size_t n) { return (n + 3) & ~size_t(3); }
 
 struct StepLayout {
-  size_t K1p, ep, K2p, K3p, Afwd, bfwd, Ainv, binv, b3, total;
+  size_t K1p, ep, K2p, K3p, R0p, Afwd, bfwd, Ainv, binv, b3, total;
+  size_t slot0, k1f0;  // floats per slot of k_net_f32's ring image; floats of its conv1 part (0: not in the ring)
 };
 
 StepLayout step_layout(int c, int F) {
@@ -147,6 +150,13 @@ StepLayout step_layout(int c, int F) {
   L.ep = o; o += pad4((size_t)6 * F);
   L.K2p = o; o += (size_t)NF * NF * 1024;
   L.K3p = o; o += (size_t)NMT * NF * 1024;
+  {
+    size_t k1f = (size_t)(((size_t)KS1 * 256 + 1023) / 1024) * 256;                 // conv1 MFMA operands [KS1][64], 1-KiB pieces
+    if (2 * ((size_t)NF * 1024 + k1f) * 4 + (size_t)6 * F * 4 > 160 * 1024) k1f = 0;  // Ring1::K1_IN_RING == false
+    L.k1f0 = k1f;
+    L.slot0 = (size_t)NF * 1024 + k1f;
+    L.R0p = o; o += (size_t)(NF + NMT) * L.slot0;
+  }
   L.Afwd = o; o += pad4((size_t)c * c);
   L.bfwd = o; o += pad4(c);
   L.Ainv = o; o += pad4((size_t)c * c);
@@ -253,21 +263,26 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
             }
             dst[L.K3p + idx] = v;
           }
+  // ring image of k_net_f32 (Ring1): slot c < NF = K2 chunk c | conv1 MFMA operands of hidden block c+1; slot NF+mt = K3 chunk mt
+  if (L.slot0) {
+    const size_t mainf = (size_t)NF * 1024, k1n = (size_t)KS1 * 64;
+    for (int c2 = 0; c2 < NF + NMT; ++c2) {
+      float* slot = dst + L.R0p + (size_t)c2 * L.slot0;
+      const float* main_src = (c2 < NF) ? dst + L.K2p + (size_t)c2 * mainf : dst + L.K3p + (size_t)(c2 - NF) * mainf;
+      std::memcpy(slot, main_src, mainf * 4);
+      const int k1blk = (c2 < NF) ? (c2 + 1) % NF : 0;
+      if (L.k1f0) std::memcpy(slot + mainf, dst + L.K1p + (size_t)k1blk * k1n, k1n * 4);
+    }
+  }
   return true;
 }
 
 // ---- launch helpers ------------------------------------------------------------------------------
 template <int CI, int NF>
 int launch_net_t(const NetArgs& a, hipStream_t s) {
-  constexpr int F = NF * 32;
-  constexpr size_t lds = (size_t)2 * NF * 256 * 16 + (size_t)6 * F * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_net_f32<CI, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
-  const int grid = (a.Q + 127) / 128;
-  hipLaunchKernelGGL((k_net_f32<CI, NF>), dim3(grid), dim3(256), lds, s, a);
+  static_assert(Ring1<CI, NF>::FITS, "ring does not fit the LDS");
+  const int ntiles = (a.Q + 127) / 128;
+  hipLaunchKernelGGL((k_net_f32<CI, NF>), dim3(ntiles), dim3(256), 0, s, a);
   LAUNCHCHK("k_net_f32");
   return 0;
 }
@@ -346,7 +361,7 @@ NetArgs net_args(glowk_handle* h, const Level& lv, const StepDev& sd, const floa
   NetArgs a;
   a.vin = vin; a.in_stride = in_stride; a.in_off = in_off;
   a.Q = N * lv.h * lv.w; a.h = lv.h; a.w = lv.w;
-  a.K1p = sd.K1p; a.ep = sd.ep; a.K2p = sd.K2p; a.K3p = sd.K3p; a.P = h->bufP;
+  a.K1p = sd.K1p; a.ep = sd.ep; a.K2p = sd.K2p; a.K3p = sd.K3p; a.R0p = sd.R0p; a.P = h->bufP;
   return a;
 }
 
@@ -566,6 +581,7 @@ int glowk_finalize_weights(glowk_handle* h) {
       d.K1p = base + SL.K1p; d.ep = base + SL.ep;
       d.K2p = reinterpret_cast<const float4*>(base + SL.K2p);
       d.K3p = reinterpret_cast<const float4*>(base + SL.K3p);
+      d.R0p = reinterpret_cast<const float4*>(base + SL.R0p);
       d.Afwd = base + SL.Afwd; d.bfwd = base + SL.bfwd; d.Ainv = base + SL.Ainv; d.binv = base + SL.binv; d.b3 = base + SL.b3;
     }
   }

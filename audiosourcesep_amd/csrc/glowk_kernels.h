@@ -13,8 +13,14 @@
 // transposed orientation the 32x32 accumulator tile of one GEMM (column = pixel on the lane, rows in the
 // 16 registers) IS the B operand of the next GEMM's v_mfma_f32_32x32x2_f32 (k pair = rows rho, rho+4), so
 // the 512-channel hiddens never leave the register file: no LDS round trip, no HBM traffic.
-// Weights stream global -> LDS by LDS-DMA (global_load_lds_dwordx4), double buffered, 64 KiB chunks,
-// pre-packed on the host into the exact lane order the MFMA A operand wants (ds_read_b128, conflict free).
+// Weights stream global -> LDS by LDS-DMA (global_load_lds_dwordx4) through a two-slot ring of 64 KiB chunks that also
+// carries conv1's operands, pre-packed on the host into the exact lane order the MFMA A operand wants
+// (ds_read_b128, conflict free).  Three rules learned on the hardware shape this kernel:
+//  1. the ring slots are distinct static __shared__ objects with static roles, otherwise hipcc puts s_waitcnt vmcnt(0)
+//     between every global_load_lds and the next ds_read and the DMA never overlaps the MFMAs;
+//  2. no VGPR-destination memory instruction (global load, scratch reload) may be issued while a DMA is in flight:
+//     vmcnt is an in-order counter, each such load is serialised behind the whole DMA;
+//  3. fp32-input MFMA and the FP32 VALU share one datapath: VALU FMAs do not hide under v_mfma_f32_32x32x2_f32.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -35,6 +41,7 @@ struct NetArgs {
   const float* ep;       // [6][F]: b1, g1, d1, b2, g2, d2   (BN folded: g = gamma/sqrt(var+eps), d = beta - mean*g)
   const float4* K2p;     // [NF fi][16 r][NF/4][64 lanes] float4 (4 consecutive fo)
   const float4* K3p;     // [NMT][NF fo][4 r4][64 lanes] float4 (4 consecutive r)
+  const float4* R0p;     // ring image (Ring1): [NF + NMT] slots
   float* P;              // [9*CO][Q]
 };
 
@@ -43,47 +50,126 @@ __device__ __forceinline__ void glds16(const float4* src_lane, float4* lds_wave_
   __builtin_amdgcn_global_load_lds(GLOWK_GPTR(src_lane), GLOWK_LPTR(lds_wave_base), 16, 0, 0);
 }
 
-template <int NPER>  // float4 per thread; chunk = NPER*256 float4, copied linearly
-__device__ __forceinline__ void stage_chunk(const float4* __restrict__ src, float4* dst, int tid) {
-  const int wbase = tid & ~63;
-  const int lane = tid & 63;
+__device__ __forceinline__ const char* uniform_ptr(const void* p) {   // force a wave-uniform pointer into SGPRs
+  const unsigned long long b = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+
+// The two ring slots are DISTINCT static __shared__ arrays and every step names its slot statically (template
+// parity): LLVM's waitcnt pass then knows that a ds_read of one slot cannot alias the LDS-DMA in flight into the
+// other one.  With a single array (or a runtime-selected slot) it inserts s_waitcnt vmcnt(0) in front of the first
+// ds_read after every global_load_lds, i.e. the weight DMA never overlaps the MFMAs (measured: 158 vs 127 us/tile).
+template <int P>
+__device__ __forceinline__ float4* ring_slot(float4* s0, float4* s1) { return P ? s1 : s0; }
+
+// geometry of k_net_f32's ring: slot = conv2 / conv3 chunk (NF * 4 KiB) + conv1's MFMA A operands of the NEXT hidden
+// block ([KS1][64 lanes] floats, padded to whole 1-KiB wave pieces)
+template <int CI, int NF>
+struct Ring1 {
+  static constexpr int KS1 = (9 * CI) / 2;
+  static constexpr int MAIN4 = NF * 256;
+  static constexpr int K1PIECES_FULL = (KS1 * 256 + 1023) / 1024;
+  // conv1 operands ride in the ring when the LDS allows it; otherwise (c = 32 at n_filters 512 only) they are loaded
+  // from global memory per step, each load serialised behind the DMA in flight (slow path, kept for completeness)
+  static constexpr bool K1_IN_RING = (size_t)2 * (MAIN4 + K1PIECES_FULL * 64) * 16 + (size_t)6 * NF * 32 * 4 <= 160 * 1024;
+  static constexpr int K1PIECES = K1_IN_RING ? K1PIECES_FULL : 0;
+  static constexpr int SLOT4 = MAIN4 + K1PIECES * 64;
+  static constexpr int PIECES = NF * 4 + K1PIECES;
+  static constexpr size_t LDS_BYTES = (size_t)2 * SLOT4 * 16 + (size_t)6 * NF * 32 * 4;
+  static constexpr bool FITS = LDS_BYTES <= 160 * 1024;
+};
+
+// pieces [P0, P0 + N) of a ring slot image, dealt round-robin to the 4 waves (wave is scalar; surplus re-fetches the last)
+template <int P0, int N>
+__device__ __forceinline__ void stage_range(const float4* __restrict__ src, float4* dst, int wave, unsigned voff) {
+  const char* gb = uniform_ptr(src);
 #pragma unroll
-  for (int it = 0; it < NPER; ++it) {
-    const int base = it * 256 + wbase;
-    glds16(src + base + lane, dst + base);
+  for (int i = 0; i < (N + 3) / 4; ++i) {
+    int p = i * 4 + wave;
+    p = P0 + (p < N ? p : N - 1);
+    glds16(reinterpret_cast<const float4*>(gb + (size_t)p * 1024 + voff), dst + p * 64);
   }
 }
 
+// conv2 contribution of hidden block fi (conv1 + epilogue first), reading slot P, DMA of the next chunk into slot P^1.
+// conv1's A operands were published with the PREVIOUS chunk (slot P^1, read before the barrier that frees it).
+template <int CI, int NF, int P>
+__device__ __forceinline__ void net_step(const float* K1p, int fi, bool first, const float4* nsrc, float4* s0, float4* s1, const float* epl,
+                                         const float (&xcol)[(9 * CI) / 2], f32x16 (&acc2)[NF], int wave, unsigned voff, int lane, int hh) {
+  using G = Ring1<CI, NF>;
+  constexpr int KS1 = G::KS1;
+  constexpr int F = NF * 32;
+  f32x16 h1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) h1[r] = 0.0f;
+  {
+    const float* k1 = G::K1_IN_RING ? reinterpret_cast<const float*>(ring_slot<P ^ 1>(s0, s1) + G::MAIN4) + lane
+                                    : K1p + (size_t)fi * KS1 * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[ks * 64], xcol[ks], h1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int f = fi * 32 + mfma_row(r, hh);
+    h1[r] = fmaf(epl[F + f], fmaxf(h1[r] + epl[f], 0.0f), epl[2 * F + f]);
+  }
+  if (!first) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // chunk fi landed in every wave's view; slot P^1 is no longer read
+  }
+  stage_range<0, G::PIECES>(nsrc, ring_slot<P ^ 1>(s0, s1), wave, voff);
+  const float4* buf = ring_slot<P>(s0, s1);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+#pragma unroll
+    for (int g = 0; g < NF / 4; ++g) {
+      const float4 wv = buf[(r * (NF / 4) + g) * 64 + lane];
+      acc2[4 * g + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, h1[r], acc2[4 * g + 0], 0, 0, 0);
+      acc2[4 * g + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, h1[r], acc2[4 * g + 1], 0, 0, 0);
+      acc2[4 * g + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, h1[r], acc2[4 * g + 2], 0, 0, 0);
+      acc2[4 * g + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, h1[r], acc2[4 * g + 3], 0, 0, 0);
+    }
+  }
+}
+
+// One workgroup = 128 pixels (4 waves x 32-pixel column blocks), all weights through the LDS ring (image R0p: slot c < NF =
+// K2 chunk c | conv1 operands of hidden block c+1; slot NF + mt = K3 chunk mt).  No VGPR-destination memory op is issued
+// while a DMA is in flight (hipcc would serialise each one behind the DMA with s_waitcnt vmcnt(0)).
 template <int CI, int NF>
 __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
+  using G = Ring1<CI, NF>;
   constexpr int CO = 2 * CI;
-  constexpr int KS1 = (9 * CI) / 2;   // k-steps (k = 2) of conv1's contraction over (tap, cin)
+  constexpr int KS1 = G::KS1;         // k-steps (k = 2) of conv1's contraction over (tap, cin)
   constexpr int M3 = 9 * CO;          // rows of P^T: (tap, cout)
   constexpr int NMT = (M3 + 31) / 32;
   constexpr int F = NF * 32;
-  constexpr int CHUNK4 = NF * 256;    // float4 per staged chunk (NF * 4 KiB)
-  static_assert(CI % 2 == 0 && NF % 4 == 0, "shape");
+  constexpr int SLOT4 = G::SLOT4;
+  static_assert(CI % 2 == 0 && NF % 4 == 0 && G::FITS, "shape");
 
-  extern __shared__ float4 lds4[];    // [2][CHUNK4] weight ring, then ep [6][F]
-  float* epl = reinterpret_cast<float*>(lds4 + 2 * CHUNK4);
+  __shared__ float4 slot0[SLOT4];     // weight ring: two distinct objects (see ring_slot)
+  __shared__ float4 slot1[SLOT4];
+  __shared__ float epl[6 * F];        // b1, g1, d1, b2, g2, d2
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned voff = (unsigned)lane * 16u;
   const int pix = lane & 31;
   const int hh = lane >> 5;
-  const int q = (blockIdx.x * 4 + wave) * 32 + pix;
+  const int q = (blockIdx.x * 4 + (tid >> 6)) * 32 + pix;
   const bool qok = q < a.Q;
-
-  for (int i = tid; i < 6 * F; i += 256) epl[i] = a.ep[i];
-  stage_chunk<NF>(a.K2p, lds4, tid);
+  const float4* ring = a.R0p;
 
   // im2col column of this lane's pixel: xcol[ks] = vb[pixel + d(tap)][cin], k = 2*ks + hh = tap*CI + cin
   float xcol[KS1];
   {
     const int hw = a.h * a.w;
-    const int rem = q % hw;
+    const int qq = qok ? q : 0;
+    const int rem = qq % hw;
     const int i = rem / a.w, j = rem % a.w;
+    const float* base = a.vin + (long)qq * a.in_stride + a.in_off;
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) {
       const int k = 2 * ks + hh;
@@ -91,10 +177,15 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
       const int dy = tap / 3 - 1, dx = tap % 3 - 1;
       const int ii = i + dy, jj = j + dx;
       const bool ok = qok && ii >= 0 && ii < a.h && jj >= 0 && jj < a.w;
-      const long src = (long)(q + dy * a.w + dx) * a.in_stride + a.in_off + cin;
-      xcol[ks] = ok ? a.vin[src] : 0.0f;
+      const int off = ok ? ((dy * a.w + dx) * a.in_stride + cin) : 0;     // clamped: always in bounds
+      const float v = base[off];
+      xcol[ks] = ok ? v : 0.0f;
     }
   }
+  for (int i = tid; i < 6 * F; i += 256) epl[i] = a.ep[i];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the gathers above are done before any DMA is issued
+  stage_range<0, G::PIECES>(ring, slot0, wave, voff);                                           // chunk 0 -> slot 0
+  if (G::K1_IN_RING) stage_range<NF * 4, (G::K1PIECES > 0 ? G::K1PIECES : 1)>(ring + (size_t)(NF - 1) * SLOT4, slot1, wave, voff);   // conv1 operands of block 0
 
   f32x16 acc2[NF];
 #pragma unroll
@@ -103,43 +194,12 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
     for (int r = 0; r < 16; ++r) acc2[fo][r] = 0.0f;
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();   // ep visible; chunk 0 landed
+  __syncthreads();   // ep visible; chunk 0 and block-0 conv1 operands landed
 
-  for (int fi = 0; fi < NF; ++fi) {
-    // ---- conv1 for hidden channels [32 fi, 32 fi + 32): A1^T tile, then bias + ReLU + BN1 ----
-    f32x16 h1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) h1[r] = 0.0f;
-    {
-      const float* k1 = a.K1p + (size_t)fi * KS1 * 64 + lane;
-#pragma unroll
-      for (int ks = 0; ks < KS1; ++ks) h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[ks * 64], xcol[ks], h1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int f = fi * 32 + mfma_row(r, hh);
-      h1[r] = fmaf(epl[F + f], fmaxf(h1[r] + epl[f], 0.0f), epl[2 * F + f]);
-    }
-    if (fi > 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();   // chunk fi landed in every wave's view; buffer (fi+1)&1 is no longer read
-    }
-    if (fi + 1 < NF) stage_chunk<NF>(a.K2p + (size_t)(fi + 1) * CHUNK4, lds4 + ((fi + 1) & 1) * CHUNK4, tid);
-    else             stage_chunk<NF>(a.K3p, lds4 + (NF & 1) * CHUNK4, tid);
-
-    // ---- conv2: acc2[fo] += K2^T[fo-tile, fi-tile] . H1^T tile ----
-    const float4* buf = lds4 + (fi & 1) * CHUNK4;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-#pragma unroll
-      for (int g = 0; g < NF / 4; ++g) {
-        const float4 wv = buf[(r * (NF / 4) + g) * 64 + lane];
-        acc2[4 * g + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, h1[r], acc2[4 * g + 0], 0, 0, 0);
-        acc2[4 * g + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, h1[r], acc2[4 * g + 1], 0, 0, 0);
-        acc2[4 * g + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, h1[r], acc2[4 * g + 2], 0, 0, 0);
-        acc2[4 * g + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, h1[r], acc2[4 * g + 3], 0, 0, 0);
-      }
-    }
+#pragma nounroll
+  for (int fi = 0; fi < NF; fi += 2) {   // chunk fi lives in slot fi & 1 (NF is even)
+    net_step<CI, NF, 0>(a.K1p, fi, fi == 0, ring + (size_t)(fi + 1) * SLOT4, slot0, slot1, epl, xcol, acc2, wave, voff, lane, hh);
+    net_step<CI, NF, 1>(a.K1p, fi + 1, false, ring + (size_t)(fi + 2) * SLOT4, slot0, slot1, epl, xcol, acc2, wave, voff, lane, hh);
   }
 
   // ---- bias + ReLU + BN2 in place: acc2 becomes H2^T ----
@@ -151,12 +211,15 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
       acc2[fo][r] = fmaf(epl[4 * F + f], fmaxf(acc2[fo][r] + epl[3 * F + f], 0.0f), epl[5 * F + f]);
     }
 
-  // ---- conv3 as nine per-tap 1x1 convolutions: P^T[(tap,co) x 32px] = K3r^T . H2^T ----
+  // ---- conv3 as nine per-tap 1x1 convolutions: P^T[(tap,co) x 32px] = K3r^T . H2^T; chunk NF+mt in slot mt & 1 ----
+#pragma unroll
   for (int mt = 0; mt < NMT; ++mt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (mt + 1 < NMT) stage_chunk<NF>(a.K3p + (size_t)(mt + 1) * CHUNK4, lds4 + ((NF + mt + 1) & 1) * CHUNK4, tid);
-    const float4* buf = lds4 + ((NF + mt) & 1) * CHUNK4;
+    float4* cur = (mt & 1) ? slot1 : slot0;
+    float4* nxt = (mt & 1) ? slot0 : slot1;
+    if (mt + 1 < NMT) stage_range<0, NF * 4>(ring + (size_t)(NF + mt + 1) * SLOT4, nxt, wave, voff);
+    const float4* buf = cur;
     f32x16 acc3;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc3[r] = 0.0f;
