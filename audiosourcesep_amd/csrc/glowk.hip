@@ -37,6 +37,8 @@ struct StepDev {            // device pointers into the arena
   const float4* K2p = nullptr;
   const float4* K3p = nullptr;
   const float4* R0p = nullptr;
+  const float* K3bp = nullptr;   // backward: conv3^T operands of the small-conv chain [NF][9c/2][64]
+  const float4* RBp = nullptr;   // backward ring image: K2^T chunk fo | K3b operands of block fo+1 ; conv1^T chunks
   const float *Afwd = nullptr, *bfwd = nullptr, *Ainv = nullptr, *binv = nullptr, *b3 = nullptr;
   size_t arena_off = 0;     // offset (floats) of this step's block in the arena
 };
@@ -70,6 +72,11 @@ struct glowk_handle {
   float *bufA = nullptr, *bufB = nullptr, *bufP = nullptr, *bufZ = nullptr, *bufC = nullptr;
   double* bufLd = nullptr;
   double* bufStat = nullptr;    // [STAT_BLOCKS][32] partial sums + [32] means
+  // input-gradient path: per-step saves of the forward pass (v, P, ReLU masks) and gradient scratch
+  int saveN = 0;
+  float *saveV = nullptr, *saveP = nullptr, *bufGz = nullptr;
+  unsigned short* saveM = nullptr;
+  std::vector<size_t> offV, offP, offM;   // per forward-order step
   // HIP-event profiler of k_net
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
@@ -138,7 +145,8 @@ inline int rho(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 inline size_t pad4(size_t n) { return (n + 3) & ~size_t(3); }
 
 struct StepLayout {
-  size_t K1p, ep, K2p, K3p, R0p, Afwd, bfwd, Ainv, binv, b3, total;
+  size_t K1p, ep, K2p, K3p, R0p, K3bp, RBp, Afwd, bfwd, Ainv, binv, b3, total;
+  size_t slotB, k3fB;  // backward ring image: floats per slot; floats of its conv3^T-operand part (0: not in the ring)
   size_t slot0, k1f0;  // floats per slot of k_net_f32's ring image; floats of its conv1 part (0: not in the ring)
 };
 
@@ -156,6 +164,15 @@ StepLayout step_layout(int c, int F) {
     L.k1f0 = k1f;
     L.slot0 = (size_t)NF * 1024 + k1f;
     L.R0p = o; o += (size_t)(NF + NMT) * L.slot0;
+  }
+  {
+    const int KS3 = (9 * c) / 2, NM1 = (9 * CI + 31) / 32;
+    L.K3bp = o; o += pad4((size_t)NF * KS3 * 64);
+    size_t k3f = (size_t)(((size_t)KS3 * 256 + 1023) / 1024) * 256;
+    if (2 * ((size_t)NF * 1024 + k3f) * 4 + (size_t)6 * F * 4 > 160 * 1024) k3f = 0;   // Ring1<c, NF>::K1_IN_RING == false
+    L.k3fB = k3f;
+    L.slotB = (size_t)NF * 1024 + k3f;
+    L.RBp = o; o += (size_t)(NF + NM1) * L.slotB;
   }
   L.Afwd = o; o += pad4((size_t)c * c);
   L.bfwd = o; o += pad4(c);
@@ -274,29 +291,73 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
       if (L.k1f0) std::memcpy(slot + mainf, dst + L.K1p + (size_t)k1blk * k1n, k1n * 4);
     }
   }
+  // ---- backward images (input-gradient path): same kernel structure, transposed weights ----
+  {
+    const int KS3 = (9 * c) / 2, NM1 = (9 * CI + 31) / 32;
+    // conv3^T as the small-conv chain: A[i = f local][k = (tap, co)] = K3[tap][f][co]
+    for (int fo = 0; fo < NF; ++fo)
+      for (int ks = 0; ks < KS3; ++ks)
+        for (int l = 0; l < 64; ++l) {
+          const int i = l & 31, hh = l >> 5, kk = 2 * ks + hh;
+          float v = 0.0f;
+          if (kk < 9 * c) { const int tap = kk / c, co = kk % c; v = K3[((size_t)tap * F + fo * 32 + i) * c + co]; }
+          dst[L.K3bp + ((size_t)fo * KS3 + ks) * 64 + l] = v;
+        }
+    const size_t mainf = (size_t)NF * 1024, k3n = (size_t)KS3 * 64;
+    for (int c2 = 0; c2 < NF + NM1; ++c2) {
+      float* slot = dst + L.RBp + (size_t)c2 * L.slotB;
+      if (c2 < NF) {
+        // conv2^T chunk of hidden block fo = c2: A[i = f_in local of tile fi][k = f_out = fo*32 + rho(r,hh)] = K2[f_in][f_out]
+        const int fo = c2;
+        for (int r = 0; r < 16; ++r)
+          for (int g = 0; g < NF / 4; ++g)
+            for (int l = 0; l < 64; ++l)
+              for (int e = 0; e < 4; ++e) {
+                const int i = l & 31, hh = l >> 5, fi = 4 * g + e;
+                slot[((((size_t)r * (NF / 4)) + g) * 64 + l) * 4 + e] = K2[(size_t)(fi * 32 + i) * F + fo * 32 + rho(r, hh)];
+              }
+        if (L.k3fB) std::memcpy(slot + mainf, dst + L.K3bp + (size_t)((fo + 1) % NF) * k3n, k3n * 4);
+      } else {
+        // conv1^T per-tap chunk mt: A[i = m local][k = f = fi*32 + rho(r,hh)] = K1[m][f], m = (tap, cin)
+        const int mt = c2 - NF;
+        for (int fi = 0; fi < NF; ++fi)
+          for (int r4 = 0; r4 < 4; ++r4)
+            for (int l = 0; l < 64; ++l)
+              for (int e = 0; e < 4; ++e) {
+                const int i = l & 31, hh = l >> 5, r = 4 * r4 + e;
+                const int m = mt * 32 + i, f = fi * 32 + rho(r, hh);
+                slot[((((size_t)fi * 4) + r4) * 64 + l) * 4 + e] = (m < 9 * CI) ? K1[(size_t)m * F + f] : 0.0f;
+              }
+      }
+    }
+  }
   return true;
 }
 
 // ---- launch helpers ------------------------------------------------------------------------------
 template <int CI, int NF>
-int launch_net_t(const NetArgs& a, hipStream_t s) {
-  static_assert(Ring1<CI, NF>::FITS, "ring does not fit the LDS");
+int launch_net_t(const NetArgs& a, int mode, hipStream_t s) {
   const int ntiles = (a.Q + 127) / 128;
-  hipLaunchKernelGGL((k_net_f32<CI, NF>), dim3(ntiles), dim3(256), 0, s, a);
+  switch (mode) {
+    case NET_FWD:      hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a); break;
+    case NET_FWD_SAVE: hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE>), dim3(ntiles), dim3(256), 0, s, a); break;
+    case NET_BWD:      hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD>), dim3(ntiles), dim3(256), 0, s, a); break;
+    default: return fail("bad k_net mode");
+  }
   LAUNCHCHK("k_net_f32");
   return 0;
 }
 
-int launch_net_raw(int c, int F, const NetArgs& a, hipStream_t s) {
-#define NETCASE(CI_, NF_) if (c == 2 * CI_ && F == 32 * NF_) return launch_net_t<CI_, NF_>(a, s);
+int launch_net_raw(int c, int F, const NetArgs& a, int mode, hipStream_t s) {
+#define NETCASE(CI_, NF_) if (c == 2 * CI_ && F == 32 * NF_) return launch_net_t<CI_, NF_>(a, mode, s);
   NETCASE(2, 16) NETCASE(4, 16) NETCASE(8, 16) NETCASE(16, 16)
   NETCASE(2, 4) NETCASE(4, 4) NETCASE(8, 4) NETCASE(16, 4)
 #undef NETCASE
   return fail("unsupported (channels, n_filters) combination: c=" + std::to_string(c) + " F=" + std::to_string(F));
 }
 
-int launch_net(glowk_handle* h, int level, int c, int F, const NetArgs& a, hipStream_t s) {
-  if (!h->profiling) return launch_net_raw(c, F, a, s);
+int launch_net(glowk_handle* h, int level, int c, int F, const NetArgs& a, hipStream_t s, int mode = NET_FWD) {
+  if (!h->profiling) return launch_net_raw(c, F, a, mode, s);
   while (h->ev_pool.size() < h->ev_used + 2) {
     hipEvent_t e;
     HIPCHK(hipEventCreate(&e));
@@ -304,7 +365,7 @@ int launch_net(glowk_handle* h, int level, int c, int F, const NetArgs& a, hipSt
   }
   hipEvent_t e0 = h->ev_pool[h->ev_used], e1 = h->ev_pool[h->ev_used + 1];
   HIPCHK(hipEventRecord(e0, s));
-  const int rc = launch_net_raw(c, F, a, s);
+  const int rc = launch_net_raw(c, F, a, mode, s);
   HIPCHK(hipEventRecord(e1, s));
   h->ev_used += 2;
   h->ev_level.push_back(level);
@@ -361,15 +422,47 @@ NetArgs net_args(glowk_handle* h, const Level& lv, const StepDev& sd, const floa
   NetArgs a;
   a.vin = vin; a.in_stride = in_stride; a.in_off = in_off;
   a.Q = N * lv.h * lv.w; a.h = lv.h; a.w = lv.w;
-  a.K1p = sd.K1p; a.ep = sd.ep; a.K2p = sd.K2p; a.K3p = sd.K3p; a.R0p = sd.R0p; a.P = h->bufP;
+  a.K1p = sd.K1p; a.ep = sd.ep; a.K2p = sd.K2p; a.K3p = sd.K3p; a.R0p = sd.R0p; a.mask1 = nullptr; a.mask2 = nullptr; a.P = h->bufP;
   return a;
 }
 
-// data -> latent (+ log-det accumulated in h->bufLd); z_dst [N,Hl,Wl,Cl]
-int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_t s) {
+// per-step save buffers of the input-gradient path, forward order index sidx = level*K + (K-1-k)
+int ensure_save(glowk_handle* h, int N) {
+  if (N <= h->saveN) return 0;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipDeviceSynchronize());
+  if (h->saveV) { hipFree(h->saveV); hipFree(h->saveP); hipFree(h->saveM); hipFree(h->bufGz); }
+  h->saveV = h->saveP = h->bufGz = nullptr; h->saveM = nullptr; h->saveN = 0;
+  const int K = h->cfg.K, L = h->cfg.L, NF = h->cfg.F / 32;
+  size_t v = 0, p = 0, m = 0;
+  h->offV.assign((size_t)L * K, 0); h->offP.assign((size_t)L * K, 0); h->offM.assign((size_t)L * K, 0);
+  for (int lvl = 0; lvl < L; ++lvl) {
+    const Level& lv = h->levels[lvl];
+    const size_t Q = (size_t)N * lv.h * lv.w;
+    const size_t blocks = ((Q + 127) / 128) * 4;
+    for (int j = 0; j < K; ++j) {
+      const size_t sidx = (size_t)lvl * K + j;
+      h->offV[sidx] = v; v += Q * lv.c;
+      h->offP[sidx] = p; p += Q * lv.c * 9;
+      h->offM[sidx] = m; m += 2 * blocks * NF * 64;   // mask1 then mask2
+    }
+  }
+  const size_t E = (size_t)h->cfg.H * h->cfg.W * h->cfg.C;
+  HIPCHK(hipMalloc(&h->saveV, v * 4));
+  HIPCHK(hipMalloc(&h->saveP, p * 4));
+  HIPCHK(hipMalloc(&h->saveM, m * 2));
+  HIPCHK(hipMalloc(&h->bufGz, (size_t)N * E * 4));
+  if (!h->bufC) HIPCHK(hipMalloc(&h->bufC, (size_t)h->wsN * E * 4));
+  h->saveN = N;
+  return 0;
+}
+
+// data -> latent (+ log-det accumulated in h->bufLd); z_dst [N,Hl,Wl,Cl].  save: keep every step's coupling input v,
+// per-tap conv3 outputs P and the two ReLU masks for run_backward.
+int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_t s, bool save = false) {
   const glowk_config& cfg = h->cfg;
-  const int K = cfg.K, L = cfg.L;
-  float* cur = h->bufA;
+  const int K = cfg.K, L = cfg.L, NF = cfg.F / 32;
+  float* cur = save ? h->saveV + h->offV[0] : h->bufA;
   float* oth = h->bufB;
   {
     const Level& lv = h->levels[0];
@@ -380,29 +473,113 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
   }
   for (int lvl = 0; lvl < L; ++lvl) {
     const Level& lv = h->levels[lvl];
+    const size_t Q = (size_t)N * lv.h * lv.w;
+    const size_t blocks = ((Q + 127) / 128) * 4;
     for (int k = K - 1; k >= 0; --k) {   // tfb.Chain applies right to left: step K-1 first (flow_glow.py:51-52)
       const StepDev& sd = lv.dev[k];
-      if (int rc = launch_net(h, lvl, lv.c, cfg.F, net_args(h, lv, sd, cur, lv.c, lv.c / 2, N), s)) return rc;
+      const size_t sidx = (size_t)lvl * K + (K - 1 - k);
+      NetArgs na = net_args(h, lv, sd, cur, lv.c, lv.c / 2, N);
+      if (save) {
+        na.P = h->saveP + h->offP[sidx];
+        na.mask1 = h->saveM + h->offM[sidx];
+        na.mask2 = na.mask1 + blocks * NF * 64;
+      }
+      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, save ? NET_FWD_SAVE : NET_FWD)) return rc;
       CoupleArgs ca;
-      ca.vin = cur; ca.P = h->bufP; ca.b3 = sd.b3; ca.logdet = h->bufLd; ca.log_s_out = nullptr; ca.t_out = nullptr;
-      ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0;
+      ca.vin = cur; ca.P = na.P; ca.b3 = sd.b3; ca.logdet = h->bufLd; ca.log_s_out = nullptr; ca.t_out = nullptr;
+      ca.Q = (int)Q; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0;
+      float* next = save && k > 0 ? h->saveV + h->offV[sidx + 1] : oth;
       if (k > 0) {
         ca.A = lv.dev[k - 1].Afwd; ca.b = lv.dev[k - 1].bfwd;
-        ca.out = oth; ca.out_stride = lv.c; ca.out_off = 0;
+        ca.out = next; ca.out_stride = lv.c; ca.out_off = 0;
       } else if (lvl < L - 1) {
         ca.A = nullptr; ca.b = nullptr; ca.out = oth; ca.out_stride = lv.c; ca.out_off = 0;
       } else {
         ca.A = nullptr; ca.b = nullptr; ca.out = z_dst; ca.out_stride = h->Cl; ca.out_off = lv.z_off;
       }
       if (int rc = launch_couple(lv.c, ca, N, s)) return rc;
-      if (k > 0 || lvl < L - 1) std::swap(cur, oth);
+      if (k > 0) {
+        if (save) cur = next; else std::swap(cur, oth);
+      } else if (lvl < L - 1) {
+        // block output sits in oth; split + squeeze + first ActNorm/1x1 of the next block
+        float* nv = save ? h->saveV + h->offV[sidx + 1] : cur;
+        const StepDev& nfirst = h->levels[lvl + 1].dev[K - 1];
+        CDISPATCH(lv.c, hipLaunchKernelGGL((k_split<CC>), dim3(N), dim3(256), 0, s, (const float*)oth, lv.h, lv.w, z_dst, h->Hl * h->Wl, h->Cl,
+                                           lv.z_off, lv.Cz, nfirst.Afwd, nfirst.bfwd, nv));
+        LAUNCHCHK("k_split");
+        cur = nv;
+        if (!save) oth = (cur == h->bufA) ? h->bufB : h->bufA;
+      }
     }
-    if (lvl < L - 1) {
-      const StepDev& nfirst = h->levels[lvl + 1].dev[K - 1];
-      CDISPATCH(lv.c, hipLaunchKernelGGL((k_split<CC>), dim3(N), dim3(256), 0, s, cur, lv.h, lv.w, z_dst, h->Hl * h->Wl, h->Cl,
-                                         lv.z_off, lv.Cz, nfirst.Afwd, nfirst.bfwd, oth));
-      LAUNCHCHK("k_split");
-      std::swap(cur, oth);
+  }
+  return 0;
+}
+
+// d sum_n log_prob[n] / dx, after run_forward(save = true) on the same x; z is that run's latent
+int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* dx, hipStream_t s) {
+  const glowk_config& cfg = h->cfg;
+  const int K = cfg.K, L = cfg.L, NF = cfg.F / 32;
+  const int E = h->Hl * h->Wl * h->Cl;
+  {
+    const size_t total = (size_t)N * E;
+    hipLaunchKernelGGL(k_prior_grad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, total, E, h->d_loc, h->d_log_scale, h->bufGz);
+    LAUNCHCHK("k_prior_grad");
+  }
+  float* gh_a = h->bufA;    // [g_va, g_yb] ping-pong
+  float* gh_b = h->bufB;
+  float* g_o = h->bufC;     // gradient wrt the network output
+  float* Pg = h->bufP;      // per-tap partial input gradients
+  float* gu = h->bufZ;      // block-level results (g_u of a block / g_y of the previous block's last step)
+  const float* gy_src = nullptr;   // upstream gradient wrt the current block's output o (set per block)
+  for (int lvl = L - 1; lvl >= 0; --lvl) {
+    const Level& lv = h->levels[lvl];
+    const int Q = N * lv.h * lv.w;
+    const size_t blocks = (((size_t)Q + 127) / 128) * 4;
+    for (int k = 0; k < K; ++k) {   // reverse of the forward order K-1 .. 0
+      const StepDev& sd = lv.dev[k];
+      const size_t sidx = (size_t)lvl * K + (K - 1 - k);
+      BwdArgs ba;
+      ba.Q = Q; ba.h = lv.h; ba.w = lv.w;
+      ba.v = h->saveV + h->offV[sidx]; ba.P = h->saveP + h->offP[sidx]; ba.b3 = sd.b3;
+      ba.g_o = g_o; ba.ghalf_out = gh_b; ba.gu_out = nullptr;
+      if (k == 0) {
+        // gradient wrt the block output: the latent slice itself (last block) or what k_bwd_split assembled
+        ba.ghalf_in = nullptr; ba.Pg = nullptr; ba.A = nullptr;
+        if (lvl == L - 1) { ba.gv_direct = h->bufGz; ba.gvd_stride = h->Cl; ba.gvd_off = lv.z_off; }
+        else              { ba.gv_direct = gy_src;   ba.gvd_stride = lv.c;  ba.gvd_off = 0; }
+      } else {
+        // merge step k-1's network gradient, go through its fused ActNorm + 1x1, then this step's coupling
+        ba.ghalf_in = gh_a; ba.Pg = Pg; ba.gv_direct = nullptr; ba.gvd_stride = 0; ba.gvd_off = 0;
+        ba.A = lv.dev[k - 1].Afwd;
+      }
+      CDISPATCH(lv.c, hipLaunchKernelGGL((k_bwd_light<CC>), dim3(N), dim3(256), 0, s, ba));
+      LAUNCHCHK("k_bwd_light");
+      std::swap(gh_a, gh_b);   // gh_a now holds this step's [g_va, g_yb]
+      NetArgs na = net_args(h, lv, sd, g_o, lv.c, 0, N);
+      na.K1p = sd.K3bp; na.R0p = sd.RBp; na.P = Pg;
+      na.mask1 = h->saveM + h->offM[sidx];
+      na.mask2 = na.mask1 + blocks * NF * 64;
+      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, NET_BWD)) return rc;
+    }
+    // first forward step of the block (k = K-1): merge, then through its ActNorm + 1x1 -> g_u of the squeezed block input
+    {
+      BwdArgs ba;
+      ba.Q = Q; ba.h = lv.h; ba.w = lv.w;
+      ba.ghalf_in = gh_a; ba.Pg = Pg; ba.gv_direct = nullptr; ba.gvd_stride = 0; ba.gvd_off = 0;
+      ba.A = lv.dev[K - 1].Afwd;
+      ba.v = nullptr; ba.P = nullptr; ba.b3 = nullptr; ba.g_o = nullptr; ba.ghalf_out = nullptr; ba.gu_out = g_o;   // reuse g_o as g_u
+      CDISPATCH(lv.c, hipLaunchKernelGGL((k_bwd_light<CC>), dim3(N), dim3(256), 0, s, ba));
+      LAUNCHCHK("k_bwd_light");
+    }
+    if (lvl > 0) {
+      const Level& pv = h->levels[lvl - 1];
+      CDISPATCH(pv.c, hipLaunchKernelGGL((k_bwd_split<CC>), dim3(N), dim3(256), 0, s, (const float*)h->bufGz, h->Hl * h->Wl, h->Cl, pv.z_off,
+                                         pv.Cz, (const float*)g_o, pv.h, pv.w, gu));
+      LAUNCHCHK("k_bwd_split");
+      gy_src = gu;
+    } else {
+      CDISPATCH(lv.c, hipLaunchKernelGGL((k_bwd_in<CC>), dim3(N), dim3(256), 0, s, (const float*)g_o, x, lv.h, lv.w, pre_args(cfg), dx));
+      LAUNCHCHK("k_bwd_in");
     }
   }
   return 0;
@@ -490,6 +667,7 @@ int glowk_destroy(glowk_handle* h) {
   if (h->bufA) { hipFree(h->bufA); hipFree(h->bufB); hipFree(h->bufP); hipFree(h->bufZ); hipFree(h->bufLd); }
   if (h->bufC) hipFree(h->bufC);
   if (h->bufStat) hipFree(h->bufStat);
+  if (h->saveV) { hipFree(h->saveV); hipFree(h->saveP); hipFree(h->saveM); hipFree(h->bufGz); }
   for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
   delete h;
   return 0;
@@ -582,6 +760,8 @@ int glowk_finalize_weights(glowk_handle* h) {
       d.K2p = reinterpret_cast<const float4*>(base + SL.K2p);
       d.K3p = reinterpret_cast<const float4*>(base + SL.K3p);
       d.R0p = reinterpret_cast<const float4*>(base + SL.R0p);
+      d.K3bp = base + SL.K3bp;
+      d.RBp = reinterpret_cast<const float4*>(base + SL.RBp);
       d.Afwd = base + SL.Afwd; d.bfwd = base + SL.bfwd; d.Ainv = base + SL.Ainv; d.binv = base + SL.binv; d.b3 = base + SL.b3;
     }
   }
@@ -758,8 +938,16 @@ int glowk_log_prob(glowk_handle* h, const float* x_dev, int N, float* logp_dev, 
 }
 
 int glowk_log_prob_grad(glowk_handle* h, const float* x_dev, int N, float* logp_dev, float* dx_dev, void* stream) {
-  (void)h; (void)x_dev; (void)N; (void)logp_dev; (void)dx_dev; (void)stream;
-  return fail("glowk_log_prob_grad: input-gradient path not built yet");
+  if (int rc = check_ready(h, N)) return rc;
+  if (!x_dev || !logp_dev || !dx_dev) return fail("null tensor");
+  if (int rc = ensure_save(h, N)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  float* z = h->bufGz;   // the latent lives in bufGz until the prior gradient overwrites it in place
+  if (int rc = run_forward(h, x_dev, N, z, s, true)) return rc;
+  hipLaunchKernelGGL(k_prior, dim3(N), dim3(256), 0, s, (const float*)z, h->Hl * h->Wl * h->Cl, h->d_loc, h->d_log_scale,
+                     (const double*)h->bufLd, logp_dev, (float*)nullptr);
+  LAUNCHCHK("k_prior");
+  return run_backward(h, x_dev, z, N, dx_dev, s);
 }
 
 int glowk_sample(glowk_handle* h, const float* eps_dev, int N, float* x_dev, void* stream) {

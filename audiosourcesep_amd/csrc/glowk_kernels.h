@@ -42,6 +42,8 @@ struct NetArgs {
   const float4* K2p;     // [NF fi][16 r][NF/4][64 lanes] float4 (4 consecutive fo)
   const float4* K3p;     // [NMT][NF fo][4 r4][64 lanes] float4 (4 consecutive r)
   const float4* R0p;     // ring image (Ring1): [NF + NMT] slots
+  unsigned short* mask1; // [blocks of 32 px][NF][64 lanes] ReLU mask bits of conv1 (NET_FWD_SAVE writes, NET_BWD reads)
+  unsigned short* mask2; // same for conv2
   float* P;              // [9*CO][Q]
 };
 
@@ -64,15 +66,15 @@ __device__ __forceinline__ const char* uniform_ptr(const void* p) {   // force a
 template <int P>
 __device__ __forceinline__ float4* ring_slot(float4* s0, float4* s1) { return P ? s1 : s0; }
 
-// geometry of k_net_f32's ring: slot = conv2 / conv3 chunk (NF * 4 KiB) + conv1's MFMA A operands of the NEXT hidden
-// block ([KS1][64 lanes] floats, padded to whole 1-KiB wave pieces)
-template <int CI, int NF>
+// geometry of k_net_f32's ring: slot = main chunk (NF * 4 KiB) + the small convolution's MFMA A operands of the NEXT
+// hidden block ([KS][64 lanes] floats, padded to whole 1-KiB wave pieces).  KIN = input channels of the small conv.
+template <int KIN, int NF>
 struct Ring1 {
-  static constexpr int KS1 = (9 * CI) / 2;
+  static constexpr int KS1 = (9 * KIN) / 2;
   static constexpr int MAIN4 = NF * 256;
   static constexpr int K1PIECES_FULL = (KS1 * 256 + 1023) / 1024;
-  // conv1 operands ride in the ring when the LDS allows it; otherwise (c = 32 at n_filters 512 only) they are loaded
-  // from global memory per step, each load serialised behind the DMA in flight (slow path, kept for completeness)
+  // the small conv's operands ride in the ring when the LDS allows it; otherwise (9*KIN = 144 at n_filters 512 only)
+  // they are loaded from global memory per step, each load serialised behind the DMA in flight (slow path)
   static constexpr bool K1_IN_RING = (size_t)2 * (MAIN4 + K1PIECES_FULL * 64) * 16 + (size_t)6 * NF * 32 * 4 <= 160 * 1024;
   static constexpr int K1PIECES = K1_IN_RING ? K1PIECES_FULL : 0;
   static constexpr int SLOT4 = MAIN4 + K1PIECES * 64;
@@ -93,12 +95,29 @@ __device__ __forceinline__ void stage_range(const float4* __restrict__ src, floa
   }
 }
 
-// conv2 contribution of hidden block fi (conv1 + epilogue first), reading slot P, DMA of the next chunk into slot P^1.
-// conv1's A operands were published with the PREVIOUS chunk (slot P^1, read before the barrier that frees it).
-template <int CI, int NF, int P>
-__device__ __forceinline__ void net_step(const float* K1p, int fi, bool first, const float4* nsrc, float4* s0, float4* s1, const float* epl,
-                                         const float (&xcol)[(9 * CI) / 2], f32x16 (&acc2)[NF], int wave, unsigned voff, int lane, int hh) {
-  using G = Ring1<CI, NF>;
+// k_net_f32 modes.  The backward pass of the coupling network has the forward pass's structure with transposed weights:
+//   NET_FWD / NET_FWD_SAVE   conv1 (K = 9ci chain) -> bias+ReLU+BN1 -> conv2 (16 accumulator tiles) -> bias+ReLU+BN2 -> conv3 per-tap
+//   NET_BWD                  conv3^T (K = 9c chain) -> x g2 x mask2  -> conv2^T (16 accumulator tiles) -> x g1 x mask1 -> conv1^T per-tap
+// NET_FWD_SAVE also stores the two ReLU masks (16 bits per lane per hidden block) for NET_BWD.
+enum { NET_FWD = 0, NET_FWD_SAVE = 1, NET_BWD = 2 };
+
+// select word j of a small register array with a wave-uniform index (v_cndmask chain; no dynamic register indexing)
+template <int N>
+__device__ __forceinline__ unsigned pick_word(const unsigned (&w)[N], int j) {
+  unsigned r = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r = (j == i) ? w[i] : r;
+  return r;
+}
+
+// contribution of hidden block fi to the 16 accumulator tiles: small conv + epilogue first, then 256 MFMAs reading slot P,
+// with the DMA of the next chunk into slot P^1.  The small conv's A operands were published with the PREVIOUS chunk
+// (slot P^1, read before the barrier that frees it).
+template <int KIN, int NF, int P, int MODE>
+__device__ __forceinline__ void net_step(const NetArgs& a, int fi, bool first, const float4* nsrc, float4* s0, float4* s1,
+                                         const float* epl, const float (&xcol)[(9 * KIN) / 2], f32x16 (&acc2)[NF],
+                                         const unsigned (&mk)[NF / 2], size_t wblk, int wave, unsigned voff, int lane, int hh) {
+  using G = Ring1<KIN, NF>;
   constexpr int KS1 = G::KS1;
   constexpr int F = NF * 32;
   f32x16 h1;
@@ -106,14 +125,28 @@ __device__ __forceinline__ void net_step(const float* K1p, int fi, bool first, c
   for (int r = 0; r < 16; ++r) h1[r] = 0.0f;
   {
     const float* k1 = G::K1_IN_RING ? reinterpret_cast<const float*>(ring_slot<P ^ 1>(s0, s1) + G::MAIN4) + lane
-                                    : K1p + (size_t)fi * KS1 * 64 + lane;
+                                    : a.K1p + (size_t)fi * KS1 * 64 + lane;
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[ks * 64], xcol[ks], h1, 0, 0, 0);
   }
+  if (MODE == NET_BWD) {
+    // g_a2 = g_h2 * g2 * [a2 + b2 > 0]
+    const unsigned w = pick_word<NF / 2>(mk, fi >> 1) >> ((fi & 1) * 16);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int f = fi * 32 + mfma_row(r, hh);
-    h1[r] = fmaf(epl[F + f], fmaxf(h1[r] + epl[f], 0.0f), epl[2 * F + f]);
+    for (int r = 0; r < 16; ++r) {
+      const int f = fi * 32 + mfma_row(r, hh);
+      h1[r] = ((w >> r) & 1u) ? h1[r] * epl[4 * F + f] : 0.0f;
+    }
+  } else {
+    unsigned bits = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = fi * 32 + mfma_row(r, hh);
+      const float pre = h1[r] + epl[f];
+      if (MODE == NET_FWD_SAVE) bits |= (pre > 0.0f ? 1u : 0u) << r;
+      h1[r] = fmaf(epl[F + f], fmaxf(pre, 0.0f), epl[2 * F + f]);
+    }
+    if (MODE == NET_FWD_SAVE) a.mask1[(wblk * NF + fi) * 64 + lane] = (unsigned short)bits;
   }
   if (!first) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -135,18 +168,19 @@ __device__ __forceinline__ void net_step(const float* K1p, int fi, bool first, c
 }
 
 // One workgroup = 128 pixels (4 waves x 32-pixel column blocks), all weights through the LDS ring (image R0p: slot c < NF =
-// K2 chunk c | conv1 operands of hidden block c+1; slot NF + mt = K3 chunk mt).  No VGPR-destination memory op is issued
-// while a DMA is in flight (hipcc would serialise each one behind the DMA with s_waitcnt vmcnt(0)).
-template <int CI, int NF>
+// main chunk c | small-conv operands of hidden block c+1; slot NF + mt = output chunk mt).  No VGPR-destination memory op is
+// issued while a DMA is in flight (hipcc would serialise each one behind the DMA with s_waitcnt vmcnt(0)).
+//   KIN   input channels of the small (3x3, K = 9*KIN) convolution: c/2 forward, c backward
+//   MOUT  rows of the per-tap output: 9*c forward (conv3), 9*c/2 backward (conv1^T)
+template <int KIN, int MOUT, int NF, int MODE>
 __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
-  using G = Ring1<CI, NF>;
-  constexpr int CO = 2 * CI;
-  constexpr int KS1 = G::KS1;         // k-steps (k = 2) of conv1's contraction over (tap, cin)
-  constexpr int M3 = 9 * CO;          // rows of P^T: (tap, cout)
-  constexpr int NMT = (M3 + 31) / 32;
+  using G = Ring1<KIN, NF>;
+  constexpr int KS1 = G::KS1;         // k-steps (k = 2) of the small conv's contraction over (tap, channel)
+  constexpr int NMT = (MOUT + 31) / 32;
   constexpr int F = NF * 32;
   constexpr int SLOT4 = G::SLOT4;
-  static_assert(CI % 2 == 0 && NF % 4 == 0 && G::FITS, "shape");
+  constexpr int SGN = (MODE == NET_BWD) ? -1 : 1;   // backward gathers at q - d(tap)
+  static_assert(KIN % 2 == 0 && NF % 4 == 0 && G::FITS, "shape");
 
   __shared__ float4 slot0[SLOT4];     // weight ring: two distinct objects (see ring_slot)
   __shared__ float4 slot1[SLOT4];
@@ -158,11 +192,12 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
   const unsigned voff = (unsigned)lane * 16u;
   const int pix = lane & 31;
   const int hh = lane >> 5;
-  const int q = (blockIdx.x * 4 + (tid >> 6)) * 32 + pix;
+  const size_t wblk = (size_t)blockIdx.x * 4 + (tid >> 6);   // 32-pixel column block of this wave
+  const int q = (int)wblk * 32 + pix;
   const bool qok = q < a.Q;
   const float4* ring = a.R0p;
 
-  // im2col column of this lane's pixel: xcol[ks] = vb[pixel + d(tap)][cin], k = 2*ks + hh = tap*CI + cin
+  // im2col column of this lane's pixel: xcol[ks] = in[pixel +- d(tap)][ch], k = 2*ks + hh = tap*KIN + ch
   float xcol[KS1];
   {
     const int hw = a.h * a.w;
@@ -173,8 +208,8 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) {
       const int k = 2 * ks + hh;
-      const int tap = k / CI, cin = k % CI;
-      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+      const int tap = k / KIN, cin = k % KIN;
+      const int dy = SGN * (tap / 3 - 1), dx = SGN * (tap % 3 - 1);
       const int ii = i + dy, jj = j + dx;
       const bool ok = qok && ii >= 0 && ii < a.h && jj >= 0 && jj < a.w;
       const int off = ok ? ((dy * a.w + dx) * a.in_stride + cin) : 0;     // clamped: always in bounds
@@ -182,10 +217,22 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
       xcol[ks] = ok ? v : 0.0f;
     }
   }
+  // backward: ReLU masks of this column block (mk1 = conv1 output / epilogue 2, mk2 = conv2 output / epilogue 1),
+  // one 32-bit word per pair of hidden blocks, kept in registers for the whole kernel
+  unsigned mk1[NF / 2], mk2[NF / 2];
+#pragma unroll
+  for (int j = 0; j < NF / 2; ++j) { mk1[j] = 0; mk2[j] = 0; }
+  if (MODE == NET_BWD) {
+#pragma unroll
+    for (int j = 0; j < NF / 2; ++j) {
+      mk1[j] = (unsigned)a.mask1[(wblk * NF + 2 * j) * 64 + lane] | ((unsigned)a.mask1[(wblk * NF + 2 * j + 1) * 64 + lane] << 16);
+      mk2[j] = (unsigned)a.mask2[(wblk * NF + 2 * j) * 64 + lane] | ((unsigned)a.mask2[(wblk * NF + 2 * j + 1) * 64 + lane] << 16);
+    }
+  }
   for (int i = tid; i < 6 * F; i += 256) epl[i] = a.ep[i];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the gathers above are done before any DMA is issued
   stage_range<0, G::PIECES>(ring, slot0, wave, voff);                                           // chunk 0 -> slot 0
-  if (G::K1_IN_RING) stage_range<NF * 4, (G::K1PIECES > 0 ? G::K1PIECES : 1)>(ring + (size_t)(NF - 1) * SLOT4, slot1, wave, voff);   // conv1 operands of block 0
+  if (G::K1_IN_RING) stage_range<NF * 4, (G::K1PIECES > 0 ? G::K1PIECES : 1)>(ring + (size_t)(NF - 1) * SLOT4, slot1, wave, voff);   // small-conv operands of block 0
 
   f32x16 acc2[NF];
 #pragma unroll
@@ -194,24 +241,38 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
     for (int r = 0; r < 16; ++r) acc2[fo][r] = 0.0f;
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();   // ep visible; chunk 0 and block-0 conv1 operands landed
+  __syncthreads();   // ep visible; chunk 0 and block-0 operands landed
 
 #pragma nounroll
   for (int fi = 0; fi < NF; fi += 2) {   // chunk fi lives in slot fi & 1 (NF is even)
-    net_step<CI, NF, 0>(a.K1p, fi, fi == 0, ring + (size_t)(fi + 1) * SLOT4, slot0, slot1, epl, xcol, acc2, wave, voff, lane, hh);
-    net_step<CI, NF, 1>(a.K1p, fi + 1, false, ring + (size_t)(fi + 2) * SLOT4, slot0, slot1, epl, xcol, acc2, wave, voff, lane, hh);
+    net_step<KIN, NF, 0, MODE>(a, fi, fi == 0, ring + (size_t)(fi + 1) * SLOT4, slot0, slot1, epl, xcol, acc2, mk2, wblk, wave, voff, lane, hh);
+    net_step<KIN, NF, 1, MODE>(a, fi + 1, false, ring + (size_t)(fi + 2) * SLOT4, slot0, slot1, epl, xcol, acc2, mk2, wblk, wave, voff, lane, hh);
   }
 
-  // ---- bias + ReLU + BN2 in place: acc2 becomes H2^T ----
+  // ---- epilogue on the 16 accumulator tiles, in place ----
 #pragma unroll
-  for (int fo = 0; fo < NF; ++fo)
+  for (int fo = 0; fo < NF; ++fo) {
+    if (MODE == NET_BWD) {
+      const unsigned w = mk1[fo >> 1] >> ((fo & 1) * 16);   // g_a1 = g_h1 * g1 * [a1 + b1 > 0]
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int f = fo * 32 + mfma_row(r, hh);
-      acc2[fo][r] = fmaf(epl[4 * F + f], fmaxf(acc2[fo][r] + epl[3 * F + f], 0.0f), epl[5 * F + f]);
+      for (int r = 0; r < 16; ++r) {
+        const int f = fo * 32 + mfma_row(r, hh);
+        acc2[fo][r] = ((w >> r) & 1u) ? acc2[fo][r] * epl[F + f] : 0.0f;
+      }
+    } else {
+      unsigned bits = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = fo * 32 + mfma_row(r, hh);
+        const float pre = acc2[fo][r] + epl[3 * F + f];
+        if (MODE == NET_FWD_SAVE) bits |= (pre > 0.0f ? 1u : 0u) << r;
+        acc2[fo][r] = fmaf(epl[4 * F + f], fmaxf(pre, 0.0f), epl[5 * F + f]);
+      }
+      if (MODE == NET_FWD_SAVE) a.mask2[(wblk * NF + fo) * 64 + lane] = (unsigned short)bits;
     }
+  }
 
-  // ---- conv3 as nine per-tap 1x1 convolutions: P^T[(tap,co) x 32px] = K3r^T . H2^T; chunk NF+mt in slot mt & 1 ----
+  // ---- the 3x3 output convolution as nine per-tap 1x1s: P^T[(tap,ch) x 32px] = W^T . H^T; chunk NF+mt in slot mt & 1 ----
 #pragma unroll
   for (int mt = 0; mt < NMT; ++mt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -237,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = mt * 32 + mfma_row(r, hh);
-      if (m < M3 && qok) a.P[(size_t)m * a.Q + q] = acc3[r];
+      if (m < MOUT && qok) a.P[(size_t)m * a.Q + q] = acc3[r];
     }
   }
 }
@@ -582,4 +643,163 @@ __global__ __launch_bounds__(256) void k_chan_stats(const float* __restrict__ x,
   }
   __syncthreads();
   if (threadIdx.x < C) part[(size_t)blockIdx.x * C + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// input-gradient path (compute_grad_logprob, run_basis_sep.py:73-79; derivation SURVEY appendix A.5)
+// ------------------------------------------------------------------------------------------------------------------
+struct BwdArgs {
+  // (1) gradient wrt the tensor v_s entering step s's coupling:
+  //     merge: g_v = [g_va, g_yb + sum_tap Pg[tap, cin][q - d(tap)]]   (ghalf_in, Pg of step s), or
+  //     direct: g_v = gv_direct[q*gvd_stride + gvd_off + .]             (Pg == null)
+  const float* ghalf_in;
+  const float* Pg;
+  const float* gv_direct;
+  int gvd_stride, gvd_off;
+  // (2) through step s's fused ActNorm + 1x1: g_y = g_v . A^T (null: g_y = g_v)
+  const float* A;
+  // (3) coupling backward of the step that produced y (forward order: the step before s), or none (v == null)
+  const float* v;          // [Q][C] saved coupling input
+  const float* P;          // [9C][Q] saved per-tap conv3 outputs
+  const float* b3;
+  float* g_o;              // [Q][C] gradient wrt the network output o = [pre-tanh log_s, t]
+  float* ghalf_out;        // [Q][C] [g_va, g_yb]
+  float* gu_out;           // [Q][C] g_y itself when no coupling follows
+  int Q, h, w;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
+  constexpr int CI = C / 2;
+  const int n = blockIdx.x;
+  const int hw = a.h * a.w;
+  for (int pp = threadIdx.x; pp < hw; pp += 256) {
+    const int q = n * hw + pp;
+    const int i = pp / a.w, j = pp % a.w;
+    float gv[C];
+    if (a.Pg) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) gv[c] = a.ghalf_in[(size_t)q * C + c];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int ii = i - dy, jj = j - dx;   // Pg[q'] contributes at q' + d(tap)
+        if (ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) {
+          const float* src = a.Pg + (size_t)(tap * CI) * a.Q + (q - dy * a.w - dx);
+#pragma unroll
+          for (int c = 0; c < CI; ++c) gv[CI + c] += src[(size_t)c * a.Q];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) gv[c] = a.gv_direct[(size_t)q * a.gvd_stride + a.gvd_off + c];
+    }
+    float gy[C];
+    if (a.A) {
+#pragma unroll
+      for (int ci = 0; ci < C; ++ci) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int co = 0; co < C; ++co) acc = fmaf(gv[co], a.A[ci * C + co], acc);
+        gy[ci] = acc;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) gy[c] = gv[c];
+    }
+    if (a.v) {
+      float o[CI];   // only the log_s half of the network output is needed
+#pragma unroll
+      for (int c = 0; c < CI; ++c) o[c] = a.b3[c];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int ii = i + dy, jj = j + dx;
+        if (ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) {
+          const float* src = a.P + (size_t)(tap * C) * a.Q + (q + dy * a.w + dx);
+#pragma unroll
+          for (int c = 0; c < CI; ++c) o[c] += src[(size_t)c * a.Q];
+        }
+      }
+      float* go = a.g_o + (size_t)q * C;
+      float* gh = a.ghalf_out + (size_t)q * C;
+#pragma unroll
+      for (int k = 0; k < CI; ++k) {
+        const float log_s = tanhf(o[k]);
+        const float sc = expf(log_s);
+        const float va = a.v[(size_t)q * C + k];
+        const float gya = gy[k];
+        const float g_ls = gya * sc * va + 1.0f;          // + 1: d(sum log_s)/d log_s (flow_tfp_bijectors.py:150-153)
+        go[k] = g_ls * (1.0f - log_s * log_s);            // through tanh
+        go[CI + k] = gya;                                 // g_t
+        gh[k] = gya * sc;                                 // g_va
+        gh[CI + k] = gy[CI + k];                          // g_yb (the network's contribution is merged by the next call)
+      }
+    } else {
+      float* gu = a.gu_out + (size_t)q * C;
+#pragma unroll
+      for (int c = 0; c < C; ++c) gu[c] = gy[c];
+    }
+  }
+}
+
+// gradient of the prior log-density wrt the latent (flow_builder.py:131-144): -(z - loc)/sigma^2 or -z
+__global__ __launch_bounds__(256) void k_prior_grad(const float* __restrict__ z, size_t total, int E, const float* __restrict__ loc,
+                                                   const float* __restrict__ log_scale, float* __restrict__ gz) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int e = (int)(idx % E);
+  const float zv = z[idx];
+  gz[idx] = loc ? -(zv - loc[e]) * expf(-2.0f * log_scale[e]) : -zv;
+}
+
+// backward of k_split: g_o [N,h,w,C] = concat(reshape(gz slice), unsqueeze(g_unext))
+template <int C>
+__global__ __launch_bounds__(256) void k_bwd_split(const float* __restrict__ gz, int HWl, int Cl, int off, int Cz,
+                                                  const float* __restrict__ gun, int h, int w, float* __restrict__ go) {
+  constexpr int CH = C / 2;
+  constexpr int C2 = 2 * C;
+  const int n = blockIdx.x, hw = h * w;
+  float* gn = go + (size_t)n * hw * C;
+  for (int e = threadIdx.x; e < hw * CH; e += 256) {
+    const int pp = e / CH, k = e % CH;
+    gn[(size_t)pp * C + k] = gz[((size_t)n * HWl + e / Cz) * Cl + off + e % Cz];
+  }
+  const int h2 = h / 2, w2 = w / 2;
+  const float* un = gun + (size_t)n * h2 * w2 * C2;
+  for (int e = threadIdx.x; e < h2 * w2 * C2; e += 256) {
+    const int pp = e / C2, cc = e % C2;
+    const int i = pp / w2, j = pp % w2;
+    const int cin = cc >> 2, da = (cc >> 1) & 1, db = cc & 1;
+    gn[(size_t)((2 * i + da) * w + 2 * j + db) * C + CH + cin] = un[e];
+  }
+}
+
+// backward of k_in: g_u [N,h,w,C] -> unsqueeze -> through SpecPreprocessing (incl. its own log-det term) -> g_x [N,2h,2w,C/4]
+template <int C>
+__global__ __launch_bounds__(256) void k_bwd_in(const float* __restrict__ gu, const float* __restrict__ x, int h, int w, PreArgs pre,
+                                               float* __restrict__ gx) {
+  constexpr int Cin = C / 4;
+  const int n = blockIdx.x, H = 2 * h, W = 2 * w;
+  const float inv = 1.0f / (pre.maxval - pre.minval);
+  for (int pp = threadIdx.x; pp < h * w; pp += 256) {
+    const int i = pp / w, j = pp % w;
+    const float* src = gu + ((size_t)n * h * w + pp) * C;
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) {
+      const int cin = cc >> 2, da = (cc >> 1) & 1, db = cc & 1;
+      const size_t xi = ((size_t)(n * H + 2 * i + da) * W + (2 * j + db)) * Cin + cin;
+      float g = src[cc];
+      if (pre.use_logit) {
+        // y = log p - log(1-p), ld = -log p - log(1-p), p = (1-2a) u + a, u = (x-min)/(max-min)
+        const float u = (x[xi] - pre.minval) * inv;
+        const float p = (1.0f - 2.0f * pre.alpha) * u + pre.alpha;
+        const float dp = (1.0f - 2.0f * pre.alpha) * inv;
+        g = g * dp * (1.0f / p + 1.0f / (1.0f - p)) + dp * (-1.0f / p + 1.0f / (1.0f - p));
+      } else {
+        g = g * inv;
+      }
+      gx[xi] = g;
+    }
+  }
 }
