@@ -1,0 +1,97 @@
+"""BASIS separation loop (annealed Langevin dynamics with two flow priors) on top of the glowk log_prob + gradient path.
+
+Mirrors the glow branch of the reference's ``run_basis_sep.py``: ``get_sigmas`` (ncsn/utils.py:7-14), the dB mixing
+process ``g`` / ``grad_g`` (run_basis_sep.py:131-147), ``basis_inner_loop`` (:152-214) and ``basis_outer_loop`` (:217-260).
+The per-step arithmetic outside ``compute_grad_logprob`` is a handful of elementwise ops on ``[n_mixed, H, W, 1]`` tensors
+(< 0.1 % of a step); it runs as torch ops on the same stream.  The noise source is injectable so that tests can replay
+the oracle's draws (the reference draws fresh ``tf.random.normal`` noise, unseeded).
+
+Convention: ``x1, x2, mixed`` live in the space the two flows were built for -- with
+``build_glow(..., data_type='melspec')`` that is dB; the flows' own SpecPreprocessing maps it to the network's range.
+Tiles are independent, so ``shard`` splits ``n_mixed`` over the ranks of a process group with no collective in the loop.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .distributed import shard_bounds
+
+
+def get_sigmas(sigma1, sigmaL, num_classes, progression="geometric"):
+    """ncsn/utils.py:7-14."""
+    if progression == "geometric":
+        sigmas = np.exp(np.linspace(np.log(sigma1), np.log(sigmaL), num=num_classes))
+    elif progression == "logarithmic":
+        sigmas = np.logspace(np.log(sigma1) / np.log(10), np.log(sigmaL) / np.log(10), num=num_classes)
+    else:
+        raise ValueError("progression should be geometric or logarithmic")
+    return sigmas.astype(np.float32)
+
+
+def mixing_db(*sources):
+    """``g`` of the dB branch, sum in power (run_basis_sep.py:133-141): 10/ln10 * (logsumexp(s ln10/10) - ln K)."""
+    k = len(sources)
+    s = torch.stack(sources, dim=0)
+    return (10.0 / math.log(10.0)) * (torch.logsumexp(s * (math.log(10.0) / 10.0), dim=0) - math.log(float(k)))
+
+
+def grad_mixing_db(*sources):
+    """``grad_g`` (run_basis_sep.py:143-147): softmax over the sources of s ln10/10."""
+    s = torch.stack(sources, dim=0)
+    return torch.unbind(torch.softmax(s * (math.log(10.0) / 10.0), dim=0), dim=0)
+
+
+def compute_grad_logprob(inputs, model):
+    """run_basis_sep.py:73-79 -- d log_prob / d inputs through the engine (no autograd tape needed)."""
+    _, g = model.engine.log_prob_grad(inputs)
+    return g
+
+
+def basis_inner_loop(mixed, x1, x2, model1, model2, sigma_idx, sigmas, delta=2e-5, T=100, noise_fn=None, debug=False):
+    """run_basis_sep.py:152-214 (model_type == 'glow').  ``noise_fn(t, which, shape) -> standard normal tensor``."""
+    sigma = float(sigmas[sigma_idx])
+    sigma_l = float(sigmas[-1])
+    eta = float(np.float32(delta * (sigma / sigma_l) ** 2))
+    lambda_recon = 1.0 / (sigma ** 2)
+    if noise_fn is None:
+        noise_fn = lambda t, which, shape: torch.randn(shape, device=x1.device, dtype=torch.float32)  # noqa: E731
+    for t in range(T):
+        eps1 = math.sqrt(2.0 * eta) * noise_fn(t, 0, x1.shape)
+        eps2 = math.sqrt(2.0 * eta) * noise_fn(t, 1, x2.shape)
+        g1 = compute_grad_logprob(x1, model1)
+        g2 = compute_grad_logprob(x2, model2)
+        mix = mixing_db(x1, x2)
+        m1, m2 = grad_mixing_db(x1, x2)
+        x1n = x1 + eta * (g1 + lambda_recon * m1 * (mixed - mix)) + eps1
+        x2n = x2 + eta * (g2 + lambda_recon * m2 * (mixed - mix)) + eps2
+        x1, x2 = x1n, x2n
+        if debug:
+            assert torch.isfinite(x1).all() and torch.isfinite(x2).all(), (sigma, t)   # run_basis_sep.py:183-191
+    return x1, x2
+
+
+def basis_outer_loop(mixed, x1, x2, model1, model2, sigmas, restore_1=None, restore_2=None, T=100, delta=2e-5, noise_fn=None,
+                     debug=False):
+    """run_basis_sep.py:217-260.  ``restore_k``: optional ``{sigma: state_dict or path}`` with the noise-conditioned
+    weights of model k for each noise level (the per-sigma checkpoints of train_noisy_glow.py:309-358)."""
+    x_arr = {"x1": [x1.cpu().numpy()], "x2": [x2.cpu().numpy()]}
+    for sigma_idx, sigma in enumerate(sigmas):
+        for model, restore in ((model1, restore_1), (model2, restore_2)):
+            if restore is not None:
+                state = restore[float(sigma)] if float(sigma) in restore else restore[sigma]
+                if isinstance(state, str):
+                    model.restore(state)
+                else:
+                    model.load_state_dict(state)
+        nf = None if noise_fn is None else (lambda t, which, shape, _s=sigma_idx: noise_fn(_s, t, which, shape))
+        x1, x2 = basis_inner_loop(mixed, x1, x2, model1, model2, sigma_idx, sigmas, delta=delta, T=T, noise_fn=nf, debug=debug)
+        x_arr["x1"].append(x1.cpu().numpy())
+        x_arr["x2"].append(x2.cpu().numpy())
+    return x1, x2, x_arr
+
+
+def shard(tensor, world_size, rank):
+    """This rank's contiguous slice of the ``n_mixed`` tiles (tiles are independent: no collective inside the loop)."""
+    a, b = shard_bounds(tensor.shape[0], world_size, rank)
+    return tensor[a:b]

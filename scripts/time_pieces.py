@@ -31,3 +31,12 @@ if len(sys.argv) > 1:
     p32 = R.cast_params(params, np.float32)
     t0 = time.time(); R.log_prob(xc.numpy()[:1], p32, cfg.as_dict()); T("numpy fp32 1 tile", t0)
     t0 = time.time(); R.log_prob(xc.numpy(), p32, cfg.as_dict()); T("numpy fp32 4 tiles", t0)
+
+if os.environ.get("GLOWK_TIME_GRAD"):
+    for n in (30, 256, 1024):
+        x = torch.from_numpy(synthetic_mel_tiles(n, cfg)).cuda()
+        lp, dx = eng.log_prob_grad(x); torch.cuda.synchronize()
+        t0 = time.time(); lp, dx = eng.log_prob_grad(x); torch.cuda.synchronize(); dt = time.time() - t0
+        t0 = time.time(); lp2 = eng.log_prob(x); torch.cuda.synchronize(); dt2 = time.time() - t0
+        print("N=%d  log_prob_grad %.4f s -> %.1f tiles/s   (log_prob alone %.4f s; ratio %.2f)  |dx| max %.3g finite %s"
+              % (n, dt, n / dt, dt2, dt / dt2, dx.abs().max().item(), bool(torch.isfinite(dx).all())), flush=True)
