@@ -81,6 +81,57 @@ def cpu_baseline(cfg, params, budget_s=20.0):
     }
 
 
+def secondary_workload(args, cfg, eng, params, rank, world, local_rank, dist):
+    """log_prob_grad: one step = log_prob + d/dx over the resident batch.  basis: one step = one Langevin update of the
+    BASIS loop (two flow priors, run_basis_sep.py:163-181) over ``--batch`` mixture tiles per GPU (reference: 30)."""
+    from audiosourcesep_amd import basis
+    from audiosourcesep_amd.flow_models.flow_glow import GlowFlow
+    from audiosourcesep_amd.synthetic import calibrated_engine
+    n = args.batch
+    x = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=1234 + rank)).cuda()
+    if args.workload == "log_prob_grad":
+        def step():
+            eng.log_prob_grad(x)
+        unit, metric, per_step = "tiles/s", "Glow log_prob + input-gradient tiles/sec", n
+    else:
+        eng2, _ = calibrated_engine(cfg, device=local_rank, init_tiles=max(n, 64), seed=4048)
+        m1, m2 = GlowFlow(eng), GlowFlow(eng2)
+        x2 = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=4321 + rank)).cuda()
+        mixed = basis.mixing_db(x, x2)
+        state = {"x1": torch.rand_like(x) * 120 - 100, "x2": torch.rand_like(x) * 120 - 100}
+        sigmas = basis.get_sigmas(1.0, 0.01, 10)
+
+        def step():
+            state["x1"], state["x2"] = basis.basis_inner_loop(mixed, state["x1"], state["x2"], m1, m2, 9, sigmas, T=1)
+        unit, metric, per_step = "tile-steps/s", "BASIS Langevin tile-steps/sec (2 Glow priors)", n
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": metric, "value": per_step * world * args.steps / elapsed, "unit": unit, "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s, %dx%dx%d tiles, L=%d K=%d n_filters=%d, %d tiles/GPU" % (args.workload, cfg.H, cfg.W, cfg.C, cfg.L, cfg.K, cfg.F, n)},
+        }), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +139,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="tiles per GPU per step")
     ap.add_argument("--config", default="B", choices=["A", "B", "YAML"])
+    ap.add_argument("--workload", default="log_prob", choices=["log_prob", "log_prob_grad", "basis"],
+                    help="log_prob = BASELINE.json's headline metric; the other two are secondary lines (SURVEY section 8f-1)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline sample")
@@ -116,6 +169,9 @@ def main():
     eng.set_precision(_lib.PREC_F32 if args.precision == "f32" else _lib.PREC_F16X3)
     n = args.batch
     eng.reserve(n)
+    if args.workload != "log_prob":
+        secondary_workload(args, cfg, eng, params, rank, world, local_rank, dist)
+        return
     x = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=1234 + rank)).cuda()   # resident in HBM before timing
     lp = torch.empty(n, device="cuda", dtype=torch.float32)
     total = torch.zeros(1, device="cuda", dtype=torch.float64)
