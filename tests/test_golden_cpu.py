@@ -12,7 +12,8 @@ from audiosourcesep_amd.synthetic import synthetic_params
 from oracle import glowref as R
 from oracle import glowref_torch as RT
 
-FILES = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+FILES = sorted(f for f in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz"))
+               if not os.path.basename(f).startswith("real_"))
 
 
 def load(path):
