@@ -37,6 +37,8 @@ struct StepDev {            // device pointers into the arena
   const float4* K2p = nullptr;
   const float4* K3p = nullptr;
   const float4* R0p = nullptr;
+  const float4* RHp = nullptr;   // f16x3 ring image (null: shape not supported by k_net_h3)
+  float sc1 = 1.f, sc2 = 1.f, sc3 = 1.f;
   const float* K3bp = nullptr;   // backward: conv3^T operands of the small-conv chain [NF][9c/2][64]
   const float4* RBp = nullptr;   // backward ring image: K2^T chunk fo | K3b operands of block fo+1 ; conv1^T chunks
   const float *Afwd = nullptr, *bfwd = nullptr, *Ainv = nullptr, *binv = nullptr, *b3 = nullptr;
@@ -69,7 +71,7 @@ struct glowk_handle {
   const float* d_log_scale = nullptr;
   // workspace
   int wsN = 0;
-  float *bufA = nullptr, *bufB = nullptr, *bufP = nullptr, *bufZ = nullptr, *bufC = nullptr;
+  float *bufA = nullptr, *bufB = nullptr, *bufP = nullptr, *bufP2 = nullptr, *bufZ = nullptr, *bufC = nullptr;
   double* bufLd = nullptr;
   double* bufStat = nullptr;    // [STAT_BLOCKS][32] partial sums + [32] means
   // input-gradient path: per-step saves of the forward pass (v, P, ReLU masks) and gradient scratch
@@ -145,7 +147,8 @@ inline int rho(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 inline size_t pad4(size_t n) { return (n + 3) & ~size_t(3); }
 
 struct StepLayout {
-  size_t K1p, ep, K2p, K3p, R0p, K3bp, RBp, Afwd, bfwd, Ainv, binv, b3, total;
+  size_t K1p, ep, K2p, K3p, R0p, K3bp, RBp, RHp, Afwd, bfwd, Ainv, binv, b3, total;
+  size_t slotH;        // floats per slot of the f16x3 ring image (0: does not fit)
   size_t slotB, k3fB;  // backward ring image: floats per slot; floats of its conv3^T-operand part (0: not in the ring)
   size_t slot0, k1f0;  // floats per slot of k_net_f32's ring image; floats of its conv1 part (0: not in the ring)
 };
@@ -173,6 +176,13 @@ StepLayout step_layout(int c, int F) {
     L.k3fB = k3f;
     L.slotB = (size_t)NF * 1024 + k3f;
     L.RBp = o; o += (size_t)(NF + NM1) * L.slotB;
+  }
+  {
+    const int KS = (9 * CI + 15) / 16;
+    const size_t slotH = ((size_t)(NF / 2) * 4 + (size_t)KS * 2) * 256;
+    const bool fitsH = 2 * slotH * 4 + (size_t)6 * F * 4 <= 160 * 1024 && NF % 4 == 0 && CI <= 8;   // RingH::FITS
+    L.slotH = fitsH ? slotH : 0;
+    L.RHp = o; o += fitsH ? (size_t)2 * (NF + NMT) * slotH : 0;
   }
   L.Afwd = o; o += pad4((size_t)c * c);
   L.bfwd = o; o += pad4(c);
@@ -227,7 +237,7 @@ bool pack_affine(const glowk_config& cfg, const Level& lv, int k, float* dst, do
 }
 
 // pack one step into dst (host staging of the arena)
-bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, double* ld_const_out, std::string* err) {
+bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, double* ld_const_out, float* scales3, std::string* err) {
   const int c = lv.c, F = cfg.F, CI = c / 2, CO = c, NF = F / 32, KS1 = (9 * CI) / 2, NMT = (9 * c + 31) / 32;
   const StepLayout L = step_layout(c, F);
   auto T = [&](int id) -> const float* { return lv.host[id][k].data(); };
@@ -291,6 +301,64 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
       if (L.k1f0) std::memcpy(slot + mainf, dst + L.K1p + (size_t)k1blk * k1n, k1n * 4);
     }
   }
+  // ---- f16x3 image (k_net_h3): weights scaled by a power of two, split hi/lo in fp16, A operands in fragment order ----
+  scales3[0] = scales3[1] = scales3[2] = 1.0f;
+  if (L.slotH) {
+    const int KS = (9 * CI + 15) / 16;
+    auto pow2_scale = [](const float* w, size_t n) {
+      float m = 0.0f;
+      for (size_t i = 0; i < n; ++i) m = std::fmax(m, std::fabs(w[i]));
+      int e = 0;
+      if (m > 0.0f) { std::frexp(m, &e); }          // m = f * 2^e, f in [0.5, 1)
+      return 14 - e;                                // |w| * 2^S < 2^14: hi well inside fp16, lo ~2^3 (normal)
+    };
+    const int S1 = pow2_scale(K1, (size_t)9 * CI * F), S2 = pow2_scale(K2, (size_t)F * F), S3 = pow2_scale(K3, (size_t)9 * F * CO);
+    const float act = 32.0f;                        // GLOWK_ACT_SCALE
+    scales3[0] = std::ldexp(1.0f, -S1) / act; scales3[1] = std::ldexp(1.0f, -S2) / act; scales3[2] = std::ldexp(1.0f, -S3) / act;
+    auto put = [](float* row_lane, int j, int hl, float w, int S) {
+      // row = 64 lanes x 8 halves; hi and lo live in consecutive rows; row_lane points at this lane's 8 halves of the hi row
+      const float ws = std::ldexp(w, S);
+      const _Float16 hi = (_Float16)ws;
+      const _Float16 lo = (_Float16)(ws - (float)hi);
+      _Float16* dsth = reinterpret_cast<_Float16*>(row_lane) + (size_t)hl * 64 * 8;
+      dsth[j] = hl ? lo : hi;
+    };
+    const int NFH = NF / 2;
+    size_t cidx = 0;
+    for (int ps = 0; ps < 2; ++ps)
+      for (int step = 0; step < NF + NMT; ++step, ++cidx) {
+        float* slot = dst + L.RHp + cidx * L.slotH;
+        for (int fol = 0; fol < NFH; ++fol)
+          for (int s2 = 0; s2 < 2; ++s2)
+            for (int l = 0; l < 64; ++l)
+              for (int j = 0; j < 8; ++j) {
+                const int i = l & 31, hh = l >> 5, fo = ps * NFH + fol;
+                const int kloc = 16 * s2 + 8 * (j >> 2) + 4 * hh + (j & 3);      // accumulator-derived k order
+                float w;
+                int S;
+                if (step < NF) { w = K2[(size_t)(step * 32 + kloc) * F + fo * 32 + i]; S = S2; }
+                else {
+                  const int m = (step - NF) * 32 + i, f = fo * 32 + kloc;
+                  w = 0.0f; S = S3;
+                  if (m < 9 * CO) { const int tap = m / CO, co = m % CO; w = K3[((size_t)tap * F + f) * CO + co]; }
+                }
+                float* row_lane = slot + ((size_t)((fol * 2 + s2) * 2) * 64 + l) * 4;   // hi row of (fo, s2); 16 B per lane = 4 floats
+                put(row_lane, j, 0, w, S);
+                put(row_lane, j, 1, w, S);
+              }
+        const int blk = step < NF ? (step + 1) % NF : 0;   // conv1 operands riding with this chunk, natural k order
+        for (int s2 = 0; s2 < KS; ++s2)
+          for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+              const int i = l & 31, hh = l >> 5, kk = 16 * s2 + 8 * hh + j;
+              const float w = kk < 9 * CI ? K1[(size_t)kk * F + blk * 32 + i] : 0.0f;
+              float* row_lane = slot + ((size_t)NFH * 4 * 64 + (size_t)(s2 * 2) * 64 + l) * 4;
+              put(row_lane, j, 0, w, S1);
+              put(row_lane, j, 1, w, S1);
+            }
+      }
+  }
+
   // ---- backward images (input-gradient path): same kernel structure, transposed weights ----
   {
     const int KS3 = (9 * c) / 2, NM1 = (9 * CI + 31) / 32;
@@ -342,6 +410,12 @@ int launch_net_t(const NetArgs& a, int mode, hipStream_t s) {
     case NET_FWD:      hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a); break;
     case NET_FWD_SAVE: hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE>), dim3(ntiles), dim3(256), 0, s, a); break;
     case NET_BWD:      hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD>), dim3(ntiles), dim3(256), 0, s, a); break;
+    case 3:
+      if constexpr (RingH<CI, NF>::FITS) {
+        if (a.RHp) { hipLaunchKernelGGL((k_net_h3<CI, NF>), dim3((a.Q + 255) / 256), dim3(512), 0, s, a); break; }
+      }
+      hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a);   // shape without an f16x3 instance
+      break;
     default: return fail("bad k_net mode");
   }
   LAUNCHCHK("k_net_f32");
@@ -399,11 +473,13 @@ int ensure_ws(glowk_handle* h, int N) {
   HIPCHK(hipDeviceSynchronize());
   if (h->bufA) { hipFree(h->bufA); hipFree(h->bufB); hipFree(h->bufP); hipFree(h->bufZ); hipFree(h->bufLd); }
   if (h->bufC) hipFree(h->bufC);
-  h->bufA = h->bufB = h->bufP = h->bufZ = h->bufC = nullptr; h->bufLd = nullptr; h->wsN = 0;
+  if (h->bufP2) hipFree(h->bufP2);
+  h->bufA = h->bufB = h->bufP = h->bufP2 = h->bufZ = h->bufC = nullptr; h->bufLd = nullptr; h->wsN = 0;
   const size_t E = (size_t)h->cfg.H * h->cfg.W * h->cfg.C;
   HIPCHK(hipMalloc(&h->bufA, (size_t)N * E * 4));
   HIPCHK(hipMalloc(&h->bufB, (size_t)N * E * 4));
   HIPCHK(hipMalloc(&h->bufP, (size_t)N * E * 9 * 4));
+  HIPCHK(hipMalloc(&h->bufP2, (size_t)N * E * 9 * 4));
   HIPCHK(hipMalloc(&h->bufZ, (size_t)N * E * 4));
   HIPCHK(hipMalloc(&h->bufLd, (size_t)N * 8));
   h->wsN = N;
@@ -414,7 +490,6 @@ int check_ready(glowk_handle* h, int N) {
   if (!h) return fail("null handle");
   if (!h->finalized) return fail("glowk_finalize_weights has not been called");
   if (N <= 0) return fail("batch size must be positive");
-  if (h->precision != GLOWK_PREC_F32) return fail("precision mode not built");
   return ensure_ws(h, N);
 }
 
@@ -423,6 +498,7 @@ NetArgs net_args(glowk_handle* h, const Level& lv, const StepDev& sd, const floa
   a.vin = vin; a.in_stride = in_stride; a.in_off = in_off;
   a.Q = N * lv.h * lv.w; a.h = lv.h; a.w = lv.w;
   a.K1p = sd.K1p; a.ep = sd.ep; a.K2p = sd.K2p; a.K3p = sd.K3p; a.R0p = sd.R0p; a.mask1 = nullptr; a.mask2 = nullptr; a.P = h->bufP;
+  a.RHp = sd.RHp; a.P2 = h->bufP2; a.sc1 = sd.sc1; a.sc2 = sd.sc2; a.sc3 = sd.sc3;
   return a;
 }
 
@@ -484,9 +560,9 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
         na.mask1 = h->saveM + h->offM[sidx];
         na.mask2 = na.mask1 + blocks * NF * 64;
       }
-      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, save ? NET_FWD_SAVE : NET_FWD)) return rc;
+      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, save ? NET_FWD_SAVE : (h->precision == GLOWK_PREC_F16X3 ? 3 : NET_FWD))) return rc;
       CoupleArgs ca;
-      ca.vin = cur; ca.P = na.P; ca.b3 = sd.b3; ca.logdet = h->bufLd; ca.log_s_out = nullptr; ca.t_out = nullptr;
+      ca.vin = cur; ca.P = na.P; ca.P2 = (!save && h->precision == GLOWK_PREC_F16X3 && sd.RHp) ? h->bufP2 : nullptr; ca.b3 = sd.b3; ca.logdet = h->bufLd; ca.log_s_out = nullptr; ca.t_out = nullptr;
       ca.Q = (int)Q; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0;
       float* next = save && k > 0 ? h->saveV + h->offV[sidx + 1] : oth;
       if (k > 0) {
@@ -600,9 +676,9 @@ int run_inverse(glowk_handle* h, const float* z, int N, float* x, hipStream_t s)
     std::swap(cur, oth);
     for (int k = 0; k < K; ++k) {   // Chain.inverse: step 0 first
       const StepDev& sd = lv.dev[k];
-      if (int rc = launch_net(h, lvl, lv.c, cfg.F, net_args(h, lv, sd, cur, lv.c, lv.c / 2, N), s)) return rc;
+      if (int rc = launch_net(h, lvl, lv.c, cfg.F, net_args(h, lv, sd, cur, lv.c, lv.c / 2, N), s, h->precision == GLOWK_PREC_F16X3 ? 3 : NET_FWD)) return rc;
       CoupleArgs ca;
-      ca.vin = cur; ca.P = h->bufP; ca.b3 = sd.b3; ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
+      ca.vin = cur; ca.P = h->bufP; ca.P2 = (h->precision == GLOWK_PREC_F16X3 && sd.RHp) ? h->bufP2 : nullptr; ca.b3 = sd.b3; ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
       ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 1;
       ca.A = sd.Ainv; ca.b = sd.binv; ca.out = oth; ca.out_stride = lv.c; ca.out_off = 0;
       if (int rc = launch_couple(lv.c, ca, N, s)) return rc;
@@ -666,6 +742,7 @@ int glowk_destroy(glowk_handle* h) {
   if (h->arena) hipFree(h->arena);
   if (h->bufA) { hipFree(h->bufA); hipFree(h->bufB); hipFree(h->bufP); hipFree(h->bufZ); hipFree(h->bufLd); }
   if (h->bufC) hipFree(h->bufC);
+  if (h->bufP2) hipFree(h->bufP2);
   if (h->bufStat) hipFree(h->bufStat);
   if (h->saveV) { hipFree(h->saveV); hipFree(h->saveP); hipFree(h->saveM); hipFree(h->bufGz); }
   for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
@@ -729,9 +806,11 @@ int glowk_finalize_weights(glowk_handle* h) {
     for (int k = 0; k < cfg.K; ++k) {
       std::string err;
       double ldc = 0;
-      if (!pack_step(cfg, lv, k, stage.data() + o, &ldc, &err))
+      float sc3[3];
+      if (!pack_step(cfg, lv, k, stage.data() + o, &ldc, sc3, &err))
         return fail("level " + std::to_string(l) + " step " + std::to_string(k) + ": " + err);
       h->ld_step[l * cfg.K + k] = ldc;
+      h->levels[l].dev[k].sc1 = sc3[0]; h->levels[l].dev[k].sc2 = sc3[1]; h->levels[l].dev[k].sc3 = sc3[2];
       h->ld_const += ldc;
       offs.push_back(o);
       o += step_layout(lv.c, cfg.F).total;
@@ -760,6 +839,7 @@ int glowk_finalize_weights(glowk_handle* h) {
       d.K2p = reinterpret_cast<const float4*>(base + SL.K2p);
       d.K3p = reinterpret_cast<const float4*>(base + SL.K3p);
       d.R0p = reinterpret_cast<const float4*>(base + SL.R0p);
+      d.RHp = SL.slotH ? reinterpret_cast<const float4*>(base + SL.RHp) : nullptr;
       d.K3bp = base + SL.K3bp;
       d.RBp = reinterpret_cast<const float4*>(base + SL.RBp);
       d.Afwd = base + SL.Afwd; d.bfwd = base + SL.bfwd; d.Ainv = base + SL.Ainv; d.binv = base + SL.binv; d.b3 = base + SL.b3;
@@ -784,7 +864,7 @@ int run_step_inplace(glowk_handle* h, int lvl, int k, float* cur, float* tmp, in
   NetArgs na = net_args(h, lv, sd, tmp, lv.c, lv.c / 2, Nl);
   if (int rc = launch_net(h, lvl, lv.c, h->cfg.F, na, s)) return rc;
   CoupleArgs ca;
-  ca.vin = tmp; ca.P = h->bufP; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
+  ca.vin = tmp; ca.P = h->bufP; ca.P2 = nullptr; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
   ca.out = cur; ca.out_stride = lv.c; ca.out_off = 0;
   ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
   ca.Q = Q; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0;
@@ -887,7 +967,7 @@ int glowk_actnorm_data_init(glowk_handle* h, const float* x_dev, int N, int runt
 
 int glowk_set_precision(glowk_handle* h, int precision) {
   if (!h) return fail("null handle");
-  if (precision != GLOWK_PREC_F32) return fail("precision mode not available in this build");
+  if (precision != GLOWK_PREC_F32 && precision != GLOWK_PREC_F16X3) return fail("unknown precision mode");
   h->precision = precision;
   return 0;
 }
@@ -897,7 +977,7 @@ int glowk_get_precision(const glowk_handle* h) { return h ? h->precision : -1; }
 size_t glowk_workspace_bytes(const glowk_handle* h, int N) {
   if (!h || N <= 0) return 0;
   const size_t E = (size_t)h->cfg.H * h->cfg.W * h->cfg.C;
-  return (size_t)N * E * 4 * 12 + (size_t)N * 8;
+  return (size_t)N * E * 4 * 21 + (size_t)N * 8;
 }
 
 int glowk_reserve(glowk_handle* h, int N) {
@@ -1046,7 +1126,7 @@ int glowk_step_forward(glowk_handle* h, int level, int step, const float* u_dev,
   const int Q = N * lv.h * lv.w;
   CDISPATCH(lv.c, hipLaunchKernelGGL((k_affine<CC>), dim3((Q + 255) / 256), dim3(256), 0, s, u_dev, Q, sd.Afwd, sd.bfwd, h->bufA));
   LAUNCHCHK("k_affine");
-  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, h->bufA, lv.c, lv.c / 2, N), s)) return rc;
+  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, h->bufA, lv.c, lv.c / 2, N), s, h->precision == GLOWK_PREC_F16X3 ? 3 : NET_FWD)) return rc;
   if (logdet_dev) {
     // logdet accumulator starts at the step's constant h*w*(sum log_scale + sum log_S)
     PreArgs p = {0, 1, 0, 0};
@@ -1056,7 +1136,7 @@ int glowk_step_forward(glowk_handle* h, int level, int step, const float* u_dev,
     HIPCHK(hipStreamSynchronize(s));
   }
   CoupleArgs ca;
-  ca.vin = h->bufA; ca.P = h->bufP; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
+  ca.vin = h->bufA; ca.P = h->bufP; ca.P2 = (h->precision == GLOWK_PREC_F16X3 && sd.RHp) ? h->bufP2 : nullptr; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
   ca.out = y_dev; ca.out_stride = lv.c; ca.out_off = 0;
   ca.logdet = logdet_dev ? h->bufLd : nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
   ca.Q = Q; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0;
@@ -1076,9 +1156,9 @@ int glowk_step_inverse(glowk_handle* h, int level, int step, const float* y_dev,
   hipStream_t s = (hipStream_t)stream;
   const Level& lv = h->levels[level];
   const StepDev& sd = lv.dev[step];
-  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, y_dev, lv.c, lv.c / 2, N), s)) return rc;
+  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, y_dev, lv.c, lv.c / 2, N), s, h->precision == GLOWK_PREC_F16X3 ? 3 : NET_FWD)) return rc;
   CoupleArgs ca;
-  ca.vin = y_dev; ca.P = h->bufP; ca.b3 = sd.b3; ca.A = sd.Ainv; ca.b = sd.binv;
+  ca.vin = y_dev; ca.P = h->bufP; ca.P2 = (h->precision == GLOWK_PREC_F16X3 && sd.RHp) ? h->bufP2 : nullptr; ca.b3 = sd.b3; ca.A = sd.Ainv; ca.b = sd.binv;
   ca.out = u_dev; ca.out_stride = lv.c; ca.out_off = 0;
   ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
   ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 1;
@@ -1092,9 +1172,9 @@ int glowk_coupling_net(glowk_handle* h, int level, int step, const float* xb_dev
   hipStream_t s = (hipStream_t)stream;
   const Level& lv = h->levels[level];
   const StepDev& sd = lv.dev[step];
-  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, xb_dev, lv.c / 2, 0, N), s)) return rc;
+  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, xb_dev, lv.c / 2, 0, N), s, h->precision == GLOWK_PREC_F16X3 ? 3 : NET_FWD)) return rc;
   CoupleArgs ca;
-  ca.vin = nullptr; ca.P = h->bufP; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
+  ca.vin = nullptr; ca.P = h->bufP; ca.P2 = (h->precision == GLOWK_PREC_F16X3 && sd.RHp) ? h->bufP2 : nullptr; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
   ca.out = nullptr; ca.out_stride = 0; ca.out_off = 0;
   ca.logdet = nullptr; ca.log_s_out = log_s_dev; ca.t_out = t_dev;
   ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0;

@@ -45,6 +45,9 @@ struct NetArgs {
   unsigned short* mask1; // [blocks of 32 px][NF][64 lanes] ReLU mask bits of conv1 (NET_FWD_SAVE writes, NET_BWD reads)
   unsigned short* mask2; // same for conv2
   float* P;              // [9*CO][Q]
+  float* P2;             // f16x3: partial sums of the second pass
+  const float4* RHp;     // f16x3 ring image (RingH), or null
+  float sc1, sc2, sc3;   // f16x3: 2^-(weight scale + activation scale) of conv1 / conv2 / conv3
 };
 
 // one 64-lane LDS-DMA piece: LDS destination = wave-uniform base + lane*16, global source per lane
@@ -303,6 +306,244 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_net_h3: the coupling network with every contraction as THREE fp16 MFMAs on error-compensated splits
+//   x = hi + lo,  hi = fp16(x), lo = fp16(x - hi);   a.b ~= a_hi.b_hi + a_hi.b_lo + a_lo.b_hi   (fp32 accumulate)
+// (fp16 products are exact in fp32; the dropped lo.lo term is 2^-22 relative) -- fp32-class accuracy at 3/16 of the
+// fp32-MFMA time.  Weights are split on the host after scaling by a power of two that keeps lo out of the fp16
+// subnormal range; activations are scaled by 2^5 before splitting; the scales are undone exactly in the epilogues.
+// Same structure and ring rules as k_net_f32 (NET_FWD); chunk = per hidden block: [fo][k-step s][hi|lo][64 lanes] half8.
+// B operands taken from accumulators use registers 8s..8s+7 as k-step s, so element j of lane half h is k-row
+// 16s + 8(j>>2) + 4h + (j&3) of the tile: the host packs the A operands in that order.
+// ------------------------------------------------------------------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#define GLOWK_ACT_SCALE 32.0f
+
+// Geometry: 8 waves per workgroup (2 per SIMD), one 32-pixel column block each (256 pixels per workgroup); the hidden
+// width is covered in 2 passes of NFH = NF/2 accumulator tiles (128 AGPRs per wave), so that each weight chunk
+// [NFH fo][2 k-steps][hi|lo][64 lanes] half8 = NFH * 4 KiB serves 256 pixels (half the DMA bytes and DMA issues per MFMA
+// of the one-pass layout) and the partner wave on the SIMD hides the DMA-issue / conv1 / epilogue phases.
+// Ring image: per pass p: conv2 chunks fi = 0..NF-1 (main = K2[fi-tile, fo in pass p] | conv1 operands of block fi+1),
+// then conv3 chunks mt (main = K3[mt tile, f in pass p] | conv1 operands of block 0).  conv3's contraction over F is split
+// by pass: pass p stores its partial sums to P_p, k_couple adds the two.
+template <int CI, int NF>
+struct RingH {
+  static constexpr int NFH = NF / 2;
+  static constexpr int K1 = 9 * CI;
+  static constexpr int KS = (K1 + 15) / 16;                       // conv1 k-steps of 16
+  static constexpr int MAIN4 = NFH * 256;                         // 16-B rows of 64 lanes: NFH fo x 2 s x 2 (hi, lo)
+  static constexpr int K1PIECES = KS * 2;
+  static constexpr int SLOT4 = MAIN4 + K1PIECES * 64;
+  static constexpr int PIECES = NFH * 4 + K1PIECES;
+  static constexpr int NMT = (18 * CI + 31) / 32;
+  static constexpr int STEPS_PASS = NF + NMT;
+  static constexpr size_t LDS_BYTES = (size_t)2 * SLOT4 * 16 + (size_t)6 * NF * 32 * 4;
+  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && CI <= 8;
+};
+
+// pieces [P0, P0 + N) of a ring slot image dealt round-robin to NW waves
+template <int P0, int N, int NW>
+__device__ __forceinline__ void stage_range_w(const float4* __restrict__ src, float4* dst, int wave, unsigned voff) {
+  const char* gb = uniform_ptr(src);
+#pragma unroll
+  for (int i = 0; i < (N + NW - 1) / NW; ++i) {
+    int p = i * NW + wave;
+    p = P0 + (p < N ? p : N - 1);
+    glds16(reinterpret_cast<const float4*>(gb + (size_t)p * 1024 + voff), dst + p * 64);
+  }
+}
+
+__device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    hi[j] = (_Float16)v[j];
+    lo[j] = (_Float16)(v[j] - (float)hi[j]);
+  }
+}
+
+__device__ __forceinline__ f32x16 mfma3(const h8& ahi, const h8& alo, const h8& bhi, const h8& blo, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc, 0, 0, 0);
+  return acc;
+}
+
+#define GLOWK_WAIT_BARRIER()                          \
+  do {                                                \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  \
+    __syncthreads();                                  \
+  } while (0)
+
+// conv2 contribution of hidden block fi to this pass's NFH accumulator tiles (conv1 of block fi first; its operands were
+// published with the previous chunk, slot P^1).  Measured alternative, rejected: running conv1(next) and conv2(cur) in
+// opposite orders in the two halves of the workgroup (to de-phase the two waves of a SIMD) doubled the code of the step
+// and brought back ~470 spilled registers reloaded behind the DMA: 2.6x slower.
+template <int CI, int NF, int P>
+__device__ __forceinline__ void h3_step(const NetArgs& a, int fi, const float4* nsrc, float4* s0, float4* s1, const float* epl,
+                                        const h8 (&xh)[(RingH<CI, NF>::KS)], const h8 (&xl)[(RingH<CI, NF>::KS)],
+                                        f32x16 (&acc2)[(RingH<CI, NF>::NFH)], int wave, unsigned voff, int lane, int hh) {
+  using G = RingH<CI, NF>;
+  constexpr int F = NF * 32;
+  f32x16 h1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) h1[r] = 0.0f;
+  {
+    const h8* k1 = reinterpret_cast<const h8*>(ring_slot<P ^ 1>(s0, s1) + G::MAIN4) + lane;   // [s][hi|lo][64]
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s) h1 = mfma3(k1[(2 * s + 0) * 64], k1[(2 * s + 1) * 64], xh[s], xl[s], h1);
+  }
+  // bias + ReLU + BN1, then scale and split into the B fragments of conv2's two k-steps
+  h8 bh[2], bl[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = 8 * s + j;
+      const int f = fi * 32 + mfma_row(r, hh);
+      v[j] = fmaf(epl[F + f], fmaxf(fmaf(h1[r], a.sc1, epl[f]), 0.0f), epl[2 * F + f]) * GLOWK_ACT_SCALE;
+    }
+    split8(v, bh[s], bl[s]);
+  }
+  GLOWK_WAIT_BARRIER();   // this step's chunk landed in every wave's view; slot P^1 is no longer read
+  stage_range_w<0, G::PIECES, 8>(nsrc, ring_slot<P ^ 1>(s0, s1), wave, voff);
+  const h8* buf = reinterpret_cast<const h8*>(ring_slot<P>(s0, s1)) + lane;
+#pragma unroll
+  for (int fo = 0; fo < G::NFH; ++fo) {
+    acc2[fo] = mfma3(buf[(fo * 4 + 0) * 64], buf[(fo * 4 + 1) * 64], bh[0], bl[0], acc2[fo]);
+    acc2[fo] = mfma3(buf[(fo * 4 + 2) * 64], buf[(fo * 4 + 3) * 64], bh[1], bl[1], acc2[fo]);
+  }
+}
+
+// one pass (F_out half PASS) of the workgroup's 256 pixels; the pass's first chunk sits in slot P0
+template <int CI, int NF, int P0, int PASS>
+__device__ __forceinline__ void h3_pass(const NetArgs& a, const float4* ring, float4* s0, float4* s1, const float* epl,
+                                        const h8 (&xh)[(RingH<CI, NF>::KS)], const h8 (&xl)[(RingH<CI, NF>::KS)], int q, bool qok, int wave,
+                                        unsigned voff, int lane, int hh) {
+  using G = RingH<CI, NF>;
+  constexpr int F = NF * 32;
+  constexpr int SLOT4 = G::SLOT4;
+  constexpr int NMT = G::NMT;
+  constexpr int M3 = 18 * CI;
+  constexpr int f2base = PASS * G::NFH * 32;
+  const float4* chunk = ring + (size_t)PASS * G::STEPS_PASS * SLOT4;
+  f32x16 acc2[G::NFH];
+#pragma unroll
+  for (int fo = 0; fo < G::NFH; ++fo)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[fo][r] = 0.0f;
+
+#pragma nounroll
+  for (int fi = 0; fi < NF; fi += 2) {
+    h3_step<CI, NF, P0>(a, fi, chunk + (size_t)(fi + 1) * SLOT4, s0, s1, epl, xh, xl, acc2, wave, voff, lane, hh);
+    h3_step<CI, NF, P0 ^ 1>(a, fi + 1, chunk + (size_t)(fi + 2) * SLOT4, s0, s1, epl, xh, xl, acc2, wave, voff, lane, hh);
+  }
+
+  // bias + ReLU + BN2 of this pass's hidden channels, pre-scaled for the conv3 split
+#pragma unroll
+  for (int fo = 0; fo < G::NFH; ++fo)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = f2base + fo * 32 + mfma_row(r, hh);
+      acc2[fo][r] = fmaf(epl[4 * F + f], fmaxf(fmaf(acc2[fo][r], a.sc2, epl[3 * F + f]), 0.0f), epl[5 * F + f]) * GLOWK_ACT_SCALE;
+    }
+
+  float* Pp = PASS == 0 ? a.P : a.P2;
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) {
+    GLOWK_WAIT_BARRIER();
+    constexpr bool dummy = false; (void)dummy;
+    const bool last_of_all = (PASS == 1) && (mt == NMT - 1);
+    const float4* nsrc = chunk + (size_t)(NF + mt + 1) * SLOT4;     // next conv3 chunk, or the next pass's first chunk
+    const h8* buf;
+    if ((mt & 1) == 0) {
+      if (!last_of_all) stage_range_w<0, G::PIECES, 8>(nsrc, ring_slot<P0 ^ 1>(s0, s1), wave, voff);
+      buf = reinterpret_cast<const h8*>(ring_slot<P0>(s0, s1)) + lane;
+    } else {
+      if (!last_of_all) stage_range_w<0, G::PIECES, 8>(nsrc, ring_slot<P0>(s0, s1), wave, voff);
+      buf = reinterpret_cast<const h8*>(ring_slot<P0 ^ 1>(s0, s1)) + lane;
+    }
+    f32x16 acc3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc3[r] = 0.0f;
+#pragma unroll
+    for (int fo = 0; fo < G::NFH; ++fo) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = acc2[fo][8 * s + j];
+        h8 bh, bl;
+        split8(v, bh, bl);
+        acc3 = mfma3(buf[(fo * 4 + 2 * s + 0) * 64], buf[(fo * 4 + 2 * s + 1) * 64], bh, bl, acc3);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mt * 32 + mfma_row(r, hh);
+      if (m < M3 && qok) Pp[(size_t)m * a.Q + q] = acc3[r] * a.sc3;
+    }
+  }
+}
+
+template <int CI, int NF>
+__global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
+  using G = RingH<CI, NF>;
+  constexpr int K1 = G::K1;
+  constexpr int KS = G::KS;
+  constexpr int F = NF * 32;
+  constexpr int SLOT4 = G::SLOT4;
+  static_assert(G::FITS, "shape");
+
+  __shared__ float4 slot0[SLOT4];
+  __shared__ float4 slot1[SLOT4];
+  __shared__ float epl[6 * F];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
+  const unsigned voff = (unsigned)lane * 16u;
+  const int pix = lane & 31;
+  const int hh = lane >> 5;
+  const int q = (blockIdx.x * 8 + (tid >> 6)) * 32 + pix;
+  const bool qok = q < a.Q;
+  const float4* ring = a.RHp;
+
+  // im2col fragments of this lane's pixel: k-step s holds k = 16 s + 8 hh + j (natural order), scaled and split
+  h8 xh[KS], xl[KS];
+  {
+    const int hw = a.h * a.w;
+    const int qq = qok ? q : 0;
+    const int rem = qq % hw;
+    const int i = rem / a.w, j0 = rem % a.w;
+    const float* base = a.vin + (long)qq * a.in_stride + a.in_off;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 16 * s + 8 * hh + j;
+        const int tap = k / CI, cin = k % CI;
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int ii = i + dy, jj = j0 + dx;
+        const bool ok = qok && k < K1 && ii >= 0 && ii < a.h && jj >= 0 && jj < a.w;
+        const int off = ok ? ((dy * a.w + dx) * a.in_stride + cin) : 0;
+        const float x = base[off];
+        v[j] = ok ? x * GLOWK_ACT_SCALE : 0.0f;
+      }
+      split8(v, xh[s], xl[s]);
+    }
+  }
+  for (int i = tid; i < 6 * F; i += 512) epl[i] = a.ep[i];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // gathers done before any DMA is issued
+  stage_range_w<0, G::PIECES, 8>(ring, slot0, wave, voff);                                                          // chunk 0 -> slot 0
+  stage_range_w<G::NFH * 4, G::K1PIECES, 8>(ring + (size_t)(G::STEPS_PASS - 1) * SLOT4, slot1, wave, voff);        // conv1 operands of block 0
+  GLOWK_WAIT_BARRIER();   // ep, chunk 0 and block-0 conv1 operands visible to every wave
+
+  h3_pass<CI, NF, 0, 0>(a, ring, slot0, slot1, epl, xh, xl, q, qok, wave, voff, lane, hh);
+  h3_pass<CI, NF, (G::STEPS_PASS & 1), 1>(a, ring, slot0, slot1, epl, xh, xl, q, qok, wave, voff, lane, hh);
+}
+
 // ------------------------------------------------------------------------------------------------
 // light kernels: one 256-thread workgroup per sample (deterministic per-sample reductions, no atomics)
 // ------------------------------------------------------------------------------------------------
@@ -426,6 +667,7 @@ __global__ __launch_bounds__(256) void k_pre_only(const float* __restrict__ x, i
 struct CoupleArgs {
   const float* vin;     // [Q][C]: forward: v = 1x1(actnorm(u)); inverse: y
   const float* P;       // [9C][Q] per-tap partial conv3 outputs of the network evaluated on vin[.., C/2:]
+  const float* P2;      // optional second partial (f16x3 path: the conv3 contraction is split over two passes)
   const float* b3;      // [C] conv3 bias
   const float* A;       // post affine [C][C] or null: forward = NEXT step's ActNorm+1x1, inverse = this step's inverse 1x1+ActNorm
   const float* b;       // [C]
@@ -458,9 +700,15 @@ __global__ __launch_bounds__(256) void k_couple(CoupleArgs a) {
       const int dy = tap / 3 - 1, dx = tap % 3 - 1;
       const int ii = i + dy, jj = j + dx;
       if (ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) {
-        const float* src = a.P + (size_t)(tap * C) * a.Q + (q + dy * a.w + dx);
+        const size_t off = (size_t)(tap * C) * a.Q + (q + dy * a.w + dx);
+        const float* src = a.P + off;
 #pragma unroll
         for (int c = 0; c < C; ++c) o[c] += src[(size_t)c * a.Q];
+        if (a.P2) {
+          const float* src2 = a.P2 + off;
+#pragma unroll
+          for (int c = 0; c < C; ++c) o[c] += src2[(size_t)c * a.Q];
+        }
       }
     }
     if (a.vin) {

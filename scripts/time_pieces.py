@@ -10,6 +10,8 @@ def T(msg, t0):
 
 cfg = CONFIG_B
 t0 = time.time(); eng, params = calibrated_engine(cfg, device=0); torch.cuda.synchronize(); T("calibrated_engine", t0)
+if os.environ.get("GLOWK_PREC"):
+    eng.set_precision(int(os.environ["GLOWK_PREC"]))
 for n in (32, 128, 512, 1024):
     x = torch.from_numpy(synthetic_mel_tiles(n, cfg)).cuda()
     eng.reserve(n)

@@ -229,3 +229,48 @@ def test_error_behaviour(gpu):
     eng.set_tensor("b0/s0/inv1x1/P", np.zeros((4, 4), np.float32))  # singular permutation
     with pytest.raises(_lib.GlowkError):
         eng.finalize()
+
+
+# ---- GLOWK_PREC_F16X3: error-compensated fp16 split, 3 MFMAs per product ---------------------------------------------
+@pytest.mark.parametrize("name", ["tiny_L3_rect", "config_A"])
+def test_f16x3_precision_mode_matches_fp64_oracle(gpu, name):
+    """The split-fp16 path must stay fp32-class: log_prob within 2e-6 relative of the fp64 oracle (bar 1e-4), latent
+    within 1e-4, and within 2e-6 of the exact-fp32 kernel's own result."""
+    from audiosourcesep_amd import _lib
+    cfg = CASES[name]
+    eng, params = make_engine(gpu, cfg)
+    x = synthetic_mel_tiles(3, cfg)
+    lp32, z32 = eng.log_prob(dev(x), return_latent=True)
+    eng.set_precision(_lib.PREC_F16X3)
+    lp16, z16 = eng.log_prob(dev(x), return_latent=True)
+    pr = p64(params)
+    z_ref, ld_ref = R.bijector_forward(x.astype(np.float64), pr, cfg.as_dict())
+    lp_ref = R.prior_log_prob(z_ref, pr, cfg.as_dict()) + ld_ref
+    print("f16x3 max rel err log_prob vs fp64: %.3e   (fp32 kernel: %.3e)   max |z16 - z_ref| %.3e  (fp32: %.3e)" % (
+        np.max(np.abs(lp16.cpu().numpy() - lp_ref) / np.abs(lp_ref)), np.max(np.abs(lp32.cpu().numpy() - lp_ref) / np.abs(lp_ref)),
+        np.max(np.abs(z16.cpu().numpy() - z_ref)), np.max(np.abs(z32.cpu().numpy() - z_ref))))
+    np.testing.assert_allclose(lp16.cpu().numpy(), lp_ref, rtol=2e-6)
+    np.testing.assert_allclose(z16.cpu().numpy(), z_ref, atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(lp16.cpu().numpy(), lp32.cpu().numpy(), rtol=2e-6)
+    xr = eng.inverse(z16).cpu().numpy()
+    np.testing.assert_allclose(xr, x, atol=5e-3)
+    eng.set_precision(_lib.PREC_F32)
+    assert torch.equal(eng.log_prob(dev(x)), lp32)
+
+
+def test_f16x3_full_size_accuracy(gpu):
+    """Config B (the metric's config) in f16x3 mode against the fp64 oracle on 2 tiles and against the fp32 kernel on 64."""
+    from audiosourcesep_amd import _lib
+    cfg = CONFIG_B
+    eng, params = make_engine(gpu, cfg)
+    x = synthetic_mel_tiles(2, cfg)
+    lp_ref = R.log_prob(x.astype(np.float64), p64(params), cfg.as_dict())
+    xb = synthetic_mel_tiles(64, cfg, seed=5)
+    lp32 = eng.log_prob(dev(xb)).cpu().numpy()
+    eng.set_precision(_lib.PREC_F16X3)
+    lp16 = eng.log_prob(dev(x)).cpu().numpy()
+    lp16b = eng.log_prob(dev(xb)).cpu().numpy()
+    print("config B f16x3: rel err vs fp64 %s ; max rel diff vs fp32 kernel over 64 tiles %.3e" % (
+        np.abs(lp16 - lp_ref) / np.abs(lp_ref), np.max(np.abs(lp16b - lp32) / np.abs(lp32))))
+    np.testing.assert_allclose(lp16, lp_ref, rtol=5e-6)          # north-star bar: 1e-4
+    np.testing.assert_allclose(lp16b, lp32, rtol=5e-6)
