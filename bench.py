@@ -34,6 +34,7 @@ from audiosourcesep_amd.config import GlowConfig, CONFIG_A, CONFIG_B, CONFIG_YAM
 from audiosourcesep_amd.synthetic import synthetic_params, synthetic_mel_tiles  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md:42
+PEAK_F16_MFMA_TFLOPS = 2500.0  # :43 (dense); the split path issues 3 fp16 MFMAs per fp32-equivalent product
 PEAK_HBM_GBS = 8000.0          # :36
 
 
@@ -141,7 +142,9 @@ def main():
     ap.add_argument("--config", default="B", choices=["A", "B", "YAML"])
     ap.add_argument("--workload", default="log_prob", choices=["log_prob", "log_prob_grad", "basis"],
                     help="log_prob = BASELINE.json's headline metric; the other two are secondary lines (SURVEY section 8f-1)")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"])
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
+                    help="f16x3: error-compensated fp16 split on the fp16 MFMA (fp32-class accuracy, demonstrated in the line); "
+                         "f32: exact fp32-input MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline sample")
     args = ap.parse_args()
@@ -183,65 +186,103 @@ def main():
         _, tot = sharded_log_prob(lambda xx: eng.log_prob(xx, out=lp), x)
         total.copy_(tot)
 
+    def timed(k_steps):
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(k_steps):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        pr = eng.profile_end()
+        if dist is not None:
+            t = torch.tensor([el], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, pr
+
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    eng.profile_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    prof = eng.profile_end()
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, prof = timed(args.steps)
     assert torch.isfinite(total).all(), "non-finite log-likelihood"
+    lp_main = lp.clone()
+    # the other arithmetic on the same batch: exact fp32 beside the split path (or vice versa), same run
+    other = "f32" if args.precision == "f16x3" else "f16x3"
+    eng.set_precision(_lib.PREC_F32 if other == "f32" else _lib.PREC_F16X3)
+    step()
+    elapsed_o, prof_o = timed(max(2, args.steps // 2))
+    steps_o = max(2, args.steps // 2)
+    lp_other = lp.clone()
+    eng.set_precision(_lib.PREC_F32 if args.precision == "f32" else _lib.PREC_F16X3)
+    rel_diff = float(((lp_main - lp_other).abs() / lp_other.abs()).max().item())
+    # accuracy of the headline arithmetic against the fp64 CPU oracle on two tiles of the same batch (rank 0)
+    acc_vs_oracle = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import glowref as R
+        xs = x[:2].cpu().numpy().astype(np.float64)
+        ref = R.log_prob(xs, R.cast_params(params, np.float64), cfg.as_dict())
+        acc_vs_oracle = float(np.max(np.abs(lp_main[:2].cpu().numpy() - ref) / np.abs(ref)))
 
     if rank == 0:
         passes = n * world * args.steps
         value = passes / elapsed
         h0, w0, c0 = cfg.level_shapes()[0]
-        ms0, launches0 = prof[0]
         flop_launch = net_flop_per_pixel(c0, cfg.F) * n * h0 * w0
-        avg_ms = ms0 / max(launches0, 1)
-        achieved = flop_launch / (avg_ms * 1e-3) / 1e12 if launches0 else None
+
+        def roofline_obj(precision, pr):
+            ms0, launches0 = pr[0]
+            avg_ms = ms0 / max(launches0, 1)
+            achieved = flop_launch / (avg_ms * 1e-3) / 1e12 if launches0 else None
+            if precision == "f32":
+                kernel, peak = "k_net_f32<CI=%d,NF=%d> (level 0)" % (c0 // 2, cfg.F // 32), PEAK_F32_MFMA_TFLOPS
+                note = "fp32-input MFMA peak"
+            else:
+                kernel, peak = "k_net_h3<CI=%d,NF=%d> (level 0)" % (c0 // 2, cfg.F // 32), PEAK_F16_MFMA_TFLOPS / 3.0
+                note = "fp16 dense MFMA peak / 3 (three fp16 MFMAs per fp32-equivalent product)"
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    key = "k_net_level0_hbm_bytes_per_launch_per_tile" if precision == "f32" else "k_net_h3_level0_hbm_bytes_per_launch_per_tile"
+                    t = json.load(open(tpath)).get(key)
+                    traffic = t * n if t is not None else None
+                except Exception:
+                    traffic = None
+            return {"kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "peak_note": note, "unit": "TFLOP/s",
+                    "frac": (achieved / peak) if achieved else None, "traffic": traffic, "avg_launch_ms": avg_ms,
+                    "launches": launches0, "flop_per_launch": flop_launch}
+
+        passes = n * world * args.steps
+        value = passes / elapsed
+        value_o = n * world * steps_o / elapsed_o
         net_ms_total = sum(m for m, _ in prof)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("k_net_level0_hbm_bytes_per_launch_per_tile")
-                traffic = traffic * n if traffic is not None else None
-            except Exception:
-                traffic = None
+        dtype_name = {"f32": "f32", "f16x3": "f16x3 (fp16 hi/lo split, 3 MFMAs per product, fp32 accumulate; fp32-class accuracy)"}
         out = {
             "metric": baseline_metric() if args.config == "B" else "Glow fwd+logdet passes/sec (config %s)" % args.config,
             "value": value, "unit": "passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f16x3->f32",
+            "vs_baseline": None, "dtype": dtype_name[args.precision],
             "data": "synthetic",
             "config": {"workload": "Glow log_prob, %dx%dx%d mel tiles, L=%d K=%d n_filters=%d, %d tiles/GPU/step"
                                    % (cfg.H, cfg.W, cfg.C, cfg.L, cfg.K, cfg.F, n),
                        "tiles_per_gpu": n, "sharding": "batch shards, 1 all-reduce(sum log-lik)/step"},
             "gflop_per_pass": cfg.flop_per_tile() / 1e9,
-            "whole_path_tflops": value / world * cfg.flop_per_tile() / 1e12,
-            "whole_path_frac_of_f32_mfma_peak": value / world * cfg.flop_per_tile() / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "whole_path_tflops_fp32_equivalent": value / world * cfg.flop_per_tile() / 1e12,
             "hbm_frac_activations": value / world * cfg.act_bytes_per_tile() / 1e9 / PEAK_HBM_GBS,
             "k_net_share_of_step_time": net_ms_total * 1e-3 / elapsed,
-            "roofline": {
-                "kernel": "k_net_f32<CI=%d,NF=%d> (level 0)" % (c0 // 2, cfg.F // 32),
-                "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": traffic,
-                "avg_launch_ms": avg_ms, "launches": launches0, "flop_per_launch": flop_launch,
-            },
+            "accuracy": {"max_rel_err_log_prob_vs_fp64_oracle_2_tiles": acc_vs_oracle,
+                         "max_rel_diff_log_prob_%s_vs_%s_%d_tiles" % (args.precision, other, n): rel_diff,
+                         "north_star_bar": 1e-4},
+            "roofline": roofline_obj(args.precision, prof),
+            ("exact_fp32" if other == "f32" else "split_fp16"): {
+                "value": value_o, "unit": "passes/s", "steps": steps_o, "ms_per_step": elapsed_o / steps_o * 1e3,
+                "dtype": dtype_name[other], "roofline": roofline_obj(other, prof_o)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, params, args.cpu_budget)
