@@ -48,8 +48,34 @@ def compute_grad_logprob(inputs, model):
     return g
 
 
-def basis_inner_loop(mixed, x1, x2, model1, model2, sigma_idx, sigmas, delta=2e-5, T=100, noise_fn=None, debug=False):
-    """run_basis_sep.py:152-214 (model_type == 'glow').  ``noise_fn(t, which, shape) -> standard normal tensor``."""
+def _grad_pair(x1, x2, model1, model2, streams):
+    """The two priors' gradients are independent: evaluate them concurrently on two HIP streams (at BASIS batch sizes the
+    deeper levels launch only tens of workgroups each, so the two kernel sequences interleave on the 256 CUs)."""
+    if streams is None or x1.device.type != "cuda":
+        return compute_grad_logprob(x1, model1), compute_grad_logprob(x2, model2)
+    cur = torch.cuda.current_stream()
+    s1, s2 = streams
+    s1.wait_stream(cur)
+    s2.wait_stream(cur)
+    with torch.cuda.stream(s1):
+        g1 = compute_grad_logprob(x1, model1)
+    with torch.cuda.stream(s2):
+        g2 = compute_grad_logprob(x2, model2)
+    cur.wait_stream(s1)
+    cur.wait_stream(s2)
+    g1.record_stream(cur)
+    g2.record_stream(cur)
+    return g1, g2
+
+
+def basis_inner_loop(mixed, x1, x2, model1, model2, sigma_idx, sigmas, delta=2e-5, T=100, noise_fn=None, debug=False,
+                     streams="auto"):
+    """run_basis_sep.py:152-214 (model_type == 'glow').  ``noise_fn(t, which, shape) -> standard normal tensor``.
+    ``streams``: "auto" (two side streams when on the GPU and the models are distinct engines), None, or (s1, s2)."""
+    if streams == "auto":
+        streams = None
+        if x1.device.type == "cuda" and getattr(model1, "engine", None) is not getattr(model2, "engine", None):
+            streams = (torch.cuda.Stream(device=x1.device), torch.cuda.Stream(device=x1.device))
     sigma = float(sigmas[sigma_idx])
     sigma_l = float(sigmas[-1])
     eta = float(np.float32(delta * (sigma / sigma_l) ** 2))
@@ -59,8 +85,7 @@ def basis_inner_loop(mixed, x1, x2, model1, model2, sigma_idx, sigmas, delta=2e-
     for t in range(T):
         eps1 = math.sqrt(2.0 * eta) * noise_fn(t, 0, x1.shape)
         eps2 = math.sqrt(2.0 * eta) * noise_fn(t, 1, x2.shape)
-        g1 = compute_grad_logprob(x1, model1)
-        g2 = compute_grad_logprob(x2, model2)
+        g1, g2 = _grad_pair(x1, x2, model1, model2, streams)
         mix = mixing_db(x1, x2)
         m1, m2 = grad_mixing_db(x1, x2)
         x1n = x1 + eta * (g1 + lambda_recon * m1 * (mixed - mix)) + eps1
