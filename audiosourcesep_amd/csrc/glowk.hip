@@ -38,6 +38,7 @@ struct StepDev {            // device pointers into the arena
   const float4* K3p = nullptr;
   const float4* R0p = nullptr;
   const float4* RHp = nullptr;   // f16x3 ring image (null: shape not supported by k_net_h3)
+  const float* epH = nullptr;    // its epilogue constants
   float sc1 = 1.f, sc2 = 1.f, sc3 = 1.f;
   const float* K3bp = nullptr;   // backward: conv3^T operands of the small-conv chain [NF][9c/2][64]
   const float4* RBp = nullptr;   // backward ring image: K2^T chunk fo | K3b operands of block fo+1 ; conv1^T chunks
@@ -147,7 +148,7 @@ inline int rho(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 inline size_t pad4(size_t n) { return (n + 3) & ~size_t(3); }
 
 struct StepLayout {
-  size_t K1p, ep, K2p, K3p, R0p, K3bp, RBp, RHp, Afwd, bfwd, Ainv, binv, b3, total;
+  size_t K1p, ep, K2p, K3p, R0p, K3bp, RBp, RHp, epH, Afwd, bfwd, Ainv, binv, b3, total;
   size_t slotH;        // floats per slot of the f16x3 ring image (0: does not fit)
   size_t slotB, k3fB;  // backward ring image: floats per slot; floats of its conv3^T-operand part (0: not in the ring)
   size_t slot0, k1f0;  // floats per slot of k_net_f32's ring image; floats of its conv1 part (0: not in the ring)
@@ -180,9 +181,11 @@ StepLayout step_layout(int c, int F) {
   {
     const int KS = (9 * CI + 15) / 16;
     const size_t slotH = ((size_t)(NF / 2) * 4 + (size_t)KS * 2) * 256;
-    const bool fitsH = 2 * slotH * 4 + (size_t)6 * F * 4 <= 160 * 1024 && NF % 4 == 0 && CI <= 8;   // RingH::FITS
+    const size_t ephn = pad4((size_t)F + 32 * NMT);                                               // RingH::EPN
+    const bool fitsH = 2 * slotH * 4 + ephn * 4 <= 160 * 1024 && NF % 4 == 0 && CI <= 8;              // RingH::FITS
     L.slotH = fitsH ? slotH : 0;
     L.RHp = o; o += fitsH ? (size_t)2 * (NF + NMT) * slotH : 0;
+    L.epH = o; o += fitsH ? ephn : 0;
   }
   L.Afwd = o; o += pad4((size_t)c * c);
   L.bfwd = o; o += pad4(c);
@@ -312,9 +315,52 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
       if (m > 0.0f) { std::frexp(m, &e); }          // m = f * 2^e, f in [0.5, 1)
       return 14 - e;                                // |w| * 2^S < 2^14: hi well inside fp16, lo ~2^3 (normal)
     };
-    const int S1 = pow2_scale(K1, (size_t)9 * CI * F), S2 = pow2_scale(K2, (size_t)F * F), S3 = pow2_scale(K3, (size_t)9 * F * CO);
+    // Every per-channel constant of the epilogues is folded into the weights (host, fp64):
+    //  * BatchNorm y = g*r + d with g = m * 2^e (|m| in [0.5,1)): the power of two scales the channel's own producer
+    //    (a row scale: exact), the mantissa m multiplies the consumer's weight column, and W.d joins the consumer's bias
+    //    (conv2: its bias; conv3: one constant per (tap, channel) row of P -- each row of P is a 1x1 of the pixel's own h2,
+    //    so there are no border terms);
+    //  * conv1's bias rides in a padding row of its 16-wide k-steps (the B fragment holds a constant 1 there);
+    //  * conv2's bias is the initial value of its accumulators.
+    // What is left in the kernel is  B = split(max(acc * 2^-S, 0))  with one uniform power of two per layer.
+    std::vector<float> K1f((size_t)(9 * CI + 1) * F), K2f((size_t)F * F), K3f((size_t)9 * F * CO);
+    std::vector<double> b2f(F), pbf((size_t)9 * CO, 0.0);
+    std::vector<int> e1(F), e2(F);
+    {
+      const float* ep = dst + L.ep;     // [b1 | g1 | d1 | b2 | g2 | d2] as packed above
+      std::vector<double> m1(F), m2(F);
+      for (int f = 0; f < F; ++f) {
+        int e;
+        m1[f] = std::frexp((double)ep[F + f], &e);      e1[f] = ep[F + f] != 0.0f ? e : 0;
+        m2[f] = std::frexp((double)ep[4 * F + f], &e);  e2[f] = ep[4 * F + f] != 0.0f ? e : 0;
+      }
+      for (int kk = 0; kk <= 9 * CI; ++kk)
+        for (int f = 0; f < F; ++f)
+          K1f[(size_t)kk * F + f] = std::ldexp(kk < 9 * CI ? K1[(size_t)kk * F + f] : ep[f], e1[f]);
+      for (int fo = 0; fo < F; ++fo) b2f[fo] = (double)ep[3 * F + fo];
+      for (int fi = 0; fi < F; ++fi)
+        for (int fo = 0; fo < F; ++fo) {
+          const double w = (double)K2[(size_t)fi * F + fo];
+          K2f[(size_t)fi * F + fo] = (float)std::ldexp(w * m1[fi], e2[fo]);
+          b2f[fo] += w * (double)ep[2 * F + fi];
+        }
+      for (int tap = 0; tap < 9; ++tap)
+        for (int f = 0; f < F; ++f)
+          for (int co = 0; co < CO; ++co) {
+            const double w = (double)K3[((size_t)tap * F + f) * CO + co];
+            K3f[((size_t)tap * F + f) * CO + co] = (float)(w * m2[f]);
+            pbf[(size_t)tap * CO + co] += w * (double)ep[5 * F + f];
+          }
+    }
+    const int S1 = pow2_scale(K1f.data(), K1f.size()), S2 = pow2_scale(K2f.data(), K2f.size()), S3 = pow2_scale(K3f.data(), K3f.size());
     const float act = 32.0f;                        // GLOWK_ACT_SCALE
-    scales3[0] = std::ldexp(1.0f, -S1) / act; scales3[1] = std::ldexp(1.0f, -S2) / act; scales3[2] = std::ldexp(1.0f, -S3) / act;
+    scales3[0] = std::ldexp(1.0f, -S1); scales3[1] = std::ldexp(1.0f, -S2); scales3[2] = std::ldexp(1.0f, -S3) / act;
+    {
+      float* eh = dst + L.epH;          // [conv2 accumulator init (F) | pb (32 * NMT)]
+      for (int f = 0; f < F; ++f) eh[f] = (float)std::ldexp((double)act * b2f[f], e2[f] + S2);
+      for (int m = 0; m < 32 * NMT; ++m) eh[F + m] = m < 9 * CO ? (float)pbf[m] : 0.0f;
+    }
+    const bool fused = NMT <= 3;        // RingH::FUSED: conv3 A tiles ordered (hidden block, row tile) instead of (row tile, hidden block)
     auto put = [](float* row_lane, int j, int hl, float w, int S) {
       // row = 64 lanes x 8 halves; hi and lo live in consecutive rows; row_lane points at this lane's 8 halves of the hi row
       const float ws = std::ldexp(w, S);
@@ -336,11 +382,13 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
                 const int kloc = 16 * s2 + 8 * (j >> 2) + 4 * hh + (j & 3);      // accumulator-derived k order
                 float w;
                 int S;
-                if (step < NF) { w = K2[(size_t)(step * 32 + kloc) * F + fo * 32 + i]; S = S2; }
+                if (step < NF) { w = K2f[(size_t)(step * 32 + kloc) * F + fo * 32 + i]; S = S2; }
                 else {
-                  const int m = (step - NF) * 32 + i, f = fo * 32 + kloc;
+                  const int t = (step - NF) * NFH + fol;                           // tile index within this pass's conv3 part
+                  const int mt = fused ? t % NMT : step - NF, fo3 = ps * NFH + (fused ? t / NMT : fol);
+                  const int m = mt * 32 + i, f = fo3 * 32 + kloc;
                   w = 0.0f; S = S3;
-                  if (m < 9 * CO) { const int tap = m / CO, co = m % CO; w = K3[((size_t)tap * F + f) * CO + co]; }
+                  if (m < 9 * CO) { const int tap = m / CO, co = m % CO; w = K3f[((size_t)tap * F + f) * CO + co]; }
                 }
                 float* row_lane = slot + ((size_t)((fol * 2 + s2) * 2) * 64 + l) * 4;   // hi row of (fo, s2); 16 B per lane = 4 floats
                 put(row_lane, j, 0, w, S);
@@ -351,7 +399,7 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
           for (int l = 0; l < 64; ++l)
             for (int j = 0; j < 8; ++j) {
               const int i = l & 31, hh = l >> 5, kk = 16 * s2 + 8 * hh + j;
-              const float w = kk < 9 * CI ? K1[(size_t)kk * F + blk * 32 + i] : 0.0f;
+              const float w = kk <= 9 * CI ? K1f[(size_t)kk * F + blk * 32 + i] : 0.0f;     // row 9 CI: the bias
               float* row_lane = slot + ((size_t)NFH * 4 * 64 + (size_t)(s2 * 2) * 64 + l) * 4;
               put(row_lane, j, 0, w, S1);
               put(row_lane, j, 1, w, S1);
@@ -412,7 +460,40 @@ int launch_net_t(const NetArgs& a, int mode, hipStream_t s) {
     case NET_BWD:      hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD>), dim3(ntiles), dim3(256), 0, s, a); break;
     case 3:
       if constexpr (RingH<CI, NF>::FITS) {
-        if (a.RHp) { hipLaunchKernelGGL((k_net_h3<CI, NF>), dim3((a.Q + 255) / 256), dim3(512), 0, s, a); break; }
+        if (a.RHp) {
+          static int abl = -1;
+          if (abl < 0) { const char* e = getenv("GLOWK_ABL"); abl = e ? atoi(e) : 0; }
+          if constexpr (CI == 2 && NF == 16) {   // timing-only ablations (wrong results by design)
+            const dim3 g((a.Q + 255) / 256), b(512);
+            if (abl == 1) { hipLaunchKernelGGL((k_net_h3<CI, NF, 1>), g, b, 0, s, a); break; }
+            if (abl == 2) { hipLaunchKernelGGL((k_net_h3<CI, NF, 2>), g, b, 0, s, a); break; }
+            if (abl == 3) { hipLaunchKernelGGL((k_net_h3<CI, NF, 3>), g, b, 0, s, a); break; }
+            if (abl == 6) { hipLaunchKernelGGL((k_net_h3<CI, NF, 6>), g, b, 0, s, a); break; }
+            if (abl == 7) { hipLaunchKernelGGL((k_net_h3<CI, NF, 7>), g, b, 0, s, a); break; }
+            if (abl == 16) { hipLaunchKernelGGL((k_net_h3<CI, NF, 16>), g, b, 0, s, a); break; }
+            if (abl == 8) {
+              static unsigned long long* dbg = nullptr; static int calls = 0;
+              const size_t n = (size_t)g.x * 8 * 16;
+              if (!dbg) hipMalloc(&dbg, (size_t)8192 * 128 * 8);
+              NetArgs a2 = a; a2.dbg = dbg;
+              hipLaunchKernelGGL((k_net_h3<CI, NF, 8>), g, b, 0, s, a2);
+              if (++calls % 32 == 0 && calls > 64) {
+                hipStreamSynchronize(s);
+                std::vector<unsigned long long> hbuf(n);
+                hipMemcpy(hbuf.data(), dbg, n * 8, hipMemcpyDeviceToHost);
+                double sum[10] = {0};
+                for (size_t w = 0; w < n / 16; ++w) for (int i = 0; i < 10; ++i) sum[i] += (double)hbuf[w * 16 + i];
+                const double nw = (double)(n / 16);
+                fprintf(stderr, "[stamp] waves %zu  cycles %.0f  realtime %.0f (100MHz)  clock %.3f GHz | per step (32 steps): conv1+epi %.0f  wait+barrier %.0f  dma issue %.0f  conv2 %.0f  | sum %.0f | tails (total of 2 passes): bn2 %.0f  wait %.0f  conv3 %.0f  stores %.0f\n",
+                        n / 16, sum[0] / nw, sum[1] / nw, sum[0] / sum[1] * 0.1, sum[2] / nw / 32, sum[3] / nw / 32, sum[4] / nw / 32, sum[5] / nw / 32,
+                        (sum[2] + sum[3] + sum[4] + sum[5]) / nw, sum[6] / nw, sum[7] / nw, sum[8] / nw, sum[9] / nw);
+              }
+              break;
+            }
+          }
+          hipLaunchKernelGGL((k_net_h3<CI, NF>), dim3((a.Q + 255) / 256), dim3(512), 0, s, a);
+          break;
+        }
       }
       hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a);   // shape without an f16x3 instance
       break;
@@ -498,7 +579,7 @@ NetArgs net_args(glowk_handle* h, const Level& lv, const StepDev& sd, const floa
   a.vin = vin; a.in_stride = in_stride; a.in_off = in_off;
   a.Q = N * lv.h * lv.w; a.h = lv.h; a.w = lv.w;
   a.K1p = sd.K1p; a.ep = sd.ep; a.K2p = sd.K2p; a.K3p = sd.K3p; a.R0p = sd.R0p; a.mask1 = nullptr; a.mask2 = nullptr; a.P = h->bufP;
-  a.RHp = sd.RHp; a.P2 = h->bufP2; a.sc1 = sd.sc1; a.sc2 = sd.sc2; a.sc3 = sd.sc3;
+  a.dbg = nullptr; a.RHp = sd.RHp; a.eph = sd.epH; a.P2 = h->bufP2; a.sc1 = sd.sc1; a.sc2 = sd.sc2; a.sc3 = sd.sc3;
   return a;
 }
 
@@ -840,6 +921,7 @@ int glowk_finalize_weights(glowk_handle* h) {
       d.K3p = reinterpret_cast<const float4*>(base + SL.K3p);
       d.R0p = reinterpret_cast<const float4*>(base + SL.R0p);
       d.RHp = SL.slotH ? reinterpret_cast<const float4*>(base + SL.RHp) : nullptr;
+      d.epH = SL.slotH ? base + SL.epH : nullptr;
       d.K3bp = base + SL.K3bp;
       d.RBp = reinterpret_cast<const float4*>(base + SL.RBp);
       d.Afwd = base + SL.Afwd; d.bfwd = base + SL.bfwd; d.Ainv = base + SL.Ainv; d.binv = base + SL.binv; d.b3 = base + SL.b3;

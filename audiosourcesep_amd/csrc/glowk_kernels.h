@@ -47,6 +47,8 @@ struct NetArgs {
   float* P;              // [9*CO][Q]
   float* P2;             // f16x3: partial sums of the second pass
   const float4* RHp;     // f16x3 ring image (RingH), or null
+  const float* eph;      // its epilogue constants [c1 | bs1 | c2 | bs2 | pb], see RingH
+  unsigned long long* dbg;
   float sc1, sc2, sc3;   // f16x3: 2^-(weight scale + activation scale) of conv1 / conv2 / conv3
 };
 
@@ -337,8 +339,12 @@ struct RingH {
   static constexpr int PIECES = NFH * 4 + K1PIECES;
   static constexpr int NMT = (18 * CI + 31) / 32;
   static constexpr int STEPS_PASS = NF + NMT;
-  static constexpr size_t LDS_BYTES = (size_t)2 * SLOT4 * 16 + (size_t)6 * NF * 32 * 4;
-  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && CI <= 8;
+  static constexpr int EPN = (NF * 32 + 32 * NMT + 3) & ~3;       // conv2 accumulator init (F) | per-row constants of P (32 NMT)
+  static constexpr size_t LDS_BYTES = (size_t)2 * SLOT4 * 16 + (size_t)EPN * 4;
+  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && CI <= 8 && K1 < KS * 16;   // a spare k row carries conv1's bias
+  // conv3 A tiles of a pass in (hidden block, row tile) order: each hidden block is split once and feeds all NMT row
+  // tiles (NMT accumulators live); for wide conv3 outputs the accumulators would not fit next to acc2: row-tile-major there
+  static constexpr bool FUSED = NMT <= 3;
 };
 
 // pieces [P0, P0 + N) of a ring slot image dealt round-robin to NW waves
@@ -368,6 +374,7 @@ __device__ __forceinline__ f32x16 mfma3(const h8& ahi, const h8& alo, const h8& 
   return acc;
 }
 
+#define GLOWK_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define GLOWK_WAIT_BARRIER()                          \
   do {                                                \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  \
@@ -378,48 +385,61 @@ __device__ __forceinline__ f32x16 mfma3(const h8& ahi, const h8& alo, const h8& 
 // published with the previous chunk, slot P^1).  Measured alternative, rejected: running conv1(next) and conv2(cur) in
 // opposite orders in the two halves of the workgroup (to de-phase the two waves of a SIMD) doubled the code of the step
 // and brought back ~470 spilled registers reloaded behind the DMA: 2.6x slower.
-template <int CI, int NF, int P>
+template <int CI, int NF, int P, int ABL>
 __device__ __forceinline__ void h3_step(const NetArgs& a, int fi, const float4* nsrc, float4* s0, float4* s1, const float* epl,
                                         const h8 (&xh)[(RingH<CI, NF>::KS)], const h8 (&xl)[(RingH<CI, NF>::KS)],
-                                        f32x16 (&acc2)[(RingH<CI, NF>::NFH)], int wave, unsigned voff, int lane, int hh) {
+                                        f32x16 (&acc2)[(RingH<CI, NF>::NFH)], int wave, unsigned voff, int lane, int hh, unsigned long long (&dt)[8]) {
   using G = RingH<CI, NF>;
   constexpr int F = NF * 32;
+  unsigned long long t0, t1, t2, t3, t4;
+  if (ABL & 8) GLOWK_STAMP(t0);
   f32x16 h1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) h1[r] = 0.0f;
   {
     const h8* k1 = reinterpret_cast<const h8*>(ring_slot<P ^ 1>(s0, s1) + G::MAIN4) + lane;   // [s][hi|lo][64]
+    if (!(ABL & 1)) {
 #pragma unroll
-    for (int s = 0; s < G::KS; ++s) h1 = mfma3(k1[(2 * s + 0) * 64], k1[(2 * s + 1) * 64], xh[s], xl[s], h1);
+      for (int s = 0; s < G::KS; ++s) h1 = mfma3(k1[(2 * s + 0) * 64], k1[(2 * s + 1) * 64], xh[s], xl[s], h1);
+    }
   }
   // bias + ReLU + BN1, then scale and split into the B fragments of conv2's two k-steps
   h8 bh[2], bl[2];
+  if (ABL & 1) { bh[0] = xh[0]; bh[1] = xh[0]; bl[0] = xl[0]; bl[1] = xl[0]; }
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < ((ABL & 1) ? 0 : 2); ++s) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int r = 8 * s + j;
-      const int f = fi * 32 + mfma_row(r, hh);
-      v[j] = fmaf(epl[F + f], fmaxf(fmaf(h1[r], a.sc1, epl[f]), 0.0f), epl[2 * F + f]) * GLOWK_ACT_SCALE;
+      v[j] = fmaxf(h1[r] * a.sc1, 0.0f);
     }
     split8(v, bh[s], bl[s]);
   }
-  GLOWK_WAIT_BARRIER();   // this step's chunk landed in every wave's view; slot P^1 is no longer read
-  stage_range_w<0, G::PIECES, 8>(nsrc, ring_slot<P ^ 1>(s0, s1), wave, voff);
+  if (ABL & 8) GLOWK_STAMP(t1);
+  if (!(ABL & 4)) GLOWK_WAIT_BARRIER();   // this step's chunk landed in every wave's view; slot P^1 is no longer read
+  if (ABL & 8) GLOWK_STAMP(t2);
+  if (!(ABL & 2)) stage_range_w<0, G::PIECES, 8>(nsrc, ring_slot<P ^ 1>(s0, s1), wave, voff);
+  if (ABL & 8) GLOWK_STAMP(t3);
   const h8* buf = reinterpret_cast<const h8*>(ring_slot<P>(s0, s1)) + lane;
 #pragma unroll
   for (int fo = 0; fo < G::NFH; ++fo) {
     acc2[fo] = mfma3(buf[(fo * 4 + 0) * 64], buf[(fo * 4 + 1) * 64], bh[0], bl[0], acc2[fo]);
     acc2[fo] = mfma3(buf[(fo * 4 + 2) * 64], buf[(fo * 4 + 3) * 64], bh[1], bl[1], acc2[fo]);
   }
+  if (ABL & 8) {
+#pragma unroll
+    for (int fo = 0; fo < G::NFH; ++fo) asm volatile("" : "+a"(acc2[fo]));
+    GLOWK_STAMP(t4);
+    dt[0] += t1 - t0; dt[1] += t2 - t1; dt[2] += t3 - t2; dt[3] += t4 - t3;
+  }
 }
 
 // one pass (F_out half PASS) of the workgroup's 256 pixels; the pass's first chunk sits in slot P0
-template <int CI, int NF, int P0, int PASS>
+template <int CI, int NF, int P0, int PASS, int ABL>
 __device__ __forceinline__ void h3_pass(const NetArgs& a, const float4* ring, float4* s0, float4* s1, const float* epl,
                                         const h8 (&xh)[(RingH<CI, NF>::KS)], const h8 (&xl)[(RingH<CI, NF>::KS)], int q, bool qok, int wave,
-                                        unsigned voff, int lane, int hh) {
+                                        unsigned voff, int lane, int hh, unsigned long long (&dt)[8]) {
   using G = RingH<CI, NF>;
   constexpr int F = NF * 32;
   constexpr int SLOT4 = G::SLOT4;
@@ -431,62 +451,73 @@ __device__ __forceinline__ void h3_pass(const NetArgs& a, const float4* ring, fl
 #pragma unroll
   for (int fo = 0; fo < G::NFH; ++fo)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[fo][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc2[fo][r] = epl[f2base + fo * 32 + mfma_row(r, hh)];   // conv2 bias (scaled)
 
 #pragma nounroll
   for (int fi = 0; fi < NF; fi += 2) {
-    h3_step<CI, NF, P0>(a, fi, chunk + (size_t)(fi + 1) * SLOT4, s0, s1, epl, xh, xl, acc2, wave, voff, lane, hh);
-    h3_step<CI, NF, P0 ^ 1>(a, fi + 1, chunk + (size_t)(fi + 2) * SLOT4, s0, s1, epl, xh, xl, acc2, wave, voff, lane, hh);
+    h3_step<CI, NF, P0, ABL>(a, fi, chunk + (size_t)(fi + 1) * SLOT4, s0, s1, epl, xh, xl, acc2, wave, voff, lane, hh, dt);
+    h3_step<CI, NF, P0 ^ 1, ABL>(a, fi + 1, chunk + (size_t)(fi + 2) * SLOT4, s0, s1, epl, xh, xl, acc2, wave, voff, lane, hh, dt);
   }
 
-  // bias + ReLU + BN2 of this pass's hidden channels, pre-scaled for the conv3 split
-#pragma unroll
-  for (int fo = 0; fo < G::NFH; ++fo)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int f = f2base + fo * 32 + mfma_row(r, hh);
-      acc2[fo][r] = fmaf(epl[4 * F + f], fmaxf(fmaf(acc2[fo][r], a.sc2, epl[3 * F + f]), 0.0f), epl[5 * F + f]) * GLOWK_ACT_SCALE;
-    }
-
+  unsigned long long u0, u1, u2, u3, u4;
+  if (ABL & 8) GLOWK_STAMP(u0);
   float* Pp = PASS == 0 ? a.P : a.P2;
+  // bias + ReLU of hidden block fo (BN2 is folded into K3), as the two split B fragments of its k-steps
+  auto frag2 = [&](int fo, h8 (&bh)[2], h8 (&bl)[2]) {
 #pragma unroll
-  for (int mt = 0; mt < NMT; ++mt) {
+    for (int s = 0; s < 2; ++s) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc2[fo][8 * s + j] * a.sc2, 0.0f);
+      split8(v, bh[s], bl[s]);
+    }
+  };
+  f32x16 acc3[NMT];
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc3[mt][r] = 0.0f;
+  h8 bh[2], bl[2];
+#pragma unroll
+  for (int st = 0; st < NMT; ++st) {
+    if (ABL & 8) GLOWK_STAMP(u1);
     GLOWK_WAIT_BARRIER();
-    constexpr bool dummy = false; (void)dummy;
-    const bool last_of_all = (PASS == 1) && (mt == NMT - 1);
-    const float4* nsrc = chunk + (size_t)(NF + mt + 1) * SLOT4;     // next conv3 chunk, or the next pass's first chunk
+    if (ABL & 8) GLOWK_STAMP(u2);
+    const bool last_of_all = (PASS == 1) && (st == NMT - 1);
+    const float4* nsrc = chunk + (size_t)(NF + st + 1) * SLOT4;     // next conv3 chunk, or the next pass's first chunk
     const h8* buf;
-    if ((mt & 1) == 0) {
+    if ((st & 1) == 0) {
       if (!last_of_all) stage_range_w<0, G::PIECES, 8>(nsrc, ring_slot<P0 ^ 1>(s0, s1), wave, voff);
       buf = reinterpret_cast<const h8*>(ring_slot<P0>(s0, s1)) + lane;
     } else {
       if (!last_of_all) stage_range_w<0, G::PIECES, 8>(nsrc, ring_slot<P0>(s0, s1), wave, voff);
       buf = reinterpret_cast<const h8*>(ring_slot<P0 ^ 1>(s0, s1)) + lane;
     }
-    f32x16 acc3;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc3[r] = 0.0f;
-#pragma unroll
-    for (int fo = 0; fo < G::NFH; ++fo) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = acc2[fo][8 * s + j];
-        h8 bh, bl;
-        split8(v, bh, bl);
-        acc3 = mfma3(buf[(fo * 4 + 2 * s + 0) * 64], buf[(fo * 4 + 2 * s + 1) * 64], bh, bl, acc3);
-      }
+    for (int i = 0; i < G::NFH; ++i) {
+      const int t = st * G::NFH + i;
+      const int fo = G::FUSED ? t / NMT : i;
+      const int mt = G::FUSED ? t % NMT : st;
+      if (!G::FUSED || mt == 0) frag2(fo, bh, bl);
+      acc3[mt] = mfma3(buf[(i * 4 + 0) * 64], buf[(i * 4 + 1) * 64], bh[0], bl[0], acc3[mt]);
+      acc3[mt] = mfma3(buf[(i * 4 + 2) * 64], buf[(i * 4 + 3) * 64], bh[1], bl[1], acc3[mt]);
     }
+    if (ABL & 8) { GLOWK_STAMP(u3); dt[5] += u2 - u1; dt[6] += u3 - u2; }
+  }
+  if (ABL & 8) GLOWK_STAMP(u3);
+  const float* pb = epl + F;
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = mt * 32 + mfma_row(r, hh);
-      if (m < M3 && qok) Pp[(size_t)m * a.Q + q] = acc3[r] * a.sc3;
+      const size_t pidx = (ABL & 16) ? (size_t)(q >> 5) * (M3 * 32) + m * 32 + (q & 31) : (size_t)m * a.Q + q;
+      if (m < M3 && qok) Pp[pidx] = PASS == 0 ? fmaf(acc3[mt][r], a.sc3, pb[m]) : acc3[mt][r] * a.sc3;
     }
-  }
+  if (ABL & 8) { GLOWK_STAMP(u4); dt[7] += u4 - u3; dt[4] += 0 * (u0 - u0); }
 }
 
-template <int CI, int NF>
+template <int CI, int NF, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
   using G = RingH<CI, NF>;
   constexpr int K1 = G::K1;
@@ -497,7 +528,7 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
 
   __shared__ float4 slot0[SLOT4];
   __shared__ float4 slot1[SLOT4];
-  __shared__ float epl[6 * F];
+  __shared__ float epl[G::EPN];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -529,19 +560,28 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
         const bool ok = qok && k < K1 && ii >= 0 && ii < a.h && jj >= 0 && jj < a.w;
         const int off = ok ? ((dy * a.w + dx) * a.in_stride + cin) : 0;
         const float x = base[off];
-        v[j] = ok ? x * GLOWK_ACT_SCALE : 0.0f;
+        v[j] = ok ? x * GLOWK_ACT_SCALE : (k == K1 ? GLOWK_ACT_SCALE : 0.0f);   // row K1: the constant that carries conv1's bias
       }
       split8(v, xh[s], xl[s]);
     }
   }
-  for (int i = tid; i < 6 * F; i += 512) epl[i] = a.ep[i];
+  for (int i = tid; i < G::EPN; i += 512) epl[i] = a.eph[i];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // gathers done before any DMA is issued
   stage_range_w<0, G::PIECES, 8>(ring, slot0, wave, voff);                                                          // chunk 0 -> slot 0
   stage_range_w<G::NFH * 4, G::K1PIECES, 8>(ring + (size_t)(G::STEPS_PASS - 1) * SLOT4, slot1, wave, voff);        // conv1 operands of block 0
   GLOWK_WAIT_BARRIER();   // ep, chunk 0 and block-0 conv1 operands visible to every wave
 
-  h3_pass<CI, NF, 0, 0>(a, ring, slot0, slot1, epl, xh, xl, q, qok, wave, voff, lane, hh);
-  h3_pass<CI, NF, (G::STEPS_PASS & 1), 1>(a, ring, slot0, slot1, epl, xh, xl, q, qok, wave, voff, lane, hh);
+  unsigned long long dt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c0 = 0, r0 = 0, c1, r1;
+  if (ABL & 8) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
+  h3_pass<CI, NF, 0, 0, ABL>(a, ring, slot0, slot1, epl, xh, xl, q, qok, wave, voff, lane, hh, dt);
+  h3_pass<CI, NF, (G::STEPS_PASS & 1), 1, ABL>(a, ring, slot0, slot1, epl, xh, xl, q, qok, wave, voff, lane, hh, dt);
+  if (ABL & 8) {
+    c1 = __builtin_amdgcn_s_memtime(); r1 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F);
+    if (lane == 0 && a.dbg) {
+      unsigned long long* d = a.dbg + (size_t)(blockIdx.x * 8 + wave) * 16;
+      d[0] = c1 - c0; d[1] = r1 - r0; d[2] = dt[0]; d[3] = dt[1]; d[4] = dt[2]; d[5] = dt[3]; d[6] = dt[4]; d[7] = dt[5]; d[8] = dt[6]; d[9] = dt[7];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
