@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libglowk.so")
+LIB_PATH = os.environ.get("GLOWK_LIB") or os.path.join(_HERE, "libglowk.so")   # GLOWK_LIB: A/B timing of two builds (scripts/ab.py)
 
 
 class GlowkLibraryMissing(RuntimeError):

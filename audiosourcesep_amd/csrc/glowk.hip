@@ -149,7 +149,7 @@ inline size_t pad4(size_t n) { return (n + 3) & ~size_t(3); }
 
 struct StepLayout {
   size_t K1p, ep, K2p, K3p, R0p, K3bp, RBp, RHp, epH, Afwd, bfwd, Ainv, binv, b3, total;
-  size_t slotH;        // floats per slot of the f16x3 ring image (0: does not fit)
+  size_t slotH;        // floats per main chunk of the f16x3 image (0: shape not supported by k_net_h3)
   size_t slotB, k3fB;  // backward ring image: floats per slot; floats of its conv3^T-operand part (0: not in the ring)
   size_t slot0, k1f0;  // floats per slot of k_net_f32's ring image; floats of its conv1 part (0: not in the ring)
 };
@@ -179,12 +179,12 @@ StepLayout step_layout(int c, int F) {
     L.RBp = o; o += (size_t)(NF + NM1) * L.slotB;
   }
   {
-    const int KS = (9 * CI + 15) / 16;
-    const size_t slotH = ((size_t)(NF / 2) * 4 + (size_t)KS * 2) * 256;
-    const size_t ephn = pad4((size_t)F + 32 * NMT);                                               // RingH::EPN
-    const bool fitsH = 2 * slotH * 4 + ephn * 4 <= 160 * 1024 && NF % 4 == 0 && CI <= 8;              // RingH::FITS
-    L.slotH = fitsH ? slotH : 0;
-    L.RHp = o; o += fitsH ? (size_t)2 * (NF + NMT) * slotH : 0;
+    const int KS = (9 * CI + 15) / 16, NFH = NF / 2;
+    const size_t ephn = pad4((size_t)F + 32 * NMT);                                                   // RingH::EPN
+    const size_t lds = (size_t)3 * NFH * 4096 + (size_t)2 * KS * 2048 + ephn * 4;                     // RingH::LDS_BYTES
+    const bool fitsH = lds <= 160 * 1024 && NF % 4 == 0 && CI >= 2 && CI <= 8 && 9 * CI < KS * 16 && NMT <= 6;   // RingH::FITS
+    L.slotH = fitsH ? (size_t)NFH * 1024 : 0;
+    L.RHp = o; o += fitsH ? (size_t)NF * KS * 512 + (size_t)2 * (NF + NMT) * NFH * 1024 : 0;
     L.epH = o; o += fitsH ? ephn : 0;
   }
   L.Afwd = o; o += pad4((size_t)c * c);
@@ -360,7 +360,6 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
       for (int f = 0; f < F; ++f) eh[f] = (float)std::ldexp((double)act * b2f[f], e2[f] + S2);
       for (int m = 0; m < 32 * NMT; ++m) eh[F + m] = m < 9 * CO ? (float)pbf[m] : 0.0f;
     }
-    const bool fused = NMT <= 3;        // RingH::FUSED: conv3 A tiles ordered (hidden block, row tile) instead of (row tile, hidden block)
     auto put = [](float* row_lane, int j, int hl, float w, int S) {
       // row = 64 lanes x 8 halves; hi and lo live in consecutive rows; row_lane points at this lane's 8 halves of the hi row
       const float ws = std::ldexp(w, S);
@@ -369,41 +368,45 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
       _Float16* dsth = reinterpret_cast<_Float16*>(row_lane) + (size_t)hl * 64 * 8;
       dsth[j] = hl ? lo : hi;
     };
-    const int NFH = NF / 2;
-    size_t cidx = 0;
+    // image (RingH): conv1 operands of every hidden block [NF][KS][hi|lo][64 lanes] half8 (natural k order, row 9 CI = bias),
+    // then per pass: K2 chunks 0..NF-1 and conv3 chunks 0..NMT-1, a chunk = NFH tiles x [2 k-steps][hi|lo][64 lanes] half8
+    const int NFH = NF / 2, G0N = NMT < 3 ? NMT : 3, G1N = NMT - G0N > 0 ? NMT - G0N : 1;
+    const size_t k1blk = (size_t)KS * 2 * 256, chunkf = (size_t)NFH * 1024;
+    float* img = dst + L.RHp;
+    for (int blk = 0; blk < NF; ++blk)
+      for (int s2 = 0; s2 < KS; ++s2)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < 8; ++j) {
+            const int i = l & 31, hh = l >> 5, kk = 16 * s2 + 8 * hh + j;
+            const float w = kk <= 9 * CI ? K1f[(size_t)kk * F + blk * 32 + i] : 0.0f;
+            float* row_lane = img + (size_t)blk * k1blk + ((size_t)(s2 * 2) * 64 + l) * 4;
+            put(row_lane, j, 0, w, S1);
+            put(row_lane, j, 1, w, S1);
+          }
     for (int ps = 0; ps < 2; ++ps)
-      for (int step = 0; step < NF + NMT; ++step, ++cidx) {
-        float* slot = dst + L.RHp + cidx * L.slotH;
-        for (int fol = 0; fol < NFH; ++fol)
+      for (int ch = 0; ch < NF + NMT; ++ch) {
+        float* chunk = img + (size_t)NF * k1blk + ((size_t)ps * (NF + NMT) + ch) * chunkf;
+        for (int tp = 0; tp < NFH; ++tp)
           for (int s2 = 0; s2 < 2; ++s2)
             for (int l = 0; l < 64; ++l)
               for (int j = 0; j < 8; ++j) {
-                const int i = l & 31, hh = l >> 5, fo = ps * NFH + fol;
+                const int i = l & 31, hh = l >> 5;
                 const int kloc = 16 * s2 + 8 * (j >> 2) + 4 * hh + (j & 3);      // accumulator-derived k order
-                float w;
+                float w = 0.0f;
                 int S;
-                if (step < NF) { w = K2f[(size_t)(step * 32 + kloc) * F + fo * 32 + i]; S = S2; }
+                if (ch < NF) { w = K2f[(size_t)(ch * 32 + kloc) * F + (ps * NFH + tp) * 32 + i]; S = S2; }
                 else {
-                  const int t = (step - NF) * NFH + fol;                           // tile index within this pass's conv3 part
-                  const int mt = fused ? t % NMT : step - NF, fo3 = ps * NFH + (fused ? t / NMT : fol);
-                  const int m = mt * 32 + i, f = fo3 * 32 + kloc;
-                  w = 0.0f; S = S3;
+                  const int t = (ch - NF) * NFH + tp;                            // RingH::tile_fo / tile_mt
+                  const int fo = t < NFH * G0N ? t / G0N : (t - NFH * G0N) / G1N;
+                  const int mt = t < NFH * G0N ? t % G0N : G0N + (t - NFH * G0N) % G1N;
+                  const int m = mt * 32 + i, f = (ps * NFH + fo) * 32 + kloc;
+                  S = S3;
                   if (m < 9 * CO) { const int tap = m / CO, co = m % CO; w = K3f[((size_t)tap * F + f) * CO + co]; }
                 }
-                float* row_lane = slot + ((size_t)((fol * 2 + s2) * 2) * 64 + l) * 4;   // hi row of (fo, s2); 16 B per lane = 4 floats
+                float* row_lane = chunk + ((size_t)((tp * 2 + s2) * 2) * 64 + l) * 4;   // hi row of (tile, k-step); 16 B per lane
                 put(row_lane, j, 0, w, S);
                 put(row_lane, j, 1, w, S);
               }
-        const int blk = step < NF ? (step + 1) % NF : 0;   // conv1 operands riding with this chunk, natural k order
-        for (int s2 = 0; s2 < KS; ++s2)
-          for (int l = 0; l < 64; ++l)
-            for (int j = 0; j < 8; ++j) {
-              const int i = l & 31, hh = l >> 5, kk = 16 * s2 + 8 * hh + j;
-              const float w = kk <= 9 * CI ? K1f[(size_t)kk * F + blk * 32 + i] : 0.0f;     // row 9 CI: the bias
-              float* row_lane = slot + ((size_t)NFH * 4 * 64 + (size_t)(s2 * 2) * 64 + l) * 4;
-              put(row_lane, j, 0, w, S1);
-              put(row_lane, j, 1, w, S1);
-            }
       }
   }
 
@@ -461,36 +464,30 @@ int launch_net_t(const NetArgs& a, int mode, hipStream_t s) {
     case 3:
       if constexpr (RingH<CI, NF>::FITS) {
         if (a.RHp) {
-          static int abl = -1;
-          if (abl < 0) { const char* e = getenv("GLOWK_ABL"); abl = e ? atoi(e) : 0; }
-          if constexpr (CI == 2 && NF == 16) {   // timing-only ablations (wrong results by design)
-            const dim3 g((a.Q + 255) / 256), b(512);
-            if (abl == 1) { hipLaunchKernelGGL((k_net_h3<CI, NF, 1>), g, b, 0, s, a); break; }
-            if (abl == 2) { hipLaunchKernelGGL((k_net_h3<CI, NF, 2>), g, b, 0, s, a); break; }
-            if (abl == 3) { hipLaunchKernelGGL((k_net_h3<CI, NF, 3>), g, b, 0, s, a); break; }
-            if (abl == 6) { hipLaunchKernelGGL((k_net_h3<CI, NF, 6>), g, b, 0, s, a); break; }
-            if (abl == 7) { hipLaunchKernelGGL((k_net_h3<CI, NF, 7>), g, b, 0, s, a); break; }
-            if (abl == 16) { hipLaunchKernelGGL((k_net_h3<CI, NF, 16>), g, b, 0, s, a); break; }
-            if (abl == 8) {
-              static unsigned long long* dbg = nullptr; static int calls = 0;
-              const size_t n = (size_t)g.x * 8 * 16;
-              if (!dbg) hipMalloc(&dbg, (size_t)8192 * 128 * 8);
-              NetArgs a2 = a; a2.dbg = dbg;
-              hipLaunchKernelGGL((k_net_h3<CI, NF, 8>), g, b, 0, s, a2);
-              if (++calls % 32 == 0 && calls > 64) {
-                hipStreamSynchronize(s);
-                std::vector<unsigned long long> hbuf(n);
-                hipMemcpy(hbuf.data(), dbg, n * 8, hipMemcpyDeviceToHost);
-                double sum[10] = {0};
-                for (size_t w = 0; w < n / 16; ++w) for (int i = 0; i < 10; ++i) sum[i] += (double)hbuf[w * 16 + i];
-                const double nw = (double)(n / 16);
-                fprintf(stderr, "[stamp] waves %zu  cycles %.0f  realtime %.0f (100MHz)  clock %.3f GHz | per step (32 steps): conv1+epi %.0f  wait+barrier %.0f  dma issue %.0f  conv2 %.0f  | sum %.0f | tails (total of 2 passes): bn2 %.0f  wait %.0f  conv3 %.0f  stores %.0f\n",
-                        n / 16, sum[0] / nw, sum[1] / nw, sum[0] / sum[1] * 0.1, sum[2] / nw / 32, sum[3] / nw / 32, sum[4] / nw / 32, sum[5] / nw / 32,
-                        (sum[2] + sum[3] + sum[4] + sum[5]) / nw, sum[6] / nw, sum[7] / nw, sum[8] / nw, sum[9] / nw);
+#ifdef GLOWK_H3_STAMPS
+          if (CI == 2 && NF == 16) {
+            static unsigned long long* dbg = nullptr; static int calls = 0;
+            const dim3 g((a.Q + 255) / 256);
+            const size_t nw = (size_t)g.x * 8;
+            if (!dbg) hipMalloc(&dbg, (size_t)8192 * 64 * 8);
+            NetArgs a2 = a; a2.mask1 = reinterpret_cast<decltype(a2.mask1)>(dbg);
+            hipLaunchKernelGGL((k_net_h3<CI, NF>), g, dim3(512), 0, s, a2);
+            if (++calls % 32 == 0 && calls > 64 && nw <= 8192) {
+              hipStreamSynchronize(s);
+              std::vector<unsigned long long> hb(nw * 8);
+              hipMemcpy(hb.data(), dbg, nw * 64, hipMemcpyDeviceToHost);
+              double sum[2][8] = {{0}}; 
+              for (size_t w = 0; w < nw; ++w) for (int i = 0; i < 8; ++i) sum[(w % 8) >> 2][i] += (double)hb[w * 8 + i];
+              for (int gg = 0; gg < 2; ++gg) {
+                const double n = (double)nw / 2;
+                fprintf(stderr, "[stamp g%d] cycles %.0f clock %.3f GHz | per step: X %.0f  X-end %.0f  Y %.0f  Y-end %.0f | main total %.0f | tail ops %.0f  tail ends %.0f\n", gg,
+                        sum[gg][0] / n, sum[gg][0] / sum[gg][1] * 0.1, sum[gg][2] / n / 32, sum[gg][3] / n / 32, sum[gg][4] / n / 32, sum[gg][5] / n / 32,
+                        (sum[gg][2] + sum[gg][3] + sum[gg][4] + sum[gg][5]) / n, sum[gg][6] / n, sum[gg][7] / n);
               }
-              break;
             }
+            break;
           }
+#endif
           hipLaunchKernelGGL((k_net_h3<CI, NF>), dim3((a.Q + 255) / 256), dim3(512), 0, s, a);
           break;
         }
@@ -579,7 +576,7 @@ NetArgs net_args(glowk_handle* h, const Level& lv, const StepDev& sd, const floa
   a.vin = vin; a.in_stride = in_stride; a.in_off = in_off;
   a.Q = N * lv.h * lv.w; a.h = lv.h; a.w = lv.w;
   a.K1p = sd.K1p; a.ep = sd.ep; a.K2p = sd.K2p; a.K3p = sd.K3p; a.R0p = sd.R0p; a.mask1 = nullptr; a.mask2 = nullptr; a.P = h->bufP;
-  a.dbg = nullptr; a.RHp = sd.RHp; a.eph = sd.epH; a.P2 = h->bufP2; a.sc1 = sd.sc1; a.sc2 = sd.sc2; a.sc3 = sd.sc3;
+  a.RHp = sd.RHp; a.eph = sd.epH; a.P2 = h->bufP2; a.sc1 = sd.sc1; a.sc2 = sd.sc2; a.sc3 = sd.sc3;
   return a;
 }
 

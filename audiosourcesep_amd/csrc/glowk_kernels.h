@@ -23,6 +23,7 @@
 //  3. fp32-input MFMA and the FP32 VALU share one datapath: VALU FMAs do not hide under v_mfma_f32_32x32x2_f32.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <utility>
 #include <stdint.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -48,7 +49,6 @@ struct NetArgs {
   float* P2;             // f16x3: partial sums of the second pass
   const float4* RHp;     // f16x3 ring image (RingH), or null
   const float* eph;      // its epilogue constants [c1 | bs1 | c2 | bs2 | pb], see RingH
-  unsigned long long* dbg;
   float sc1, sc2, sc3;   // f16x3: 2^-(weight scale + activation scale) of conv1 / conv2 / conv3
 };
 
@@ -313,50 +313,71 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
 //   x = hi + lo,  hi = fp16(x), lo = fp16(x - hi);   a.b ~= a_hi.b_hi + a_hi.b_lo + a_lo.b_hi   (fp32 accumulate)
 // (fp16 products are exact in fp32; the dropped lo.lo term is 2^-22 relative) -- fp32-class accuracy at 3/16 of the
 // fp32-MFMA time.  Weights are split on the host after scaling by a power of two that keeps lo out of the fp16
-// subnormal range; activations are scaled by 2^5 before splitting; the scales are undone exactly in the epilogues.
-// Same structure and ring rules as k_net_f32 (NET_FWD); chunk = per hidden block: [fo][k-step s][hi|lo][64 lanes] half8.
+// subnormal range; activations are scaled by 2^5 before splitting.  Every per-channel constant (BatchNorm, biases) is
+// folded into the weights by the host (glowk.hip:pack_step), so the epilogues are  B = split(max(acc * 2^-S, 0)).
 // B operands taken from accumulators use registers 8s..8s+7 as k-step s, so element j of lane half h is k-row
 // 16s + 8(j>>2) + 4h + (j&3) of the tile: the host packs the A operands in that order.
+//
+// Geometry: 8 waves per workgroup, one 32-pixel column block each (256 pixels per workgroup); the hidden width is covered
+// in 2 passes of NFH = NF/2 accumulator tiles (128 registers per wave).  A pass is a sequence of OPS, one per phase:
+//     X_i  conv1 of hidden block i + ReLU + split                  (6..15 MFMAs, then ~80 VALU: MFMA pipe mostly idle)
+//     Y_i  conv2 contribution of block i to the NFH accumulators   (6 NFH MFMAs, no VALU)
+//     Z_z  half a chunk of conv3 A tiles                           (3 NFH MFMAs + ReLU/split of the accumulators)
+// in the order X_0 Y_0 X_1 Y_1 ... Z_0 Z_1 ...; phases are separated by one workgroup barrier.  The two waves of a SIMD
+// (wave w and w+4, "groups" 0 and 1) run the SAME op sequence ONE PHASE APART: while one is in the VALU-heavy X the
+// other is in the MFMA-only Y, so the matrix pipe sees one Y per phase instead of idling while both waves do epilogues
+// (measured before this: 5450 cycles per X+Y step against 3456 cycles of MFMA).
+//
+// LDS: main slots A/B (K2 chunks, and the later conv3 chunks) 32 KiB each, slot D (first conv3 chunk, loaded early),
+// two small slots for the conv1 operands.  What phase r of a pass starts (all 8 waves issue their share of the pieces):
+//     r = 2i-2: conv1 operands of block i       r = 2i-1: main chunk i (K2(i), or conv3 chunk i-NF+1)       r = 2: slot D
+// i.e. everything is requested two phases before its first reader; a phase ends with "wait until only this phase's own
+// DMA is in flight" + barrier, so a piece has two phases to land and every slot is rewritten only after the barrier that
+// follows its last reader (group 1 of the phase before).
 // ------------------------------------------------------------------------------------------------------------------
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define GLOWK_ACT_SCALE 32.0f
 
-// Geometry: 8 waves per workgroup (2 per SIMD), one 32-pixel column block each (256 pixels per workgroup); the hidden
-// width is covered in 2 passes of NFH = NF/2 accumulator tiles (128 AGPRs per wave), so that each weight chunk
-// [NFH fo][2 k-steps][hi|lo][64 lanes] half8 = NFH * 4 KiB serves 256 pixels (half the DMA bytes and DMA issues per MFMA
-// of the one-pass layout) and the partner wave on the SIMD hides the DMA-issue / conv1 / epilogue phases.
-// Ring image: per pass p: conv2 chunks fi = 0..NF-1 (main = K2[fi-tile, fo in pass p] | conv1 operands of block fi+1),
-// then conv3 chunks mt (main = K3[mt tile, f in pass p] | conv1 operands of block 0).  conv3's contraction over F is split
-// by pass: pass p stores its partial sums to P_p, k_couple adds the two.
 template <int CI, int NF>
 struct RingH {
   static constexpr int NFH = NF / 2;
   static constexpr int K1 = 9 * CI;
-  static constexpr int KS = (K1 + 15) / 16;                       // conv1 k-steps of 16
-  static constexpr int MAIN4 = NFH * 256;                         // 16-B rows of 64 lanes: NFH fo x 2 s x 2 (hi, lo)
-  static constexpr int K1PIECES = KS * 2;
-  static constexpr int SLOT4 = MAIN4 + K1PIECES * 64;
-  static constexpr int PIECES = NFH * 4 + K1PIECES;
-  static constexpr int NMT = (18 * CI + 31) / 32;
-  static constexpr int STEPS_PASS = NF + NMT;
+  static constexpr int KS = (K1 + 15) / 16;                       // conv1 k-steps of 16 (a spare row carries the bias)
+  static constexpr int MAINP = NFH * 4;                           // 1-KiB pieces per main chunk: NFH tiles x 2 k-steps x (hi, lo)
+  static constexpr int MAIN4 = MAINP * 64;                        // float4 per main chunk
+  static constexpr int K1P = KS * 2;                              // pieces of one block's conv1 operands
+  static constexpr int K14 = K1P * 64;
+  static constexpr int M3 = 18 * CI;                              // rows of P: 9 taps x 2 ci outputs
+  static constexpr int NMT = (M3 + 31) / 32;
+  static constexpr int G0N = NMT < 3 ? NMT : 3;                   // conv3 row tiles are processed in fused groups of <= 3:
+  static constexpr int G1N = NMT - G0N;                           // one ReLU/split of a hidden block feeds all tiles of a group
+  static constexpr int NOPS = 2 * NF + 2 * NMT;                   // ops (= phases) per pass
   static constexpr int EPN = (NF * 32 + 32 * NMT + 3) & ~3;       // conv2 accumulator init (F) | per-row constants of P (32 NMT)
-  static constexpr size_t LDS_BYTES = (size_t)2 * SLOT4 * 16 + (size_t)EPN * 4;
-  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && CI <= 8 && K1 < KS * 16;   // a spare k row carries conv1's bias
-  // conv3 A tiles of a pass in (hidden block, row tile) order: each hidden block is split once and feeds all NMT row
-  // tiles (NMT accumulators live); for wide conv3 outputs the accumulators would not fit next to acc2: row-tile-major there
-  static constexpr bool FUSED = NMT <= 3;
+  static constexpr size_t LDS_BYTES = (size_t)3 * MAIN4 * 16 + (size_t)2 * K14 * 16 + (size_t)EPN * 4;
+  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && CI >= 2 && CI <= 8 && K1 < KS * 16 && G1N <= 3;
+  // image: conv1 operands of all blocks, then per pass K2 chunks 0..NF-1 and conv3 chunks 0..NMT-1
+  static constexpr int K1TOT4 = NF * K14;
+  static constexpr int PASS4 = (NF + NMT) * MAIN4;
+  // conv3 A tile t of a pass -> (hidden block, row tile); tiles of a group are ordered (hidden block, row tile)
+  static constexpr int G1D = G1N > 0 ? G1N : 1;
+  static constexpr int tile_fo(int t) { return t < NFH * G0N ? t / G0N : (t - NFH * G0N) / G1D; }
+  static constexpr int tile_mt(int t) { return t < NFH * G0N ? t % G0N : G0N + (t - NFH * G0N) % G1D; }
 };
 
-// pieces [P0, P0 + N) of a ring slot image dealt round-robin to NW waves
-template <int P0, int N, int NW>
-__device__ __forceinline__ void stage_range_w(const float4* __restrict__ src, float4* dst, int wave, unsigned voff) {
+// pieces [0, N) of an image of 1-KiB pieces dealt round-robin to the 4 waves of a group (w4 = wave & 3, scalar; surplus
+// lanes re-fetch the last piece).  TAG is unique per call site: the marker keeps LLVM from sinking the DMA of two branches
+// into one block with a phi'd LDS pointer (the slot would no longer be static and every later ds_read would get an
+// s_waitcnt vmcnt(0): see ring_slot).
+template <int N, int TAG>
+__device__ __forceinline__ void stage4(const float4* __restrict__ src, float4* dst, int w4, unsigned voff) {
   const char* gb = uniform_ptr(src);
 #pragma unroll
-  for (int i = 0; i < (N + NW - 1) / NW; ++i) {
-    int p = i * NW + wave;
-    p = P0 + (p < N ? p : N - 1);
+  for (int i = 0; i < (N + 3) / 4; ++i) {
+    int p = i * 4 + w4;
+    p = p < N ? p : N - 1;
     glds16(reinterpret_cast<const float4*>(gb + (size_t)p * 1024 + voff), dst + p * 64);
   }
+  asm volatile("; dma site %0" ::"n"(TAG));
 }
 
 __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
@@ -374,171 +395,271 @@ __device__ __forceinline__ f32x16 mfma3(const h8& ahi, const h8& alo, const h8& 
   return acc;
 }
 
-#define GLOWK_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define GLOWK_WAIT_BARRIER()                          \
-  do {                                                \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  \
-    __syncthreads();                                  \
-  } while (0)
+// end of a phase.  DMA is only issued by ops that end with the bare barrier (Y); the op after it (X, Z) ends with
+// "everything of this wave has landed" + barrier, so a piece has two phases to land and is published by the second barrier.
+// The waits are builtins so that the compiler's own wait-count bookkeeping sees them.
+__device__ __forceinline__ void h3_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void h3_wait_barrier() {
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  h3_barrier();
+}
 
-// conv2 contribution of hidden block fi to this pass's NFH accumulator tiles (conv1 of block fi first; its operands were
-// published with the previous chunk, slot P^1).  Measured alternative, rejected: running conv1(next) and conv2(cur) in
-// opposite orders in the two halves of the workgroup (to de-phase the two waves of a SIMD) doubled the code of the step
-// and brought back ~470 spilled registers reloaded behind the DMA: 2.6x slower.
-template <int CI, int NF, int P, int ABL>
-__device__ __forceinline__ void h3_step(const NetArgs& a, int fi, const float4* nsrc, float4* s0, float4* s1, const float* epl,
-                                        const h8 (&xh)[(RingH<CI, NF>::KS)], const h8 (&xl)[(RingH<CI, NF>::KS)],
-                                        f32x16 (&acc2)[(RingH<CI, NF>::NFH)], int wave, unsigned voff, int lane, int hh, unsigned long long (&dt)[8]) {
+#ifdef GLOWK_H3_STAMPS   // diagnostic build only: per-op cycle stamps, written to the (otherwise unused) mask1 buffer
+#define H3_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define H3_ACC(i, a, b) (c.dt[i] += (b) - (a))
+#else
+#define H3_STAMP(t) do { } while (0)
+#define H3_ACC(i, a, b) do { } while (0)
+#endif
+
+template <int CI, int NF>
+struct H3Ctx {                      // wave-uniform pointers of the kernel (LDS arrays are distinct statics: see ring_slot)
+  float4 *sA, *sB, *sD, *k1s0, *k1s1;
+  const float4 *k1img, *pass_img, *next_img;
+  int w4;
+  unsigned voff;
+#ifdef GLOWK_H3_STAMPS
+  unsigned long long dt[8];
+#endif
+};
+
+// X: conv1 of one hidden block (operands in conv1 slot KP) + ReLU, as the split B fragments of conv2's two k-steps
+template <int CI, int NF, int KP>
+__device__ __forceinline__ void h3_X(const H3Ctx<CI, NF>& c, const h8 (&xh)[(RingH<CI, NF>::KS)], const h8 (&xl)[(RingH<CI, NF>::KS)],
+                                     float sc1, int lane, h8 (&bh)[2], h8 (&bl)[2]) {
   using G = RingH<CI, NF>;
-  constexpr int F = NF * 32;
-  unsigned long long t0, t1, t2, t3, t4;
-  if (ABL & 8) GLOWK_STAMP(t0);
   f32x16 h1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) h1[r] = 0.0f;
-  {
-    const h8* k1 = reinterpret_cast<const h8*>(ring_slot<P ^ 1>(s0, s1) + G::MAIN4) + lane;   // [s][hi|lo][64]
-    if (!(ABL & 1)) {
+  const h8* k1 = reinterpret_cast<const h8*>(KP ? c.k1s1 : c.k1s0) + lane;   // [s][hi|lo][64]
+  if constexpr (G::KS <= 3) {       // all operand reads in flight before the first MFMA
+    h8 kf[2 * G::KS];
 #pragma unroll
-      for (int s = 0; s < G::KS; ++s) h1 = mfma3(k1[(2 * s + 0) * 64], k1[(2 * s + 1) * 64], xh[s], xl[s], h1);
-    }
+    for (int i = 0; i < 2 * G::KS; ++i) kf[i] = k1[i * 64];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s) h1 = mfma3(kf[2 * s], kf[2 * s + 1], xh[s], xl[s], h1);
+  } else {
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s) h1 = mfma3(k1[(2 * s + 0) * 64], k1[(2 * s + 1) * 64], xh[s], xl[s], h1);
   }
-  // bias + ReLU + BN1, then scale and split into the B fragments of conv2's two k-steps
-  h8 bh[2], bl[2];
-  if (ABL & 1) { bh[0] = xh[0]; bh[1] = xh[0]; bl[0] = xl[0]; bl[1] = xl[0]; }
 #pragma unroll
-  for (int s = 0; s < ((ABL & 1) ? 0 : 2); ++s) {
+  for (int s = 0; s < 2; ++s) {
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int r = 8 * s + j;
-      v[j] = fmaxf(h1[r] * a.sc1, 0.0f);
-    }
+    for (int j = 0; j < 8; ++j) v[j] = fmaxf(h1[8 * s + j] * sc1, 0.0f);
     split8(v, bh[s], bl[s]);
-  }
-  if (ABL & 8) GLOWK_STAMP(t1);
-  if (!(ABL & 4)) GLOWK_WAIT_BARRIER();   // this step's chunk landed in every wave's view; slot P^1 is no longer read
-  if (ABL & 8) GLOWK_STAMP(t2);
-  if (!(ABL & 2)) stage_range_w<0, G::PIECES, 8>(nsrc, ring_slot<P ^ 1>(s0, s1), wave, voff);
-  if (ABL & 8) GLOWK_STAMP(t3);
-  const h8* buf = reinterpret_cast<const h8*>(ring_slot<P>(s0, s1)) + lane;
-#pragma unroll
-  for (int fo = 0; fo < G::NFH; ++fo) {
-    acc2[fo] = mfma3(buf[(fo * 4 + 0) * 64], buf[(fo * 4 + 1) * 64], bh[0], bl[0], acc2[fo]);
-    acc2[fo] = mfma3(buf[(fo * 4 + 2) * 64], buf[(fo * 4 + 3) * 64], bh[1], bl[1], acc2[fo]);
-  }
-  if (ABL & 8) {
-#pragma unroll
-    for (int fo = 0; fo < G::NFH; ++fo) asm volatile("" : "+a"(acc2[fo]));
-    GLOWK_STAMP(t4);
-    dt[0] += t1 - t0; dt[1] += t2 - t1; dt[2] += t3 - t2; dt[3] += t4 - t3;
   }
 }
 
-// one pass (F_out half PASS) of the workgroup's 256 pixels; the pass's first chunk sits in slot P0
-template <int CI, int NF, int P0, int PASS, int ABL>
-__device__ __forceinline__ void h3_pass(const NetArgs& a, const float4* ring, float4* s0, float4* s1, const float* epl,
-                                        const h8 (&xh)[(RingH<CI, NF>::KS)], const h8 (&xl)[(RingH<CI, NF>::KS)], int q, bool qok, int wave,
-                                        unsigned voff, int lane, int hh, unsigned long long (&dt)[8]) {
+// Y: conv2 contribution of one hidden block to this pass's NFH accumulator tiles (chunk in `slot`).  The wave is alone on
+// the matrix pipe during Y (its SIMD partner is in X), so two accumulator tiles are interleaved to keep dependent MFMAs
+// apart, and the DMA this wave owes (group 0: its NFH pieces of the next main chunk, group 1: its piece of the next-but-one
+// block's conv1 operands) is spread over the tile pairs instead of delaying the first MFMA.
+template <int CI, int NF, int TAG>
+__device__ __forceinline__ void h3_Y(const float4* slot, const h8 (&bh)[2], const h8 (&bl)[2], f32x16 (&acc2)[(RingH<CI, NF>::NFH)],
+                                     int lane, int g, const float4* main_src, float4* main_dst, const float4* k1_src, float4* k1_dst,
+                                     int w4, unsigned voff) {
   using G = RingH<CI, NF>;
-  constexpr int F = NF * 32;
-  constexpr int SLOT4 = G::SLOT4;
-  constexpr int NMT = G::NMT;
-  constexpr int M3 = 18 * CI;
-  constexpr int f2base = PASS * G::NFH * 32;
-  const float4* chunk = ring + (size_t)PASS * G::STEPS_PASS * SLOT4;
-  f32x16 acc2[G::NFH];
+  const h8* buf = reinterpret_cast<const h8*>(slot) + lane;
+  const char* mb = uniform_ptr(main_src);
+  // groups of 6 MFMAs = (tile pair p, k-step s); the A fragments of group i+1 are read while group i computes (the
+  // compiler on its own reads each fragment right before its MFMA and waits for it: ~1000 exposed cycles per Y)
+  constexpr int NG = G::NFH;
+  h8 A[2][4];
+  auto load = [&](h8 (&d)[4], int gi) {
+    const int p = gi >> 1, s = gi & 1;
+    d[0] = buf[((2 * p) * 4 + 2 * s + 0) * 64];      // tile 2p hi, lo; tile 2p+1 hi, lo
+    d[1] = buf[((2 * p) * 4 + 2 * s + 1) * 64];
+    d[2] = buf[((2 * p + 1) * 4 + 2 * s + 0) * 64];
+    d[3] = buf[((2 * p + 1) * 4 + 2 * s + 1) * 64];
+  };
+  load(A[0], 0);
 #pragma unroll
-  for (int fo = 0; fo < G::NFH; ++fo)
+  for (int gi = 0; gi < NG; ++gi) {
+    const int p = gi >> 1, s = gi & 1, f0 = 2 * p, f1 = 2 * p + 1;
+    if (gi + 1 < NG) load(A[(gi + 1) & 1], gi + 1);
+    if (!g) {
+      const int piece = gi * 4 + w4;                  // NFH pieces per wave, one per group
+      glds16(reinterpret_cast<const float4*>(mb + (size_t)piece * 1024 + voff), main_dst + piece * 64);
+      asm volatile("; dma site %0" ::"n"(TAG * 16 + gi));
+    } else if (gi == 0) {
+      stage4<G::K1P, TAG * 16 + 15>(k1_src, k1_dst, w4, voff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const h8 (&a)[4] = A[gi & 1];
+    acc2[f0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bh[s], acc2[f0], 0, 0, 0);
+    acc2[f1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[3], bh[s], acc2[f1], 0, 0, 0);
+    acc2[f0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bl[s], acc2[f0], 0, 0, 0);
+    acc2[f1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2], bl[s], acc2[f1], 0, 0, 0);
+    acc2[f0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bh[s], acc2[f0], 0, 0, 0);
+    acc2[f1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2], bh[s], acc2[f1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Z: conv3 op z of a pass = half a chunk of A tiles.  ReLU + split of hidden block fo happens once per fused group of row
+// tiles; a row tile is stored when its last hidden block has been added.
+template <int CI, int NF, int P0, int PASS, int Z>
+__device__ __forceinline__ void h3_Z(const NetArgs& a, H3Ctx<CI, NF>& c, const float* epl, f32x16 (&acc2)[(RingH<CI, NF>::NFH)],
+                                     f32x16 (&acc3)[(RingH<CI, NF>::G0N)], h8 (&bh)[2], h8 (&bl)[2], int g, int q, bool qok, int lane, int hh) {
+  using G = RingH<CI, NF>;
+  constexpr int NFH = G::NFH, M3 = G::M3;
+  unsigned long long z0 = 0, z1 = 0, z2 = 0;
+  (void)z0; (void)z1; (void)z2;
+  H3_STAMP(z0);
+  constexpr int S = Z >> 1;
+  constexpr int P0N = (G::NMT + 1 + P0) & 1;                       // main slot of the next pass's chunk 0
+  if (!g) {   // group 0 requests the later conv3 chunks (chunk 2 as soon as K2(NF-1) is dead, chunk s >= 3 when chunk s-2 is) ...
+    constexpr int SN = Z == 1 ? 2 : (Z >= 5 && (Z & 1)) ? (Z + 1) / 2 : 0;
+    if constexpr (SN >= 2 && SN < G::NMT)
+      stage4<G::MAINP, 16 + Z>(c.pass_img + (size_t)(NF + SN) * G::MAIN4, ((NF + SN - 1 + P0) & 1) ? c.sB : c.sA, c.w4, c.voff);
+    if constexpr (PASS == 0 && Z == 2 * G::NMT - 1) {               // ... and, in its last op, the next pass's first chunks
+      stage4<G::MAINP, 48>(c.next_img, P0N ? c.sB : c.sA, c.w4, c.voff);
+      stage4<G::MAINP, 49>(c.next_img + (size_t)NF * G::MAIN4, c.sD, c.w4, c.voff);
+    }
+  }
+  const float4* slot = S == 0 ? c.sD : (((NF + S - 1 + P0) & 1) ? c.sB : c.sA);
+  const h8* buf = reinterpret_cast<const h8*>(slot) + lane;
+  float* Pp = PASS == 0 ? a.P : a.P2;
+  const float* pb = epl + NF * 32;
+#pragma unroll
+  for (int i = 0; i < NFH / 2; ++i) {
+    const int tp = (Z & 1) * (NFH / 2) + i;            // tile position in the chunk
+    const int t = S * NFH + tp;
+    const int fo = G::tile_fo(t), mt = G::tile_mt(t);
+    const int ml = t >= NFH * G::G0N ? mt - G::G0N : mt;   // this row tile's accumulator within its group
+    if (ml == 0) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc2[fo][8 * s2 + j] * a.sc2, 0.0f);
+        split8(v, bh[s2], bl[s2]);
+      }
+    }
+    if (fo == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc3[ml][r] = 0.0f;
+    }
+    acc3[ml] = mfma3(buf[(tp * 4 + 0) * 64], buf[(tp * 4 + 1) * 64], bh[0], bl[0], acc3[ml]);
+    acc3[ml] = mfma3(buf[(tp * 4 + 2) * 64], buf[(tp * 4 + 3) * 64], bh[1], bl[1], acc3[ml]);
+    if (fo == NFH - 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mt * 32 + mfma_row(r, hh);
+        if (m < M3 && qok) Pp[(size_t)m * a.Q + q] = PASS == 0 ? fmaf(acc3[ml][r], a.sc3, pb[m]) : acc3[ml][r] * a.sc3;
+      }
+    }
+  }
+  H3_STAMP(z1);
+  h3_wait_barrier();
+  H3_STAMP(z2);
+  H3_ACC(4, z0, z1); H3_ACC(5, z1, z2);
+}
+
+template <int CI, int NF, int P0, int PASS, int... Z>
+__device__ __forceinline__ void h3_tail(const NetArgs& a, H3Ctx<CI, NF>& c, const float* epl, f32x16 (&acc2)[(RingH<CI, NF>::NFH)],
+                                        f32x16 (&acc3)[(RingH<CI, NF>::G0N)], h8 (&bh)[2], h8 (&bl)[2], int g, int q, bool qok, int lane, int hh,
+                                        std::integer_sequence<int, Z...>) {
+  (h3_Z<CI, NF, P0, PASS, Z>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, hh), ...);
+}
+
+// one pass (hidden half PASS) of the workgroup's 256 pixels.  g = this wave's group: its ops run in phase (op index + g).
+template <int CI, int NF, int P0, int PASS>
+__device__ __forceinline__ void h3_pass(const NetArgs& a, H3Ctx<CI, NF>& c, const float* epl,
+                                        const h8 (&xh)[(RingH<CI, NF>::KS)], const h8 (&xl)[(RingH<CI, NF>::KS)],
+                                        int g, int q, bool qok, int lane, int hh) {
+  using G = RingH<CI, NF>;
+  constexpr int NFH = G::NFH, NMT = G::NMT, M3 = G::M3;
+  constexpr int f2base = PASS * NFH * 32;
+  f32x16 acc2[NFH];
+#pragma unroll
+  for (int fo = 0; fo < NFH; ++fo)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[fo][r] = epl[f2base + fo * 32 + mfma_row(r, hh)];   // conv2 bias (scaled)
 
+  h8 bh[2], bl[2];
 #pragma nounroll
-  for (int fi = 0; fi < NF; fi += 2) {
-    h3_step<CI, NF, P0, ABL>(a, fi, chunk + (size_t)(fi + 1) * SLOT4, s0, s1, epl, xh, xl, acc2, wave, voff, lane, hh, dt);
-    h3_step<CI, NF, P0 ^ 1, ABL>(a, fi + 1, chunk + (size_t)(fi + 2) * SLOT4, s0, s1, epl, xh, xl, acc2, wave, voff, lane, hh, dt);
+  for (int i0 = 0; i0 < NF; i0 += 2) {
+    // X_i0 | Y_i0 | X_i0+1 | Y_i0+1.  During its Y ops group 0 requests the next main chunk (K2(i+1), after the last K2 the
+    // second conv3 chunk) into the other main slot, group 1 the conv1 operands of block i+2 (wrapping into the next pass)
+    // into the slot its X_i has just finished with.
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    (void)t0; (void)t1; (void)t2; (void)t3; (void)t4;
+    H3_STAMP(t0);
+    h3_X<CI, NF, 0>(c, xh, xl, a.sc1, lane, bh, bl);
+    asm volatile("" : "+v"(bh[0]), "+v"(bh[1]), "+v"(bl[0]), "+v"(bl[1]));
+    H3_STAMP(t1);
+    h3_wait_barrier();
+    H3_STAMP(t2);
+    h3_Y<CI, NF, 1>(P0 ? c.sB : c.sA, bh, bl, acc2, lane, g, c.pass_img + (size_t)(i0 + 1) * G::MAIN4, P0 ? c.sA : c.sB,
+                    c.k1img + (size_t)((i0 + 2) % NF) * G::K14, c.k1s0, c.w4, c.voff);
+#ifdef GLOWK_H3_STAMPS
+#pragma unroll
+    for (int fo = 0; fo < NFH; ++fo) asm volatile("" : "+v"(acc2[fo]));
+#endif
+    H3_STAMP(t3);
+    h3_barrier();
+    H3_STAMP(t4);
+    H3_ACC(0, t0, t1); H3_ACC(1, t1, t2); H3_ACC(2, t2, t3); H3_ACC(3, t3, t4);
+    H3_STAMP(t0);
+    h3_X<CI, NF, 1>(c, xh, xl, a.sc1, lane, bh, bl);
+    asm volatile("" : "+v"(bh[0]), "+v"(bh[1]), "+v"(bl[0]), "+v"(bl[1]));
+    H3_STAMP(t1);
+    h3_wait_barrier();
+    H3_STAMP(t2);
+    h3_Y<CI, NF, 2>(P0 ? c.sA : c.sB, bh, bl, acc2, lane, g, c.pass_img + (size_t)(i0 + 2 < NF ? i0 + 2 : NF + 1) * G::MAIN4,
+                    P0 ? c.sB : c.sA, c.k1img + (size_t)((i0 + 3) % NF) * G::K14, c.k1s1, c.w4, c.voff);
+#ifdef GLOWK_H3_STAMPS
+#pragma unroll
+    for (int fo = 0; fo < NFH; ++fo) asm volatile("" : "+v"(acc2[fo]));
+#endif
+    H3_STAMP(t3);
+    h3_barrier();
+    H3_STAMP(t4);
+    H3_ACC(0, t0, t1); H3_ACC(1, t1, t2); H3_ACC(2, t2, t3); H3_ACC(3, t3, t4);
   }
 
-  unsigned long long u0, u1, u2, u3, u4;
-  if (ABL & 8) GLOWK_STAMP(u0);
-  float* Pp = PASS == 0 ? a.P : a.P2;
-  // bias + ReLU of hidden block fo (BN2 is folded into K3), as the two split B fragments of its k-steps
-  auto frag2 = [&](int fo, h8 (&bh)[2], h8 (&bl)[2]) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc2[fo][8 * s + j] * a.sc2, 0.0f);
-      split8(v, bh[s], bl[s]);
-    }
-  };
-  f32x16 acc3[NMT];
-#pragma unroll
-  for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc3[mt][r] = 0.0f;
-  h8 bh[2], bl[2];
-#pragma unroll
-  for (int st = 0; st < NMT; ++st) {
-    if (ABL & 8) GLOWK_STAMP(u1);
-    GLOWK_WAIT_BARRIER();
-    if (ABL & 8) GLOWK_STAMP(u2);
-    const bool last_of_all = (PASS == 1) && (st == NMT - 1);
-    const float4* nsrc = chunk + (size_t)(NF + st + 1) * SLOT4;     // next conv3 chunk, or the next pass's first chunk
-    const h8* buf;
-    if ((st & 1) == 0) {
-      if (!last_of_all) stage_range_w<0, G::PIECES, 8>(nsrc, ring_slot<P0 ^ 1>(s0, s1), wave, voff);
-      buf = reinterpret_cast<const h8*>(ring_slot<P0>(s0, s1)) + lane;
-    } else {
-      if (!last_of_all) stage_range_w<0, G::PIECES, 8>(nsrc, ring_slot<P0>(s0, s1), wave, voff);
-      buf = reinterpret_cast<const h8*>(ring_slot<P0 ^ 1>(s0, s1)) + lane;
-    }
-#pragma unroll
-    for (int i = 0; i < G::NFH; ++i) {
-      const int t = st * G::NFH + i;
-      const int fo = G::FUSED ? t / NMT : i;
-      const int mt = G::FUSED ? t % NMT : st;
-      if (!G::FUSED || mt == 0) frag2(fo, bh, bl);
-      acc3[mt] = mfma3(buf[(i * 4 + 0) * 64], buf[(i * 4 + 1) * 64], bh[0], bl[0], acc3[mt]);
-      acc3[mt] = mfma3(buf[(i * 4 + 2) * 64], buf[(i * 4 + 3) * 64], bh[1], bl[1], acc3[mt]);
-    }
-    if (ABL & 8) { GLOWK_STAMP(u3); dt[5] += u2 - u1; dt[6] += u3 - u2; }
-  }
-  if (ABL & 8) GLOWK_STAMP(u3);
-  const float* pb = epl + F;
-#pragma unroll
-  for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = mt * 32 + mfma_row(r, hh);
-      const size_t pidx = (ABL & 16) ? (size_t)(q >> 5) * (M3 * 32) + m * 32 + (q & 31) : (size_t)m * a.Q + q;
-      if (m < M3 && qok) Pp[pidx] = PASS == 0 ? fmaf(acc3[mt][r], a.sc3, pb[m]) : acc3[mt][r] * a.sc3;
-    }
-  if (ABL & 8) { GLOWK_STAMP(u4); dt[7] += u4 - u3; dt[4] += 0 * (u0 - u0); }
+  // conv3: per-tap 1x1 partial sums of this pass's hidden half (k_couple adds the two passes)
+  f32x16 acc3[G::G0N];
+  h3_tail<CI, NF, P0, PASS>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, hh, std::make_integer_sequence<int, 2 * NMT>());
 }
 
-template <int CI, int NF, int ABL = 0>
+template <int CI, int NF>
 __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
   using G = RingH<CI, NF>;
   constexpr int K1 = G::K1;
   constexpr int KS = G::KS;
-  constexpr int F = NF * 32;
-  constexpr int SLOT4 = G::SLOT4;
   static_assert(G::FITS, "shape");
 
-  __shared__ float4 slot0[SLOT4];
-  __shared__ float4 slot1[SLOT4];
+  __shared__ float4 slotA[G::MAIN4];
+  __shared__ float4 slotB[G::MAIN4];
+  __shared__ float4 slotD[G::MAIN4];
+  __shared__ float4 k1slot0[G::K14];
+  __shared__ float4 k1slot1[G::K14];
   __shared__ float epl[G::EPN];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
-  const unsigned voff = (unsigned)lane * 16u;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7; waves w and w+4 share a SIMD
+  const int g = wave >> 2;
   const int pix = lane & 31;
   const int hh = lane >> 5;
   const int q = (blockIdx.x * 8 + (tid >> 6)) * 32 + pix;
   const bool qok = q < a.Q;
-  const float4* ring = a.RHp;
+
+  H3Ctx<CI, NF> c;
+  c.sA = slotA; c.sB = slotB; c.sD = slotD; c.k1s0 = k1slot0; c.k1s1 = k1slot1;
+  c.k1img = a.RHp;
+  c.pass_img = a.RHp + G::K1TOT4;
+  c.next_img = a.RHp + G::K1TOT4 + G::PASS4;
+  c.w4 = wave & 3;
+  c.voff = (unsigned)lane * 16u;
 
   // im2col fragments of this lane's pixel: k-step s holds k = 16 s + 8 hh + j (natural order), scaled and split
   h8 xh[KS], xl[KS];
@@ -567,21 +688,34 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
   }
   for (int i = tid; i < G::EPN; i += 512) epl[i] = a.eph[i];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // gathers done before any DMA is issued
-  stage_range_w<0, G::PIECES, 8>(ring, slot0, wave, voff);                                                          // chunk 0 -> slot 0
-  stage_range_w<G::NFH * 4, G::K1PIECES, 8>(ring + (size_t)(G::STEPS_PASS - 1) * SLOT4, slot1, wave, voff);        // conv1 operands of block 0
-  GLOWK_WAIT_BARRIER();   // ep, chunk 0 and block-0 conv1 operands visible to every wave
-
-  unsigned long long dt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c0 = 0, r0 = 0, c1, r1;
-  if (ABL & 8) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
-  h3_pass<CI, NF, 0, 0, ABL>(a, ring, slot0, slot1, epl, xh, xl, q, qok, wave, voff, lane, hh, dt);
-  h3_pass<CI, NF, (G::STEPS_PASS & 1), 1, ABL>(a, ring, slot0, slot1, epl, xh, xl, q, qok, wave, voff, lane, hh, dt);
-  if (ABL & 8) {
-    c1 = __builtin_amdgcn_s_memtime(); r1 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F);
-    if (lane == 0 && a.dbg) {
-      unsigned long long* d = a.dbg + (size_t)(blockIdx.x * 8 + wave) * 16;
-      d[0] = c1 - c0; d[1] = r1 - r0; d[2] = dt[0]; d[3] = dt[1]; d[4] = dt[2]; d[5] = dt[3]; d[6] = dt[4]; d[7] = dt[5]; d[8] = dt[6]; d[9] = dt[7];
-    }
+  if (!g) {
+    stage4<G::MAINP, 60>(c.pass_img, slotA, c.w4, c.voff);                                // K2 chunk 0
+    stage4<G::MAINP, 61>(c.pass_img + (size_t)NF * G::MAIN4, slotD, c.w4, c.voff);        // first conv3 chunk
+  } else {
+    stage4<G::K1P, 62>(c.k1img, k1slot0, c.w4, c.voff);                                   // conv1 operands of blocks 0, 1
+    stage4<G::K1P, 63>(c.k1img + G::K14, k1slot1, c.w4, c.voff);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                         // epl and the first chunks visible to every wave
+
+#ifdef GLOWK_H3_STAMPS
+  for (int i = 0; i < 8; ++i) c.dt[i] = 0;
+  unsigned long long k0, k1, rr0, rr1;
+  k0 = __builtin_amdgcn_s_memtime(); rr0 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+  if (g) h3_barrier();                                     // group 1 runs one phase behind group 0
+  h3_pass<CI, NF, 0, 0>(a, c, epl, xh, xl, g, q, qok, lane, hh);
+  c.pass_img = c.next_img;
+  h3_pass<CI, NF, (G::NMT + 1) & 1, 1>(a, c, epl, xh, xl, g, q, qok, lane, hh);
+  if (!g) h3_barrier();                                    // group 0 idles through the last phase
+#ifdef GLOWK_H3_STAMPS
+  k1 = __builtin_amdgcn_s_memtime(); rr1 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F);
+  if (lane == 0 && a.mask1) {
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(a.mask1) + (size_t)(blockIdx.x * 8 + wave) * 8;
+    d[0] = k1 - k0; d[1] = rr1 - rr0;
+    for (int i = 0; i < 6; ++i) d[2 + i] = c.dt[i];
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
