@@ -39,6 +39,8 @@ struct StepDev {            // device pointers into the arena
   const float4* R0p = nullptr;
   const float4* RHp = nullptr;   // f16x3 ring image (null: shape not supported by k_net_h3)
   const float* epH = nullptr;    // its epilogue constants
+  const float4* RHBp = nullptr;  // f16x3 image of the backward network (null: not supported: exact fp32 backward)
+  float scb1 = 1.f, scb2 = 1.f, scb3 = 1.f;
   float sc1 = 1.f, sc2 = 1.f, sc3 = 1.f;
   const float* K3bp = nullptr;   // backward: conv3^T operands of the small-conv chain [NF][9c/2][64]
   const float4* RBp = nullptr;   // backward ring image: K2^T chunk fo | K3b operands of block fo+1 ; conv1^T chunks
@@ -77,7 +79,7 @@ struct glowk_handle {
   double* bufStat = nullptr;    // [STAT_BLOCKS][32] partial sums + [32] means
   // input-gradient path: per-step saves of the forward pass (v, P, ReLU masks) and gradient scratch
   int saveN = 0;
-  float *saveV = nullptr, *saveP = nullptr, *bufGz = nullptr;
+  float *saveV = nullptr, *saveP = nullptr, *saveP2 = nullptr, *bufGz = nullptr;   // saveP2: second partial of P (f16x3 forward)
   unsigned short* saveM = nullptr;
   std::vector<size_t> offV, offP, offM;   // per forward-order step
   // HIP-event profiler of k_net
@@ -148,8 +150,9 @@ inline int rho(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 inline size_t pad4(size_t n) { return (n + 3) & ~size_t(3); }
 
 struct StepLayout {
-  size_t K1p, ep, K2p, K3p, R0p, K3bp, RBp, RHp, epH, Afwd, bfwd, Ainv, binv, b3, total;
+  size_t K1p, ep, K2p, K3p, R0p, K3bp, RBp, RHp, epH, RHBp, Afwd, bfwd, Ainv, binv, b3, total;
   size_t slotH;        // floats per main chunk of the f16x3 image (0: shape not supported by k_net_h3)
+  size_t slotHB;       // the same for the backward network's image
   size_t slotB, k3fB;  // backward ring image: floats per slot; floats of its conv3^T-operand part (0: not in the ring)
   size_t slot0, k1f0;  // floats per slot of k_net_f32's ring image; floats of its conv1 part (0: not in the ring)
 };
@@ -179,13 +182,18 @@ StepLayout step_layout(int c, int F) {
     L.RBp = o; o += (size_t)(NF + NM1) * L.slotB;
   }
   {
-    const int KS = (9 * CI + 15) / 16, NFH = NF / 2;
-    const size_t ephn = pad4((size_t)F + 32 * NMT);                                                   // RingH::EPN
-    const size_t lds = (size_t)3 * NFH * 4096 + (size_t)2 * KS * 2048 + ephn * 4;                     // RingH::LDS_BYTES
-    const bool fitsH = lds <= 160 * 1024 && NF % 4 == 0 && CI >= 2 && CI <= 8 && 9 * CI < KS * 16 && NMT <= 6;   // RingH::FITS
+    const int KS = (9 * CI + 1 + 15) / 16, NFH = NF / 2;                                              // RingH<CI, 18 CI, NF, fwd>
+    const size_t ephn = pad4((size_t)F + 32 * NMT);
+    const size_t lds = (size_t)3 * NFH * 4096 + (size_t)2 * KS * 2048 + ephn * 4;
+    const bool fitsH = lds <= 160 * 1024 && NF % 4 == 0 && KS <= 5 && NMT <= 6;
     L.slotH = fitsH ? (size_t)NFH * 1024 : 0;
     L.RHp = o; o += fitsH ? (size_t)NF * KS * 512 + (size_t)2 * (NF + NMT) * NFH * 1024 : 0;
     L.epH = o; o += fitsH ? ephn : 0;
+    const int KSB = (9 * c + 15) / 16, NMB = (9 * CI + 31) / 32;                                      // RingH<c, 9 CI, NF, bwd>
+    const size_t ldsb = (size_t)3 * NFH * 4096 + (size_t)2 * KSB * 2048 + pad4((size_t)F + 32 * NMB) * 4 + (size_t)2 * NF * 1024;
+    const bool fitsHB = ldsb <= 160 * 1024 && NF % 4 == 0 && KSB <= 5 && NMB <= 6;
+    L.slotHB = fitsHB ? (size_t)NFH * 1024 : 0;
+    L.RHBp = o; o += fitsHB ? (size_t)NF * KSB * 512 + (size_t)2 * (NF + NMB) * NFH * 1024 : 0;
   }
   L.Afwd = o; o += pad4((size_t)c * c);
   L.bfwd = o; o += pad4(c);
@@ -240,7 +248,7 @@ bool pack_affine(const glowk_config& cfg, const Level& lv, int k, float* dst, do
 }
 
 // pack one step into dst (host staging of the arena)
-bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, double* ld_const_out, float* scales3, std::string* err) {
+bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, double* ld_const_out, float* scales3 /* [6]: fwd, bwd */, std::string* err) {
   const int c = lv.c, F = cfg.F, CI = c / 2, CO = c, NF = F / 32, KS1 = (9 * CI) / 2, NMT = (9 * c + 31) / 32;
   const StepLayout L = step_layout(c, F);
   auto T = [&](int id) -> const float* { return lv.host[id][k].data(); };
@@ -305,16 +313,24 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
     }
   }
   // ---- f16x3 image (k_net_h3): weights scaled by a power of two, split hi/lo in fp16, A operands in fragment order ----
-  scales3[0] = scales3[1] = scales3[2] = 1.0f;
+  for (int i = 0; i < 6; ++i) scales3[i] = 1.0f;
+  auto pow2_scale = [](const float* w, size_t n) {
+    float m = 0.0f;
+    for (size_t i = 0; i < n; ++i) m = std::fmax(m, std::fabs(w[i]));
+    int e = 0;
+    if (m > 0.0f) { std::frexp(m, &e); }          // m = f * 2^e, f in [0.5, 1)
+    return 14 - e;                                // |w| * 2^S < 2^14: hi well inside fp16, lo ~2^3 (normal)
+  };
+  // one A-operand element: scaled, split, stored as half j of this lane's 16 bytes in the hi row and in the lo row after it
+  auto put = [](float* row_lane, int j, int hl, float w, int S) {
+    const float ws = std::ldexp(w, S);
+    const _Float16 hi = (_Float16)ws;
+    const _Float16 lo = (_Float16)(ws - (float)hi);
+    _Float16* dsth = reinterpret_cast<_Float16*>(row_lane) + (size_t)hl * 64 * 8;
+    dsth[j] = hl ? lo : hi;
+  };
   if (L.slotH) {
-    const int KS = (9 * CI + 15) / 16;
-    auto pow2_scale = [](const float* w, size_t n) {
-      float m = 0.0f;
-      for (size_t i = 0; i < n; ++i) m = std::fmax(m, std::fabs(w[i]));
-      int e = 0;
-      if (m > 0.0f) { std::frexp(m, &e); }          // m = f * 2^e, f in [0.5, 1)
-      return 14 - e;                                // |w| * 2^S < 2^14: hi well inside fp16, lo ~2^3 (normal)
-    };
+    const int KS = (9 * CI + 1 + 15) / 16;
     // Every per-channel constant of the epilogues is folded into the weights (host, fp64):
     //  * BatchNorm y = g*r + d with g = m * 2^e (|m| in [0.5,1)): the power of two scales the channel's own producer
     //    (a row scale: exact), the mantissa m multiplies the consumer's weight column, and W.d joins the consumer's bias
@@ -360,14 +376,6 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
       for (int f = 0; f < F; ++f) eh[f] = (float)std::ldexp((double)act * b2f[f], e2[f] + S2);
       for (int m = 0; m < 32 * NMT; ++m) eh[F + m] = m < 9 * CO ? (float)pbf[m] : 0.0f;
     }
-    auto put = [](float* row_lane, int j, int hl, float w, int S) {
-      // row = 64 lanes x 8 halves; hi and lo live in consecutive rows; row_lane points at this lane's 8 halves of the hi row
-      const float ws = std::ldexp(w, S);
-      const _Float16 hi = (_Float16)ws;
-      const _Float16 lo = (_Float16)(ws - (float)hi);
-      _Float16* dsth = reinterpret_cast<_Float16*>(row_lane) + (size_t)hl * 64 * 8;
-      dsth[j] = hl ? lo : hi;
-    };
     // image (RingH): conv1 operands of every hidden block [NF][KS][hi|lo][64 lanes] half8 (natural k order, row 9 CI = bias),
     // then per pass: K2 chunks 0..NF-1 and conv3 chunks 0..NMT-1, a chunk = NFH tiles x [2 k-steps][hi|lo][64 lanes] half8
     const int NFH = NF / 2, G0N = NMT < 3 ? NMT : 3, G1N = NMT - G0N > 0 ? NMT - G0N : 1;
@@ -404,6 +412,58 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
                   if (m < 9 * CO) { const int tap = m / CO, co = m % CO; w = K3f[((size_t)tap * F + f) * CO + co]; }
                 }
                 float* row_lane = chunk + ((size_t)((tp * 2 + s2) * 2) * 64 + l) * 4;   // hi row of (tile, k-step); 16 B per lane
+                put(row_lane, j, 0, w, S);
+                put(row_lane, j, 1, w, S);
+              }
+      }
+  }
+
+  // ---- f16x3 image of the backward network (k_net_h3, NET_BWD): g_a2 = g2 * mask2 * conv3^T(g_o), g_a1 = g1 * mask1 * K2 g_a2,
+  //      per-tap conv1^T.  The BatchNorm factors multiply the producing layer's output rows (a weight change, any sign). ----
+  if (L.slotHB) {
+    const int KSB = (9 * c + 15) / 16, NMB = (9 * CI + 31) / 32, NFH = NF / 2;
+    const int G0N = NMB < 3 ? NMB : 3, G1N = NMB - G0N > 0 ? NMB - G0N : 1;
+    const float* ep = dst + L.ep;       // [b1 | g1 | d1 | b2 | g2 | d2]
+    std::vector<float> W3b((size_t)9 * c * F), W2b((size_t)F * F);
+    for (int kk = 0; kk < 9 * c; ++kk)
+      for (int f = 0; f < F; ++f) { const int tap = kk / c, co = kk % c; W3b[(size_t)kk * F + f] = K3[((size_t)tap * F + f) * c + co] * ep[4 * F + f]; }
+    for (int f2 = 0; f2 < F; ++f2)
+      for (int f1 = 0; f1 < F; ++f1) W2b[(size_t)f2 * F + f1] = K2[(size_t)f1 * F + f2] * ep[F + f1];      // [k = f2][out = f1]
+    const int S1 = pow2_scale(W3b.data(), W3b.size()), S2 = pow2_scale(W2b.data(), W2b.size()), S3 = pow2_scale(K1, (size_t)9 * CI * F);
+    scales3[3] = std::ldexp(1.0f, -S1); scales3[4] = std::ldexp(1.0f, -S2); scales3[5] = std::ldexp(1.0f, -S3) / 32.0f;
+    const size_t k1blk = (size_t)KSB * 2 * 256, chunkf = (size_t)NFH * 1024;
+    float* img = dst + L.RHBp;
+    for (int blk = 0; blk < NF; ++blk)
+      for (int s2 = 0; s2 < KSB; ++s2)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < 8; ++j) {
+            const int i = l & 31, hh = l >> 5, kk = 16 * s2 + 8 * hh + j;
+            const float w = kk < 9 * c ? W3b[(size_t)kk * F + blk * 32 + i] : 0.0f;
+            float* row_lane = img + (size_t)blk * k1blk + ((size_t)(s2 * 2) * 64 + l) * 4;
+            put(row_lane, j, 0, w, S1);
+            put(row_lane, j, 1, w, S1);
+          }
+    for (int ps = 0; ps < 2; ++ps)
+      for (int ch = 0; ch < NF + NMB; ++ch) {
+        float* chunk = img + (size_t)NF * k1blk + ((size_t)ps * (NF + NMB) + ch) * chunkf;
+        for (int tp = 0; tp < NFH; ++tp)
+          for (int s2 = 0; s2 < 2; ++s2)
+            for (int l = 0; l < 64; ++l)
+              for (int j = 0; j < 8; ++j) {
+                const int i = l & 31, hh = l >> 5;
+                const int kloc = 16 * s2 + 8 * (j >> 2) + 4 * hh + (j & 3);
+                float w = 0.0f;
+                int S;
+                if (ch < NF) { w = W2b[(size_t)(ch * 32 + kloc) * F + (ps * NFH + tp) * 32 + i]; S = S2; }
+                else {
+                  const int t = (ch - NF) * NFH + tp;
+                  const int fo = t < NFH * G0N ? t / G0N : (t - NFH * G0N) / G1N;
+                  const int mt = t < NFH * G0N ? t % G0N : G0N + (t - NFH * G0N) % G1N;
+                  const int m = mt * 32 + i, f = (ps * NFH + fo) * 32 + kloc;
+                  S = S3;
+                  if (m < 9 * CI) w = K1[(size_t)m * F + f];          // conv1^T: row (tap, cin), contraction over the hidden channel
+                }
+                float* row_lane = chunk + ((size_t)((tp * 2 + s2) * 2) * 64 + l) * 4;
                 put(row_lane, j, 0, w, S);
                 put(row_lane, j, 1, w, S);
               }
@@ -461,38 +521,23 @@ int launch_net_t(const NetArgs& a, int mode, hipStream_t s) {
     case NET_FWD:      hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a); break;
     case NET_FWD_SAVE: hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE>), dim3(ntiles), dim3(256), 0, s, a); break;
     case NET_BWD:      hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD>), dim3(ntiles), dim3(256), 0, s, a); break;
-    case 3:
-      if constexpr (RingH<CI, NF>::FITS) {
-        if (a.RHp) {
-#ifdef GLOWK_H3_STAMPS
-          if (CI == 2 && NF == 16) {
-            static unsigned long long* dbg = nullptr; static int calls = 0;
-            const dim3 g((a.Q + 255) / 256);
-            const size_t nw = (size_t)g.x * 8;
-            if (!dbg) hipMalloc(&dbg, (size_t)8192 * 64 * 8);
-            NetArgs a2 = a; a2.mask1 = reinterpret_cast<decltype(a2.mask1)>(dbg);
-            hipLaunchKernelGGL((k_net_h3<CI, NF>), g, dim3(512), 0, s, a2);
-            if (++calls % 32 == 0 && calls > 64 && nw <= 8192) {
-              hipStreamSynchronize(s);
-              std::vector<unsigned long long> hb(nw * 8);
-              hipMemcpy(hb.data(), dbg, nw * 64, hipMemcpyDeviceToHost);
-              double sum[2][8] = {{0}}; 
-              for (size_t w = 0; w < nw; ++w) for (int i = 0; i < 8; ++i) sum[(w % 8) >> 2][i] += (double)hb[w * 8 + i];
-              for (int gg = 0; gg < 2; ++gg) {
-                const double n = (double)nw / 2;
-                fprintf(stderr, "[stamp g%d] cycles %.0f clock %.3f GHz | per step: X %.0f  X-end %.0f  Y %.0f  Y-end %.0f | main total %.0f | tail ops %.0f  tail ends %.0f\n", gg,
-                        sum[gg][0] / n, sum[gg][0] / sum[gg][1] * 0.1, sum[gg][2] / n / 32, sum[gg][3] / n / 32, sum[gg][4] / n / 32, sum[gg][5] / n / 32,
-                        (sum[gg][2] + sum[gg][3] + sum[gg][4] + sum[gg][5]) / n, sum[gg][6] / n, sum[gg][7] / n);
-              }
-            }
-            break;
-          }
-#endif
-          hipLaunchKernelGGL((k_net_h3<CI, NF>), dim3((a.Q + 255) / 256), dim3(512), 0, s, a);
-          break;
-        }
+    case 3:   // f16x3 arithmetic: forward / forward with saves / backward; shapes without an instance run the exact fp32 kernel
+      if constexpr (RingH<CI, 18 * CI, NF, NET_FWD>::FITS) {
+        if (a.RHp) { hipLaunchKernelGGL((k_net_h3<CI, 18 * CI, NF, NET_FWD>), dim3((a.Q + 255) / 256), dim3(512), 0, s, a); break; }
       }
-      hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a);   // shape without an f16x3 instance
+      hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a);
+      break;
+    case 4:
+      if constexpr (RingH<CI, 18 * CI, NF, NET_FWD_SAVE>::FITS) {
+        if (a.RHp) { hipLaunchKernelGGL((k_net_h3<CI, 18 * CI, NF, NET_FWD_SAVE>), dim3((a.Q + 255) / 256), dim3(512), 0, s, a); break; }
+      }
+      hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE>), dim3(ntiles), dim3(256), 0, s, a);
+      break;
+    case 5:
+      if constexpr (RingH<2 * CI, 9 * CI, NF, NET_BWD>::FITS) {
+        if (a.RHp) { hipLaunchKernelGGL((k_net_h3<2 * CI, 9 * CI, NF, NET_BWD>), dim3((a.Q + 255) / 256), dim3(512), 0, s, a); break; }
+      }
+      hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD>), dim3(ntiles), dim3(256), 0, s, a);
       break;
     default: return fail("bad k_net mode");
   }
@@ -585,8 +630,8 @@ int ensure_save(glowk_handle* h, int N) {
   if (N <= h->saveN) return 0;
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipDeviceSynchronize());
-  if (h->saveV) { hipFree(h->saveV); hipFree(h->saveP); hipFree(h->saveM); hipFree(h->bufGz); }
-  h->saveV = h->saveP = h->bufGz = nullptr; h->saveM = nullptr; h->saveN = 0;
+  if (h->saveV) { hipFree(h->saveV); hipFree(h->saveP); hipFree(h->saveP2); hipFree(h->saveM); hipFree(h->bufGz); }
+  h->saveV = h->saveP = h->saveP2 = h->bufGz = nullptr; h->saveM = nullptr; h->saveN = 0;
   const int K = h->cfg.K, L = h->cfg.L, NF = h->cfg.F / 32;
   size_t v = 0, p = 0, m = 0;
   h->offV.assign((size_t)L * K, 0); h->offP.assign((size_t)L * K, 0); h->offM.assign((size_t)L * K, 0);
@@ -604,6 +649,7 @@ int ensure_save(glowk_handle* h, int N) {
   const size_t E = (size_t)h->cfg.H * h->cfg.W * h->cfg.C;
   HIPCHK(hipMalloc(&h->saveV, v * 4));
   HIPCHK(hipMalloc(&h->saveP, p * 4));
+  HIPCHK(hipMalloc(&h->saveP2, p * 4));
   HIPCHK(hipMalloc(&h->saveM, m * 2));
   HIPCHK(hipMalloc(&h->bufGz, (size_t)N * E * 4));
   if (!h->bufC) HIPCHK(hipMalloc(&h->bufC, (size_t)h->wsN * E * 4));
@@ -633,14 +679,16 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
       const StepDev& sd = lv.dev[k];
       const size_t sidx = (size_t)lvl * K + (K - 1 - k);
       NetArgs na = net_args(h, lv, sd, cur, lv.c, lv.c / 2, N);
+      const bool h3 = h->precision == GLOWK_PREC_F16X3 && sd.RHp;   // two-pass kernel: P arrives as two partial sums
       if (save) {
         na.P = h->saveP + h->offP[sidx];
+        na.P2 = h->saveP2 + h->offP[sidx];
         na.mask1 = h->saveM + h->offM[sidx];
         na.mask2 = na.mask1 + blocks * NF * 64;
       }
-      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, save ? NET_FWD_SAVE : (h->precision == GLOWK_PREC_F16X3 ? 3 : NET_FWD))) return rc;
+      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, h->precision == GLOWK_PREC_F16X3 ? (save ? 4 : 3) : (save ? NET_FWD_SAVE : NET_FWD))) return rc;
       CoupleArgs ca;
-      ca.vin = cur; ca.P = na.P; ca.P2 = (!save && h->precision == GLOWK_PREC_F16X3 && sd.RHp) ? h->bufP2 : nullptr; ca.b3 = sd.b3; ca.logdet = h->bufLd; ca.log_s_out = nullptr; ca.t_out = nullptr;
+      ca.vin = cur; ca.P = na.P; ca.P2 = h3 ? na.P2 : nullptr; ca.b3 = sd.b3; ca.logdet = h->bufLd; ca.log_s_out = nullptr; ca.t_out = nullptr;
       ca.Q = (int)Q; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0;
       float* next = save && k > 0 ? h->saveV + h->offV[sidx + 1] : oth;
       if (k > 0) {
@@ -689,21 +737,23 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
     const Level& lv = h->levels[lvl];
     const int Q = N * lv.h * lv.w;
     const size_t blocks = (((size_t)Q + 127) / 128) * 4;
+    bool pg2_live = false;          // the previous network launch left a second partial of Pg in bufP2
     for (int k = 0; k < K; ++k) {   // reverse of the forward order K-1 .. 0
       const StepDev& sd = lv.dev[k];
       const size_t sidx = (size_t)lvl * K + (K - 1 - k);
       BwdArgs ba;
       ba.Q = Q; ba.h = lv.h; ba.w = lv.w;
-      ba.v = h->saveV + h->offV[sidx]; ba.P = h->saveP + h->offP[sidx]; ba.b3 = sd.b3;
+      const bool h3f = h->precision == GLOWK_PREC_F16X3 && sd.RHp;    // how this step's forward pass ran
+      ba.v = h->saveV + h->offV[sidx]; ba.P = h->saveP + h->offP[sidx]; ba.P2 = h3f ? h->saveP2 + h->offP[sidx] : nullptr; ba.b3 = sd.b3;
       ba.g_o = g_o; ba.ghalf_out = gh_b; ba.gu_out = nullptr;
       if (k == 0) {
         // gradient wrt the block output: the latent slice itself (last block) or what k_bwd_split assembled
-        ba.ghalf_in = nullptr; ba.Pg = nullptr; ba.A = nullptr;
+        ba.ghalf_in = nullptr; ba.Pg = nullptr; ba.Pg2 = nullptr; ba.A = nullptr;
         if (lvl == L - 1) { ba.gv_direct = h->bufGz; ba.gvd_stride = h->Cl; ba.gvd_off = lv.z_off; }
         else              { ba.gv_direct = gy_src;   ba.gvd_stride = lv.c;  ba.gvd_off = 0; }
       } else {
         // merge step k-1's network gradient, go through its fused ActNorm + 1x1, then this step's coupling
-        ba.ghalf_in = gh_a; ba.Pg = Pg; ba.gv_direct = nullptr; ba.gvd_stride = 0; ba.gvd_off = 0;
+        ba.ghalf_in = gh_a; ba.Pg = Pg; ba.Pg2 = pg2_live ? h->bufP2 : nullptr; ba.gv_direct = nullptr; ba.gvd_stride = 0; ba.gvd_off = 0;
         ba.A = lv.dev[k - 1].Afwd;
       }
       CDISPATCH(lv.c, hipLaunchKernelGGL((k_bwd_light<CC>), dim3(N), dim3(256), 0, s, ba));
@@ -713,15 +763,18 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       na.K1p = sd.K3bp; na.R0p = sd.RBp; na.P = Pg;
       na.mask1 = h->saveM + h->offM[sidx];
       na.mask2 = na.mask1 + blocks * NF * 64;
-      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, NET_BWD)) return rc;
+      const bool h3b = h->precision == GLOWK_PREC_F16X3 && sd.RHBp;
+      if (h3b) { na.RHp = sd.RHBp; na.eph = nullptr; na.sc1 = sd.scb1; na.sc2 = sd.scb2; na.sc3 = sd.scb3; na.P2 = h->bufP2; }
+      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, h3b ? 5 : NET_BWD)) return rc;
+      pg2_live = h3b;
     }
     // first forward step of the block (k = K-1): merge, then through its ActNorm + 1x1 -> g_u of the squeezed block input
     {
       BwdArgs ba;
       ba.Q = Q; ba.h = lv.h; ba.w = lv.w;
-      ba.ghalf_in = gh_a; ba.Pg = Pg; ba.gv_direct = nullptr; ba.gvd_stride = 0; ba.gvd_off = 0;
+      ba.ghalf_in = gh_a; ba.Pg = Pg; ba.Pg2 = pg2_live ? h->bufP2 : nullptr; ba.gv_direct = nullptr; ba.gvd_stride = 0; ba.gvd_off = 0;
       ba.A = lv.dev[K - 1].Afwd;
-      ba.v = nullptr; ba.P = nullptr; ba.b3 = nullptr; ba.g_o = nullptr; ba.ghalf_out = nullptr; ba.gu_out = g_o;   // reuse g_o as g_u
+      ba.v = nullptr; ba.P = nullptr; ba.P2 = nullptr; ba.b3 = nullptr; ba.g_o = nullptr; ba.ghalf_out = nullptr; ba.gu_out = g_o;   // reuse g_o as g_u
       CDISPATCH(lv.c, hipLaunchKernelGGL((k_bwd_light<CC>), dim3(N), dim3(256), 0, s, ba));
       LAUNCHCHK("k_bwd_light");
     }
@@ -822,7 +875,7 @@ int glowk_destroy(glowk_handle* h) {
   if (h->bufC) hipFree(h->bufC);
   if (h->bufP2) hipFree(h->bufP2);
   if (h->bufStat) hipFree(h->bufStat);
-  if (h->saveV) { hipFree(h->saveV); hipFree(h->saveP); hipFree(h->saveM); hipFree(h->bufGz); }
+  if (h->saveV) { hipFree(h->saveV); hipFree(h->saveP); hipFree(h->saveP2); hipFree(h->saveM); hipFree(h->bufGz); }
   for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
   delete h;
   return 0;
@@ -884,11 +937,12 @@ int glowk_finalize_weights(glowk_handle* h) {
     for (int k = 0; k < cfg.K; ++k) {
       std::string err;
       double ldc = 0;
-      float sc3[3];
+      float sc3[6];
       if (!pack_step(cfg, lv, k, stage.data() + o, &ldc, sc3, &err))
         return fail("level " + std::to_string(l) + " step " + std::to_string(k) + ": " + err);
       h->ld_step[l * cfg.K + k] = ldc;
       h->levels[l].dev[k].sc1 = sc3[0]; h->levels[l].dev[k].sc2 = sc3[1]; h->levels[l].dev[k].sc3 = sc3[2];
+      h->levels[l].dev[k].scb1 = sc3[3]; h->levels[l].dev[k].scb2 = sc3[4]; h->levels[l].dev[k].scb3 = sc3[5];
       h->ld_const += ldc;
       offs.push_back(o);
       o += step_layout(lv.c, cfg.F).total;
@@ -919,6 +973,7 @@ int glowk_finalize_weights(glowk_handle* h) {
       d.R0p = reinterpret_cast<const float4*>(base + SL.R0p);
       d.RHp = SL.slotH ? reinterpret_cast<const float4*>(base + SL.RHp) : nullptr;
       d.epH = SL.slotH ? base + SL.epH : nullptr;
+      d.RHBp = SL.slotHB ? reinterpret_cast<const float4*>(base + SL.RHBp) : nullptr;
       d.K3bp = base + SL.K3bp;
       d.RBp = reinterpret_cast<const float4*>(base + SL.RBp);
       d.Afwd = base + SL.Afwd; d.bfwd = base + SL.bfwd; d.Ainv = base + SL.Ainv; d.binv = base + SL.binv; d.b3 = base + SL.b3;

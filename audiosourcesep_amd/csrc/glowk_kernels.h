@@ -338,28 +338,32 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define GLOWK_ACT_SCALE 32.0f
 
-template <int CI, int NF>
+// KIN = input channels of the small 3x3 convolution (c/2 forward: conv1; c backward: conv3^T), MOUT = rows of the per-tap
+// output (18 ci forward: conv3; 9 ci backward: conv1^T), MODE as for k_net_f32.
+template <int KIN, int MOUT, int NF, int MODE>
 struct RingH {
+  static constexpr bool BWD = MODE == NET_BWD;
   static constexpr int NFH = NF / 2;
-  static constexpr int K1 = 9 * CI;
-  static constexpr int KS = (K1 + 15) / 16;                       // conv1 k-steps of 16 (a spare row carries the bias)
+  static constexpr int K1 = 9 * KIN;
+  static constexpr int KROWS = K1 + (BWD ? 0 : 1);                // forward: a spare k row carries conv1's bias
+  static constexpr int KS = (KROWS + 15) / 16;                    // small-conv k-steps of 16
   static constexpr int MAINP = NFH * 4;                           // 1-KiB pieces per main chunk: NFH tiles x 2 k-steps x (hi, lo)
   static constexpr int MAIN4 = MAINP * 64;                        // float4 per main chunk
-  static constexpr int K1P = KS * 2;                              // pieces of one block's conv1 operands
+  static constexpr int K1P = KS * 2;                              // pieces of one block's small-conv operands
   static constexpr int K14 = K1P * 64;
-  static constexpr int M3 = 18 * CI;                              // rows of P: 9 taps x 2 ci outputs
+  static constexpr int M3 = MOUT;
   static constexpr int NMT = (M3 + 31) / 32;
-  static constexpr int G0N = NMT < 3 ? NMT : 3;                   // conv3 row tiles are processed in fused groups of <= 3:
+  static constexpr int G0N = NMT < 3 ? NMT : 3;                   // output row tiles are processed in fused groups of <= 3:
   static constexpr int G1N = NMT - G0N;                           // one ReLU/split of a hidden block feeds all tiles of a group
-  static constexpr int NOPS = 2 * NF + 2 * NMT;                   // ops (= phases) per pass
+  static constexpr int G1D = G1N > 0 ? G1N : 1;
   static constexpr int EPN = (NF * 32 + 32 * NMT + 3) & ~3;       // conv2 accumulator init (F) | per-row constants of P (32 NMT)
-  static constexpr size_t LDS_BYTES = (size_t)3 * MAIN4 * 16 + (size_t)2 * K14 * 16 + (size_t)EPN * 4;
-  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && CI >= 2 && CI <= 8 && K1 < KS * 16 && G1N <= 3;
-  // image: conv1 operands of all blocks, then per pass K2 chunks 0..NF-1 and conv3 chunks 0..NMT-1
+  static constexpr int MASK2B = BWD ? 2 * NF * 512 * 2 : 0;       // backward: both ReLU masks of the workgroup's 8 column blocks
+  static constexpr size_t LDS_BYTES = (size_t)3 * MAIN4 * 16 + (size_t)2 * K14 * 16 + (size_t)EPN * 4 + MASK2B;
+  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && KS <= 5 && G1N <= 3;
+  // image: small-conv operands of all blocks, then per pass main chunks 0..NF-1 and output chunks 0..NMT-1
   static constexpr int K1TOT4 = NF * K14;
   static constexpr int PASS4 = (NF + NMT) * MAIN4;
-  // conv3 A tile t of a pass -> (hidden block, row tile); tiles of a group are ordered (hidden block, row tile)
-  static constexpr int G1D = G1N > 0 ? G1N : 1;
+  // output A tile t of a pass -> (hidden block, row tile); tiles of a group are ordered (hidden block, row tile)
   static constexpr int tile_fo(int t) { return t < NFH * G0N ? t / G0N : (t - NFH * G0N) / G1D; }
   static constexpr int tile_mt(int t) { return t < NFH * G0N ? t % G0N : G0N + (t - NFH * G0N) % G1D; }
 };
@@ -408,34 +412,50 @@ __device__ __forceinline__ void h3_wait_barrier() {
   h3_barrier();
 }
 
-#ifdef GLOWK_H3_STAMPS   // diagnostic build only: per-op cycle stamps, written to the (otherwise unused) mask1 buffer
-#define H3_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define H3_ACC(i, a, b) (c.dt[i] += (b) - (a))
-#else
-#define H3_STAMP(t) do { } while (0)
-#define H3_ACC(i, a, b) do { } while (0)
-#endif
-
-template <int CI, int NF>
 struct H3Ctx {                      // wave-uniform pointers of the kernel (LDS arrays are distinct statics: see ring_slot)
   float4 *sA, *sB, *sD, *k1s0, *k1s1;
   const float4 *k1img, *pass_img, *next_img;
+  const unsigned short* mkl;        // backward: LDS copy of the masks, [which][hidden block][512 threads]
+  size_t wblk;                      // 32-pixel column block of this wave
+  bool wok;                         // it holds at least one pixel
   int w4;
   unsigned voff;
-#ifdef GLOWK_H3_STAMPS
-  unsigned long long dt[8];
-#endif
 };
 
-// X: conv1 of one hidden block (operands in conv1 slot KP) + ReLU, as the split B fragments of conv2's two k-steps
-template <int CI, int NF, int KP>
-__device__ __forceinline__ void h3_X(const H3Ctx<CI, NF>& c, const h8 (&xh)[(RingH<CI, NF>::KS)], const h8 (&xl)[(RingH<CI, NF>::KS)],
-                                     float sc1, int lane, h8 (&bh)[2], h8 (&bl)[2]) {
-  using G = RingH<CI, NF>;
+// activation epilogue of 16 accumulator values: forward max(acc * sc, 0) (+ the ReLU decisions as bits), backward
+// acc * sc where the forward pass's ReLU was open
+template <int MODE>
+__device__ __forceinline__ unsigned h3_act(const f32x16& acc, float sc, unsigned mask, h8 (&bh)[2], h8 (&bl)[2]) {
+  unsigned bits = 0;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = 8 * s + j;
+      if (MODE == NET_BWD) v[j] = ((mask >> r) & 1u) ? acc[r] * sc : 0.0f;
+      else {
+        v[j] = fmaxf(acc[r] * sc, 0.0f);
+        if (MODE == NET_FWD_SAVE) bits |= (acc[r] > 0.0f ? 1u : 0u) << r;
+      }
+    }
+    split8(v, bh[s], bl[s]);
+  }
+  return bits;
+}
+
+// X: small convolution of one hidden block (operands in slot KP) + activation, as the split B fragments of the main
+// contraction's two k-steps
+template <int KIN, int MOUT, int NF, int MODE, int KP, int PASS>
+__device__ __forceinline__ void h3_X(const NetArgs& a, const H3Ctx& c, int fi, const h8 (&xh)[(RingH<KIN, MOUT, NF, MODE>::KS)],
+                                     const h8 (&xl)[(RingH<KIN, MOUT, NF, MODE>::KS)], int lane, h8 (&bh)[2], h8 (&bl)[2]) {
+  using G = RingH<KIN, MOUT, NF, MODE>;
   f32x16 h1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) h1[r] = 0.0f;
   const h8* k1 = reinterpret_cast<const h8*>(KP ? c.k1s1 : c.k1s0) + lane;   // [s][hi|lo][64]
+  unsigned mask = 0;
+  if (MODE == NET_BWD) mask = c.mkl[(size_t)(NF + fi) * 512 + threadIdx.x];  // mask2: the ReLU after conv2
   if constexpr (G::KS <= 3) {       // all operand reads in flight before the first MFMA
     h8 kf[2 * G::KS];
 #pragma unroll
@@ -447,29 +467,24 @@ __device__ __forceinline__ void h3_X(const H3Ctx<CI, NF>& c, const h8 (&xh)[(Rin
 #pragma unroll
     for (int s = 0; s < G::KS; ++s) h1 = mfma3(k1[(2 * s + 0) * 64], k1[(2 * s + 1) * 64], xh[s], xl[s], h1);
   }
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = fmaxf(h1[8 * s + j] * sc1, 0.0f);
-    split8(v, bh[s], bl[s]);
-  }
+  const unsigned bits = h3_act<MODE>(h1, a.sc1, mask, bh, bl);
+  if (MODE == NET_FWD_SAVE && PASS == 0 && c.wok) a.mask1[(c.wblk * NF + fi) * 64 + lane] = (unsigned short)bits;
 }
 
-// Y: conv2 contribution of one hidden block to this pass's NFH accumulator tiles (chunk in `slot`).  The wave is alone on
-// the matrix pipe during Y (its SIMD partner is in X), so two accumulator tiles are interleaved to keep dependent MFMAs
-// apart, and the DMA this wave owes (group 0: its NFH pieces of the next main chunk, group 1: its piece of the next-but-one
-// block's conv1 operands) is spread over the tile pairs instead of delaying the first MFMA.
-template <int CI, int NF, int TAG>
-__device__ __forceinline__ void h3_Y(const float4* slot, const h8 (&bh)[2], const h8 (&bl)[2], f32x16 (&acc2)[(RingH<CI, NF>::NFH)],
-                                     int lane, int g, const float4* main_src, float4* main_dst, const float4* k1_src, float4* k1_dst,
+// Y: main contraction's contribution of one hidden block to this pass's NFH accumulator tiles (chunk in `slot`).  The wave
+// is alone on the matrix pipe during Y (its SIMD partner is in X), so two accumulator tiles are interleaved to keep
+// dependent MFMAs apart, the A fragments of the next 6-MFMA group are read while the current one computes (hipcc alone
+// reads each fragment right before its MFMA and waits: ~1000 exposed cycles per Y), and the DMA this wave owes (group 0:
+// its NFH pieces of the next main chunk, group 1: its piece of the next-but-one block's small-conv operands) is spread over
+// the groups instead of delaying the first MFMA.
+template <int KIN, int MOUT, int NF, int MODE, int TAG>
+__device__ __forceinline__ void h3_Y(const float4* slot, const h8 (&bh)[2], const h8 (&bl)[2], f32x16 (&acc2)[NF / 2], int lane, int g,
+                                     bool main_ok, const float4* main_src, float4* main_dst, const float4* k1_src, float4* k1_dst,
                                      int w4, unsigned voff) {
-  using G = RingH<CI, NF>;
+  using G = RingH<KIN, MOUT, NF, MODE>;
   const h8* buf = reinterpret_cast<const h8*>(slot) + lane;
   const char* mb = uniform_ptr(main_src);
-  // groups of 6 MFMAs = (tile pair p, k-step s); the A fragments of group i+1 are read while group i computes (the
-  // compiler on its own reads each fragment right before its MFMA and waits for it: ~1000 exposed cycles per Y)
-  constexpr int NG = G::NFH;
+  constexpr int NG = G::NFH;        // groups of 6 MFMAs = (tile pair p, k-step s)
   h8 A[2][4];
   auto load = [&](h8 (&d)[4], int gi) {
     const int p = gi >> 1, s = gi & 1;
@@ -484,43 +499,43 @@ __device__ __forceinline__ void h3_Y(const float4* slot, const h8 (&bh)[2], cons
     const int p = gi >> 1, s = gi & 1, f0 = 2 * p, f1 = 2 * p + 1;
     if (gi + 1 < NG) load(A[(gi + 1) & 1], gi + 1);
     if (!g) {
-      const int piece = gi * 4 + w4;                  // NFH pieces per wave, one per group
-      glds16(reinterpret_cast<const float4*>(mb + (size_t)piece * 1024 + voff), main_dst + piece * 64);
+      if (main_ok) {
+        const int piece = gi * 4 + w4;                // NFH pieces per wave, one per group
+        glds16(reinterpret_cast<const float4*>(mb + (size_t)piece * 1024 + voff), main_dst + piece * 64);
+      }
       asm volatile("; dma site %0" ::"n"(TAG * 16 + gi));
     } else if (gi == 0) {
       stage4<G::K1P, TAG * 16 + 15>(k1_src, k1_dst, w4, voff);
     }
     __builtin_amdgcn_sched_barrier(0);
-    const h8 (&a)[4] = A[gi & 1];
-    acc2[f0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bh[s], acc2[f0], 0, 0, 0);
-    acc2[f1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[3], bh[s], acc2[f1], 0, 0, 0);
-    acc2[f0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bl[s], acc2[f0], 0, 0, 0);
-    acc2[f1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2], bl[s], acc2[f1], 0, 0, 0);
-    acc2[f0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bh[s], acc2[f0], 0, 0, 0);
-    acc2[f1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2], bh[s], acc2[f1], 0, 0, 0);
+    const h8 (&af)[4] = A[gi & 1];
+    acc2[f0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bh[s], acc2[f0], 0, 0, 0);
+    acc2[f1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[3], bh[s], acc2[f1], 0, 0, 0);
+    acc2[f0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bl[s], acc2[f0], 0, 0, 0);
+    acc2[f1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2], bl[s], acc2[f1], 0, 0, 0);
+    acc2[f0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bh[s], acc2[f0], 0, 0, 0);
+    acc2[f1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2], bh[s], acc2[f1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// Z: conv3 op z of a pass = half a chunk of A tiles.  ReLU + split of hidden block fo happens once per fused group of row
-// tiles; a row tile is stored when its last hidden block has been added.
-template <int CI, int NF, int P0, int PASS, int Z>
-__device__ __forceinline__ void h3_Z(const NetArgs& a, H3Ctx<CI, NF>& c, const float* epl, f32x16 (&acc2)[(RingH<CI, NF>::NFH)],
-                                     f32x16 (&acc3)[(RingH<CI, NF>::G0N)], h8 (&bh)[2], h8 (&bl)[2], int g, int q, bool qok, int lane, int hh) {
-  using G = RingH<CI, NF>;
+// Z: output op z of a pass = half a chunk of per-tap A tiles.  The activation + split of hidden block fo happens once per
+// fused group of row tiles; a row tile is stored when its last hidden block has been added.
+template <int KIN, int MOUT, int NF, int MODE, int P0, int PASS, int Z>
+__device__ __forceinline__ void h3_Z(const NetArgs& a, const H3Ctx& c, const float* epl, f32x16 (&acc2)[NF / 2],
+                                     f32x16 (&acc3)[(RingH<KIN, MOUT, NF, MODE>::G0N)], h8 (&bh)[2], h8 (&bl)[2], int g, int q, bool qok,
+                                     int lane, int hh) {
+  using G = RingH<KIN, MOUT, NF, MODE>;
   constexpr int NFH = G::NFH, M3 = G::M3;
-  unsigned long long z0 = 0, z1 = 0, z2 = 0;
-  (void)z0; (void)z1; (void)z2;
-  H3_STAMP(z0);
   constexpr int S = Z >> 1;
   constexpr int P0N = (G::NMT + 1 + P0) & 1;                       // main slot of the next pass's chunk 0
-  if (!g) {   // group 0 requests the later conv3 chunks (chunk 2 as soon as K2(NF-1) is dead, chunk s >= 3 when chunk s-2 is) ...
+  if (!g) {   // group 0 requests the later output chunks (chunk 2 as soon as the last main chunk is dead, chunk s >= 3 when chunk s-2 is) ...
     constexpr int SN = Z == 1 ? 2 : (Z >= 5 && (Z & 1)) ? (Z + 1) / 2 : 0;
     if constexpr (SN >= 2 && SN < G::NMT)
       stage4<G::MAINP, 16 + Z>(c.pass_img + (size_t)(NF + SN) * G::MAIN4, ((NF + SN - 1 + P0) & 1) ? c.sB : c.sA, c.w4, c.voff);
     if constexpr (PASS == 0 && Z == 2 * G::NMT - 1) {               // ... and, in its last op, the next pass's first chunks
       stage4<G::MAINP, 48>(c.next_img, P0N ? c.sB : c.sA, c.w4, c.voff);
-      stage4<G::MAINP, 49>(c.next_img + (size_t)NF * G::MAIN4, c.sD, c.w4, c.voff);
+      if constexpr (G::NMT >= 2) stage4<G::MAINP, 49>(c.next_img + (size_t)NF * G::MAIN4, c.sD, c.w4, c.voff);   // (NMT = 1: slot D still read; see h3_pass)
     }
   }
   const float4* slot = S == 0 ? c.sD : (((NF + S - 1 + P0) & 1) ? c.sB : c.sA);
@@ -532,15 +547,13 @@ __device__ __forceinline__ void h3_Z(const NetArgs& a, H3Ctx<CI, NF>& c, const f
     const int tp = (Z & 1) * (NFH / 2) + i;            // tile position in the chunk
     const int t = S * NFH + tp;
     const int fo = G::tile_fo(t), mt = G::tile_mt(t);
-    const int ml = t >= NFH * G::G0N ? mt - G::G0N : mt;   // this row tile's accumulator within its group
+    const bool first_group = t < NFH * G::G0N;
+    const int ml = first_group ? mt : mt - G::G0N;     // this row tile's accumulator within its group
     if (ml == 0) {
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc2[fo][8 * s2 + j] * a.sc2, 0.0f);
-        split8(v, bh[s2], bl[s2]);
-      }
+      unsigned mask = 0;
+      if (MODE == NET_BWD) mask = c.mkl[(size_t)(PASS * NFH + fo) * 512 + threadIdx.x];   // mask1: the ReLU after conv1
+      const unsigned bits = h3_act<MODE>(acc2[fo], a.sc2, mask, bh, bl);
+      if (MODE == NET_FWD_SAVE && first_group && c.wok) a.mask2[(c.wblk * NF + PASS * NFH + fo) * 64 + lane] = (unsigned short)bits;
     }
     if (fo == 0) {
 #pragma unroll
@@ -552,89 +565,66 @@ __device__ __forceinline__ void h3_Z(const NetArgs& a, H3Ctx<CI, NF>& c, const f
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mt * 32 + mfma_row(r, hh);
-        if (m < M3 && qok) Pp[(size_t)m * a.Q + q] = PASS == 0 ? fmaf(acc3[ml][r], a.sc3, pb[m]) : acc3[ml][r] * a.sc3;
+        if (m < M3 && qok) Pp[(size_t)m * a.Q + q] = (PASS == 0 && MODE != NET_BWD) ? fmaf(acc3[ml][r], a.sc3, pb[m]) : acc3[ml][r] * a.sc3;
       }
     }
   }
-  H3_STAMP(z1);
   h3_wait_barrier();
-  H3_STAMP(z2);
-  H3_ACC(4, z0, z1); H3_ACC(5, z1, z2);
 }
 
-template <int CI, int NF, int P0, int PASS, int... Z>
-__device__ __forceinline__ void h3_tail(const NetArgs& a, H3Ctx<CI, NF>& c, const float* epl, f32x16 (&acc2)[(RingH<CI, NF>::NFH)],
-                                        f32x16 (&acc3)[(RingH<CI, NF>::G0N)], h8 (&bh)[2], h8 (&bl)[2], int g, int q, bool qok, int lane, int hh,
-                                        std::integer_sequence<int, Z...>) {
-  (h3_Z<CI, NF, P0, PASS, Z>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, hh), ...);
+template <int KIN, int MOUT, int NF, int MODE, int P0, int PASS, int... Z>
+__device__ __forceinline__ void h3_tail(const NetArgs& a, const H3Ctx& c, const float* epl, f32x16 (&acc2)[NF / 2],
+                                        f32x16 (&acc3)[(RingH<KIN, MOUT, NF, MODE>::G0N)], h8 (&bh)[2], h8 (&bl)[2], int g, int q, bool qok,
+                                        int lane, int hh, std::integer_sequence<int, Z...>) {
+  (h3_Z<KIN, MOUT, NF, MODE, P0, PASS, Z>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, hh), ...);
 }
 
 // one pass (hidden half PASS) of the workgroup's 256 pixels.  g = this wave's group: its ops run in phase (op index + g).
-template <int CI, int NF, int P0, int PASS>
-__device__ __forceinline__ void h3_pass(const NetArgs& a, H3Ctx<CI, NF>& c, const float* epl,
-                                        const h8 (&xh)[(RingH<CI, NF>::KS)], const h8 (&xl)[(RingH<CI, NF>::KS)],
+template <int KIN, int MOUT, int NF, int MODE, int P0, int PASS>
+__device__ __forceinline__ void h3_pass(const NetArgs& a, const H3Ctx& c, const float* epl,
+                                        const h8 (&xh)[(RingH<KIN, MOUT, NF, MODE>::KS)], const h8 (&xl)[(RingH<KIN, MOUT, NF, MODE>::KS)],
                                         int g, int q, bool qok, int lane, int hh) {
-  using G = RingH<CI, NF>;
-  constexpr int NFH = G::NFH, NMT = G::NMT, M3 = G::M3;
+  using G = RingH<KIN, MOUT, NF, MODE>;
+  constexpr int NFH = G::NFH, NMT = G::NMT;
   constexpr int f2base = PASS * NFH * 32;
   f32x16 acc2[NFH];
 #pragma unroll
   for (int fo = 0; fo < NFH; ++fo)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[fo][r] = epl[f2base + fo * 32 + mfma_row(r, hh)];   // conv2 bias (scaled)
+    for (int r = 0; r < 16; ++r) acc2[fo][r] = MODE == NET_BWD ? 0.0f : epl[f2base + fo * 32 + mfma_row(r, hh)];   // conv2 bias (scaled)
 
   h8 bh[2], bl[2];
 #pragma nounroll
   for (int i0 = 0; i0 < NF; i0 += 2) {
-    // X_i0 | Y_i0 | X_i0+1 | Y_i0+1.  During its Y ops group 0 requests the next main chunk (K2(i+1), after the last K2 the
-    // second conv3 chunk) into the other main slot, group 1 the conv1 operands of block i+2 (wrapping into the next pass)
+    // X_i0 | Y_i0 | X_i0+1 | Y_i0+1.  During its Y ops group 0 requests the next main chunk (after the last one the second
+    // output chunk) into the other main slot, group 1 the small-conv operands of block i+2 (wrapping into the next pass)
     // into the slot its X_i has just finished with.
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-    (void)t0; (void)t1; (void)t2; (void)t3; (void)t4;
-    H3_STAMP(t0);
-    h3_X<CI, NF, 0>(c, xh, xl, a.sc1, lane, bh, bl);
-    asm volatile("" : "+v"(bh[0]), "+v"(bh[1]), "+v"(bl[0]), "+v"(bl[1]));
-    H3_STAMP(t1);
+    h3_X<KIN, MOUT, NF, MODE, 0, PASS>(a, c, i0, xh, xl, lane, bh, bl);
     h3_wait_barrier();
-    H3_STAMP(t2);
-    h3_Y<CI, NF, 1>(P0 ? c.sB : c.sA, bh, bl, acc2, lane, g, c.pass_img + (size_t)(i0 + 1) * G::MAIN4, P0 ? c.sA : c.sB,
-                    c.k1img + (size_t)((i0 + 2) % NF) * G::K14, c.k1s0, c.w4, c.voff);
-#ifdef GLOWK_H3_STAMPS
-#pragma unroll
-    for (int fo = 0; fo < NFH; ++fo) asm volatile("" : "+v"(acc2[fo]));
-#endif
-    H3_STAMP(t3);
+    if (PASS == 1 && NMT == 1 && i0 == 0 && !g)   // single output chunk: slot D of pass 0 is read until the phase before this one
+      stage4<G::MAINP, 50>(c.pass_img + (size_t)NF * G::MAIN4, c.sD, c.w4, c.voff);
+    h3_Y<KIN, MOUT, NF, MODE, 1>(P0 ? c.sB : c.sA, bh, bl, acc2, lane, g, true, c.pass_img + (size_t)(i0 + 1) * G::MAIN4, P0 ? c.sA : c.sB,
+                                 c.k1img + (size_t)((i0 + 2) % NF) * G::K14, c.k1s0, c.w4, c.voff);
     h3_barrier();
-    H3_STAMP(t4);
-    H3_ACC(0, t0, t1); H3_ACC(1, t1, t2); H3_ACC(2, t2, t3); H3_ACC(3, t3, t4);
-    H3_STAMP(t0);
-    h3_X<CI, NF, 1>(c, xh, xl, a.sc1, lane, bh, bl);
-    asm volatile("" : "+v"(bh[0]), "+v"(bh[1]), "+v"(bl[0]), "+v"(bl[1]));
-    H3_STAMP(t1);
+    h3_X<KIN, MOUT, NF, MODE, 1, PASS>(a, c, i0 + 1, xh, xl, lane, bh, bl);
     h3_wait_barrier();
-    H3_STAMP(t2);
-    h3_Y<CI, NF, 2>(P0 ? c.sA : c.sB, bh, bl, acc2, lane, g, c.pass_img + (size_t)(i0 + 2 < NF ? i0 + 2 : NF + 1) * G::MAIN4,
-                    P0 ? c.sB : c.sA, c.k1img + (size_t)((i0 + 3) % NF) * G::K14, c.k1s1, c.w4, c.voff);
-#ifdef GLOWK_H3_STAMPS
-#pragma unroll
-    for (int fo = 0; fo < NFH; ++fo) asm volatile("" : "+v"(acc2[fo]));
-#endif
-    H3_STAMP(t3);
+    h3_Y<KIN, MOUT, NF, MODE, 2>(P0 ? c.sA : c.sB, bh, bl, acc2, lane, g, i0 + 2 < NF || NMT >= 2,
+                                 c.pass_img + (size_t)(i0 + 2 < NF ? i0 + 2 : NF + 1) * G::MAIN4, P0 ? c.sB : c.sA,
+                                 c.k1img + (size_t)((i0 + 3) % NF) * G::K14, c.k1s1, c.w4, c.voff);
     h3_barrier();
-    H3_STAMP(t4);
-    H3_ACC(0, t0, t1); H3_ACC(1, t1, t2); H3_ACC(2, t2, t3); H3_ACC(3, t3, t4);
   }
 
-  // conv3: per-tap 1x1 partial sums of this pass's hidden half (k_couple adds the two passes)
+  // the 3x3 output convolution as per-tap 1x1 partial sums over this pass's hidden half (the consumer adds the two passes)
   f32x16 acc3[G::G0N];
-  h3_tail<CI, NF, P0, PASS>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, hh, std::make_integer_sequence<int, 2 * NMT>());
+  h3_tail<KIN, MOUT, NF, MODE, P0, PASS>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, hh, std::make_integer_sequence<int, 2 * NMT>());
 }
 
-template <int CI, int NF>
+template <int KIN, int MOUT, int NF, int MODE>
 __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
-  using G = RingH<CI, NF>;
+  using G = RingH<KIN, MOUT, NF, MODE>;
   constexpr int K1 = G::K1;
   constexpr int KS = G::KS;
+  constexpr int SGN = (MODE == NET_BWD) ? -1 : 1;   // backward gathers at q - d(tap)
   static_assert(G::FITS, "shape");
 
   __shared__ float4 slotA[G::MAIN4];
@@ -643,6 +633,7 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
   __shared__ float4 k1slot0[G::K14];
   __shared__ float4 k1slot1[G::K14];
   __shared__ float epl[G::EPN];
+  __shared__ unsigned short mkl[G::MASK2B / 2 + 2];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -653,11 +644,14 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
   const int q = (blockIdx.x * 8 + (tid >> 6)) * 32 + pix;
   const bool qok = q < a.Q;
 
-  H3Ctx<CI, NF> c;
+  H3Ctx c;
   c.sA = slotA; c.sB = slotB; c.sD = slotD; c.k1s0 = k1slot0; c.k1s1 = k1slot1;
   c.k1img = a.RHp;
   c.pass_img = a.RHp + G::K1TOT4;
   c.next_img = a.RHp + G::K1TOT4 + G::PASS4;
+  c.mkl = mkl;
+  c.wblk = (size_t)blockIdx.x * 8 + wave;
+  c.wok = (long)c.wblk * 32 < a.Q;
   c.w4 = wave & 3;
   c.voff = (unsigned)lane * 16u;
 
@@ -675,47 +669,41 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int k = 16 * s + 8 * hh + j;
-        const int tap = k / CI, cin = k % CI;
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int tap = k / KIN, cin = k % KIN;
+        const int dy = SGN * (tap / 3 - 1), dx = SGN * (tap % 3 - 1);
         const int ii = i + dy, jj = j0 + dx;
         const bool ok = qok && k < K1 && ii >= 0 && ii < a.h && jj >= 0 && jj < a.w;
         const int off = ok ? ((dy * a.w + dx) * a.in_stride + cin) : 0;
         const float x = base[off];
-        v[j] = ok ? x * GLOWK_ACT_SCALE : (k == K1 ? GLOWK_ACT_SCALE : 0.0f);   // row K1: the constant that carries conv1's bias
+        v[j] = ok ? x * GLOWK_ACT_SCALE : ((MODE != NET_BWD && k == K1) ? GLOWK_ACT_SCALE : 0.0f);   // forward, row K1: carries conv1's bias
       }
       split8(v, xh[s], xl[s]);
     }
   }
-  for (int i = tid; i < G::EPN; i += 512) epl[i] = a.eph[i];
+  if (MODE == NET_BWD) {   // the forward pass's ReLU decisions of this workgroup's column blocks: [mask1 | mask2][block][thread]
+    for (int f = 0; f < NF; ++f) {
+      mkl[(size_t)f * 512 + tid] = c.wok ? a.mask1[(c.wblk * NF + f) * 64 + lane] : (unsigned short)0;
+      mkl[(size_t)(NF + f) * 512 + tid] = c.wok ? a.mask2[(c.wblk * NF + f) * 64 + lane] : (unsigned short)0;
+    }
+  } else {
+    for (int i = tid; i < G::EPN; i += 512) epl[i] = a.eph[i];
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // gathers done before any DMA is issued
   if (!g) {
-    stage4<G::MAINP, 60>(c.pass_img, slotA, c.w4, c.voff);                                // K2 chunk 0
-    stage4<G::MAINP, 61>(c.pass_img + (size_t)NF * G::MAIN4, slotD, c.w4, c.voff);        // first conv3 chunk
+    stage4<G::MAINP, 60>(c.pass_img, slotA, c.w4, c.voff);                                // main chunk 0
+    stage4<G::MAINP, 61>(c.pass_img + (size_t)NF * G::MAIN4, slotD, c.w4, c.voff);        // first output chunk
   } else {
-    stage4<G::K1P, 62>(c.k1img, k1slot0, c.w4, c.voff);                                   // conv1 operands of blocks 0, 1
+    stage4<G::K1P, 62>(c.k1img, k1slot0, c.w4, c.voff);                                   // small-conv operands of blocks 0, 1
     stage4<G::K1P, 63>(c.k1img + G::K14, k1slot1, c.w4, c.voff);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();                                         // epl and the first chunks visible to every wave
+  __syncthreads();                                         // constants and the first chunks visible to every wave
 
-#ifdef GLOWK_H3_STAMPS
-  for (int i = 0; i < 8; ++i) c.dt[i] = 0;
-  unsigned long long k0, k1, rr0, rr1;
-  k0 = __builtin_amdgcn_s_memtime(); rr0 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F);
-#endif
   if (g) h3_barrier();                                     // group 1 runs one phase behind group 0
-  h3_pass<CI, NF, 0, 0>(a, c, epl, xh, xl, g, q, qok, lane, hh);
+  h3_pass<KIN, MOUT, NF, MODE, 0, 0>(a, c, epl, xh, xl, g, q, qok, lane, hh);
   c.pass_img = c.next_img;
-  h3_pass<CI, NF, (G::NMT + 1) & 1, 1>(a, c, epl, xh, xl, g, q, qok, lane, hh);
+  h3_pass<KIN, MOUT, NF, MODE, (G::NMT + 1) & 1, 1>(a, c, epl, xh, xl, g, q, qok, lane, hh);
   if (!g) h3_barrier();                                    // group 0 idles through the last phase
-#ifdef GLOWK_H3_STAMPS
-  k1 = __builtin_amdgcn_s_memtime(); rr1 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F);
-  if (lane == 0 && a.mask1) {
-    unsigned long long* d = reinterpret_cast<unsigned long long*>(a.mask1) + (size_t)(blockIdx.x * 8 + wave) * 8;
-    d[0] = k1 - k0; d[1] = rr1 - rr0;
-    for (int i = 0; i < 6; ++i) d[2 + i] = c.dt[i];
-  }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1076,6 +1064,7 @@ struct BwdArgs {
   //     direct: g_v = gv_direct[q*gvd_stride + gvd_off + .]             (Pg == null)
   const float* ghalf_in;
   const float* Pg;
+  const float* Pg2;        // second partial of Pg (two-pass f16x3 backward kernel), or null
   const float* gv_direct;
   int gvd_stride, gvd_off;
   // (2) through step s's fused ActNorm + 1x1: g_y = g_v . A^T (null: g_y = g_v)
@@ -1083,6 +1072,7 @@ struct BwdArgs {
   // (3) coupling backward of the step that produced y (forward order: the step before s), or none (v == null)
   const float* v;          // [Q][C] saved coupling input
   const float* P;          // [9C][Q] saved per-tap conv3 outputs
+  const float* P2;         // their second partial (two-pass f16x3 forward kernel), or null
   const float* b3;
   float* g_o;              // [Q][C] gradient wrt the network output o = [pre-tanh log_s, t]
   float* ghalf_out;        // [Q][C] [g_va, g_yb]
@@ -1107,9 +1097,9 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
         const int ii = i - dy, jj = j - dx;   // Pg[q'] contributes at q' + d(tap)
         if (ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) {
-          const float* src = a.Pg + (size_t)(tap * CI) * a.Q + (q - dy * a.w - dx);
+          const size_t po = (size_t)(tap * CI) * a.Q + (q - dy * a.w - dx);
 #pragma unroll
-          for (int c = 0; c < CI; ++c) gv[CI + c] += src[(size_t)c * a.Q];
+          for (int c = 0; c < CI; ++c) gv[CI + c] += a.Pg[po + (size_t)c * a.Q] + (a.Pg2 ? a.Pg2[po + (size_t)c * a.Q] : 0.0f);
         }
       }
     } else {
@@ -1138,9 +1128,9 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
         const int ii = i + dy, jj = j + dx;
         if (ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) {
-          const float* src = a.P + (size_t)(tap * C) * a.Q + (q + dy * a.w + dx);
+          const size_t po = (size_t)(tap * C) * a.Q + (q + dy * a.w + dx);
 #pragma unroll
-          for (int c = 0; c < CI; ++c) o[c] += src[(size_t)c * a.Q];
+          for (int c = 0; c < CI; ++c) o[c] += a.P[po + (size_t)c * a.Q] + (a.P2 ? a.P2[po + (size_t)c * a.Q] : 0.0f);
         }
       }
       float* go = a.g_o + (size_t)q * C;

@@ -96,6 +96,9 @@ class GlowEngine:
     def set_precision(self, mode):
         _lib.check(self.lib.glowk_set_precision(self.h, int(mode)))
 
+    def get_precision(self):
+        return int(self.lib.glowk_get_precision(self.h))
+
     def reserve(self, n):
         _lib.check(self.lib.glowk_reserve(self.h, int(n)))
 

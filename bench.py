@@ -96,6 +96,7 @@ def secondary_workload(args, cfg, eng, params, rank, world, local_rank, dist):
         unit, metric, per_step = "tiles/s", "Glow log_prob + input-gradient tiles/sec", n
     else:
         eng2, _ = calibrated_engine(cfg, device=local_rank, init_tiles=max(n, 64), seed=4048)
+        eng2.set_precision(eng.get_precision())
         m1, m2 = GlowFlow(eng), GlowFlow(eng2)
         x2 = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=4321 + rank)).cuda()
         mixed = basis.mixing_db(x, x2)
@@ -125,7 +126,7 @@ def secondary_workload(args, cfg, eng, params, rank, world, local_rank, dist):
         print(json.dumps({
             "metric": metric, "value": per_step * world * args.steps / elapsed, "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "%s, %dx%dx%d tiles, L=%d K=%d n_filters=%d, %d tiles/GPU" % (args.workload, cfg.H, cfg.W, cfg.C, cfg.L, cfg.K, cfg.F, n)},
         }), flush=True)
     if dist is not None:

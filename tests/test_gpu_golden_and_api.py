@@ -155,3 +155,23 @@ def test_input_gradient_autograd_contract():
     (flow.log_prob(xt2) * w).sum().backward()
     np.testing.assert_allclose(xt2.grad.cpu().numpy(), g_ref * np.arange(1, 6).reshape(-1, 1, 1, 1),
                                atol=1e-3 * np.abs(g_ref).max(), rtol=2e-3)
+
+
+def test_input_gradient_in_f16x3_arithmetic():
+    """glowk_log_prob_grad with the fp16x3 kernels (forward with saves and backward network; the c = 16 level's backward
+    falls back to exact fp32) against the fp64 autograd of the oracle and against the exact-fp32 kernels."""
+    from audiosourcesep_amd import _lib
+    from audiosourcesep_amd.synthetic import calibrated_engine
+    from oracle import glowref_torch as RT
+    cfg = GlowConfig(H=16, W=16, C=1, L=3, K=4, F=128)
+    eng, params = calibrated_engine(cfg, device=0, init_tiles=16)
+    x = synthetic_mel_tiles(21, cfg, seed=9)                 # ragged: 21 tiles -> partial workgroups at every level
+    lp32, g32 = eng.log_prob_grad(dev(x))
+    eng.set_precision(_lib.PREC_F16X3)
+    lp16, g16 = eng.log_prob_grad(dev(x))
+    assert torch.equal(lp16, eng.log_prob(dev(x)))           # the saving forward pass computes the plain one's bits
+    lp_ref, g_ref = RT.log_prob_and_grad(x.astype(np.float64), params, cfg.as_dict())
+    scale = np.abs(g_ref).max()
+    np.testing.assert_allclose(lp16.cpu().numpy(), lp_ref, rtol=1e-6)
+    np.testing.assert_allclose(g16.cpu().numpy(), g_ref, atol=2e-4 * scale, rtol=2e-3)
+    np.testing.assert_allclose(g16.cpu().numpy(), g32.cpu().numpy(), atol=5e-5 * scale, rtol=1e-3)
