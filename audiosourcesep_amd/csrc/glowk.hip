@@ -514,6 +514,22 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
 }
 
 // ---- launch helpers ------------------------------------------------------------------------------
+int g_num_cus = 0;   // compute units of the current device (queried once)
+
+// k_net_h3: one workgroup per 256 pixels running both hidden halves, or -- when that leaves at least half of the CUs
+// without a workgroup -- one workgroup per (256 pixels, hidden half): half the latency per launch
+template <int KIN, int MOUT, int NF, int MODE>
+void launch_h3(const NetArgs& a, hipStream_t s) {
+  if (g_num_cus == 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
+    if (g_num_cus <= 0) g_num_cus = 256;
+  }
+  const int wgs = (a.Q + 255) / 256;
+  if (2 * wgs <= g_num_cus) hipLaunchKernelGGL((k_net_h3<KIN, MOUT, NF, MODE, true>), dim3(wgs, 2), dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((k_net_h3<KIN, MOUT, NF, MODE, false>), dim3(wgs), dim3(512), 0, s, a);
+}
+
 template <int CI, int NF>
 int launch_net_t(const NetArgs& a, int mode, hipStream_t s) {
   const int ntiles = (a.Q + 127) / 128;
@@ -523,19 +539,19 @@ int launch_net_t(const NetArgs& a, int mode, hipStream_t s) {
     case NET_BWD:      hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD>), dim3(ntiles), dim3(256), 0, s, a); break;
     case 3:   // f16x3 arithmetic: forward / forward with saves / backward; shapes without an instance run the exact fp32 kernel
       if constexpr (RingH<CI, 18 * CI, NF, NET_FWD>::FITS) {
-        if (a.RHp) { hipLaunchKernelGGL((k_net_h3<CI, 18 * CI, NF, NET_FWD>), dim3((a.Q + 255) / 256), dim3(512), 0, s, a); break; }
+        if (a.RHp) { launch_h3<CI, 18 * CI, NF, NET_FWD>(a, s); break; }
       }
       hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a);
       break;
     case 4:
       if constexpr (RingH<CI, 18 * CI, NF, NET_FWD_SAVE>::FITS) {
-        if (a.RHp) { hipLaunchKernelGGL((k_net_h3<CI, 18 * CI, NF, NET_FWD_SAVE>), dim3((a.Q + 255) / 256), dim3(512), 0, s, a); break; }
+        if (a.RHp) { launch_h3<CI, 18 * CI, NF, NET_FWD_SAVE>(a, s); break; }
       }
       hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE>), dim3(ntiles), dim3(256), 0, s, a);
       break;
     case 5:
       if constexpr (RingH<2 * CI, 9 * CI, NF, NET_BWD>::FITS) {
-        if (a.RHp) { hipLaunchKernelGGL((k_net_h3<2 * CI, 9 * CI, NF, NET_BWD>), dim3((a.Q + 255) / 256), dim3(512), 0, s, a); break; }
+        if (a.RHp) { launch_h3<2 * CI, 9 * CI, NF, NET_BWD>(a, s); break; }
       }
       hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD>), dim3(ntiles), dim3(256), 0, s, a);
       break;

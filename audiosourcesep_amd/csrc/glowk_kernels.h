@@ -521,7 +521,7 @@ __device__ __forceinline__ void h3_Y(const float4* slot, const h8 (&bh)[2], cons
 
 // Z: output op z of a pass = half a chunk of per-tap A tiles.  The activation + split of hidden block fo happens once per
 // fused group of row tiles; a row tile is stored when its last hidden block has been added.
-template <int KIN, int MOUT, int NF, int MODE, int P0, int PASS, int Z>
+template <int KIN, int MOUT, int NF, int MODE, int P0, int PASS, bool SOLO, int Z>
 __device__ __forceinline__ void h3_Z(const NetArgs& a, const H3Ctx& c, const float* epl, f32x16 (&acc2)[NF / 2],
                                      f32x16 (&acc3)[(RingH<KIN, MOUT, NF, MODE>::G0N)], h8 (&bh)[2], h8 (&bl)[2], int g, int q, bool qok,
                                      int lane, int hh) {
@@ -533,7 +533,7 @@ __device__ __forceinline__ void h3_Z(const NetArgs& a, const H3Ctx& c, const flo
     constexpr int SN = Z == 1 ? 2 : (Z >= 5 && (Z & 1)) ? (Z + 1) / 2 : 0;
     if constexpr (SN >= 2 && SN < G::NMT)
       stage4<G::MAINP, 16 + Z>(c.pass_img + (size_t)(NF + SN) * G::MAIN4, ((NF + SN - 1 + P0) & 1) ? c.sB : c.sA, c.w4, c.voff);
-    if constexpr (PASS == 0 && Z == 2 * G::NMT - 1) {               // ... and, in its last op, the next pass's first chunks
+    if constexpr (PASS == 0 && !SOLO && Z == 2 * G::NMT - 1) {      // ... and, in its last op, the next pass's first chunks
       stage4<G::MAINP, 48>(c.next_img, P0N ? c.sB : c.sA, c.w4, c.voff);
       if constexpr (G::NMT >= 2) stage4<G::MAINP, 49>(c.next_img + (size_t)NF * G::MAIN4, c.sD, c.w4, c.voff);   // (NMT = 1: slot D still read; see h3_pass)
     }
@@ -572,15 +572,16 @@ __device__ __forceinline__ void h3_Z(const NetArgs& a, const H3Ctx& c, const flo
   h3_wait_barrier();
 }
 
-template <int KIN, int MOUT, int NF, int MODE, int P0, int PASS, int... Z>
+template <int KIN, int MOUT, int NF, int MODE, int P0, int PASS, bool SOLO, int... Z>
 __device__ __forceinline__ void h3_tail(const NetArgs& a, const H3Ctx& c, const float* epl, f32x16 (&acc2)[NF / 2],
                                         f32x16 (&acc3)[(RingH<KIN, MOUT, NF, MODE>::G0N)], h8 (&bh)[2], h8 (&bl)[2], int g, int q, bool qok,
                                         int lane, int hh, std::integer_sequence<int, Z...>) {
-  (h3_Z<KIN, MOUT, NF, MODE, P0, PASS, Z>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, hh), ...);
+  (h3_Z<KIN, MOUT, NF, MODE, P0, PASS, SOLO, Z>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, hh), ...);
 }
 
 // one pass (hidden half PASS) of the workgroup's 256 pixels.  g = this wave's group: its ops run in phase (op index + g).
-template <int KIN, int MOUT, int NF, int MODE, int P0, int PASS>
+// SOLO: the workgroup runs this pass only (the other half belongs to another workgroup).
+template <int KIN, int MOUT, int NF, int MODE, int P0, int PASS, bool SOLO>
 __device__ __forceinline__ void h3_pass(const NetArgs& a, const H3Ctx& c, const float* epl,
                                         const h8 (&xh)[(RingH<KIN, MOUT, NF, MODE>::KS)], const h8 (&xl)[(RingH<KIN, MOUT, NF, MODE>::KS)],
                                         int g, int q, bool qok, int lane, int hh) {
@@ -601,7 +602,7 @@ __device__ __forceinline__ void h3_pass(const NetArgs& a, const H3Ctx& c, const 
     // into the slot its X_i has just finished with.
     h3_X<KIN, MOUT, NF, MODE, 0, PASS>(a, c, i0, xh, xl, lane, bh, bl);
     h3_wait_barrier();
-    if (PASS == 1 && NMT == 1 && i0 == 0 && !g)   // single output chunk: slot D of pass 0 is read until the phase before this one
+    if (PASS == 1 && !SOLO && NMT == 1 && i0 == 0 && !g)   // single output chunk: slot D of pass 0 is read until the phase before this one
       stage4<G::MAINP, 50>(c.pass_img + (size_t)NF * G::MAIN4, c.sD, c.w4, c.voff);
     h3_Y<KIN, MOUT, NF, MODE, 1>(P0 ? c.sB : c.sA, bh, bl, acc2, lane, g, true, c.pass_img + (size_t)(i0 + 1) * G::MAIN4, P0 ? c.sA : c.sB,
                                  c.k1img + (size_t)((i0 + 2) % NF) * G::K14, c.k1s0, c.w4, c.voff);
@@ -616,10 +617,11 @@ __device__ __forceinline__ void h3_pass(const NetArgs& a, const H3Ctx& c, const 
 
   // the 3x3 output convolution as per-tap 1x1 partial sums over this pass's hidden half (the consumer adds the two passes)
   f32x16 acc3[G::G0N];
-  h3_tail<KIN, MOUT, NF, MODE, P0, PASS>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, hh, std::make_integer_sequence<int, 2 * NMT>());
+  h3_tail<KIN, MOUT, NF, MODE, P0, PASS, SOLO>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, hh, std::make_integer_sequence<int, 2 * NMT>());
 }
 
-template <int KIN, int MOUT, int NF, int MODE>
+// SPLIT: grid.y = 2 and each workgroup runs ONE pass (small grids: half the latency per launch on twice the workgroups)
+template <int KIN, int MOUT, int NF, int MODE, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
   using G = RingH<KIN, MOUT, NF, MODE>;
   constexpr int K1 = G::K1;
@@ -647,7 +649,8 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
   H3Ctx c;
   c.sA = slotA; c.sB = slotB; c.sD = slotD; c.k1s0 = k1slot0; c.k1s1 = k1slot1;
   c.k1img = a.RHp;
-  c.pass_img = a.RHp + G::K1TOT4;
+  const int solo_pass = SPLIT ? (int)blockIdx.y : 0;
+  c.pass_img = a.RHp + G::K1TOT4 + (size_t)solo_pass * G::PASS4;
   c.next_img = a.RHp + G::K1TOT4 + G::PASS4;
   c.mkl = mkl;
   c.wblk = (size_t)blockIdx.x * 8 + wave;
@@ -700,9 +703,14 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
   __syncthreads();                                         // constants and the first chunks visible to every wave
 
   if (g) h3_barrier();                                     // group 1 runs one phase behind group 0
-  h3_pass<KIN, MOUT, NF, MODE, 0, 0>(a, c, epl, xh, xl, g, q, qok, lane, hh);
-  c.pass_img = c.next_img;
-  h3_pass<KIN, MOUT, NF, MODE, (G::NMT + 1) & 1, 1>(a, c, epl, xh, xl, g, q, qok, lane, hh);
+  if constexpr (SPLIT) {
+    if (solo_pass == 0) h3_pass<KIN, MOUT, NF, MODE, 0, 0, true>(a, c, epl, xh, xl, g, q, qok, lane, hh);
+    else h3_pass<KIN, MOUT, NF, MODE, 0, 1, true>(a, c, epl, xh, xl, g, q, qok, lane, hh);
+  } else {
+    h3_pass<KIN, MOUT, NF, MODE, 0, 0, false>(a, c, epl, xh, xl, g, q, qok, lane, hh);
+    c.pass_img = c.next_img;
+    h3_pass<KIN, MOUT, NF, MODE, (G::NMT + 1) & 1, 1, false>(a, c, epl, xh, xl, g, q, qok, lane, hh);
+  }
   if (!g) h3_barrier();                                    // group 0 idles through the last phase
 }
 

@@ -175,3 +175,11 @@ def test_input_gradient_in_f16x3_arithmetic():
     np.testing.assert_allclose(lp16.cpu().numpy(), lp_ref, rtol=1e-6)
     np.testing.assert_allclose(g16.cpu().numpy(), g_ref, atol=2e-4 * scale, rtol=2e-3)
     np.testing.assert_allclose(g16.cpu().numpy(), g32.cpu().numpy(), atol=5e-5 * scale, rtol=1e-3)
+    # a batch large enough for the one-workgroup-per-256-pixels launch at level 0 (small grids launch one workgroup per
+    # hidden half): the two launch shapes must agree with the exact-fp32 kernels alike
+    xl = dev(synthetic_mel_tiles(640, cfg, seed=10))
+    lpl16, gl16 = eng.log_prob_grad(xl)
+    eng.set_precision(_lib.PREC_F32)
+    lpl32, gl32 = eng.log_prob_grad(xl)
+    np.testing.assert_allclose(lpl16.cpu().numpy(), lpl32.cpu().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(gl16.cpu().numpy(), gl32.cpu().numpy(), atol=2e-4 * float(gl32.abs().max()), rtol=2e-3)   # the bar vs fp64
