@@ -34,8 +34,6 @@ int fail(const std::string& m) {
 struct StepDev {            // device pointers into the arena
   const float* K1p = nullptr;
   const float* ep = nullptr;
-  const float4* K2p = nullptr;
-  const float4* K3p = nullptr;
   const float4* R0p = nullptr;
   const float4* RHp = nullptr;   // f16x3 ring image (null: shape not supported by k_net_h3)
   const float* epH = nullptr;    // its epilogue constants
@@ -150,7 +148,7 @@ inline int rho(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 inline size_t pad4(size_t n) { return (n + 3) & ~size_t(3); }
 
 struct StepLayout {
-  size_t K1p, ep, K2p, K3p, R0p, K3bp, RBp, RHp, epH, RHBp, Afwd, bfwd, Ainv, binv, b3, total;
+  size_t K1p, ep, R0p, K3bp, RBp, RHp, epH, RHBp, Afwd, bfwd, Ainv, binv, b3, total;
   size_t slotH;        // floats per main chunk of the f16x3 image (0: shape not supported by k_net_h3)
   size_t slotHB;       // the same for the backward network's image
   size_t slotB, k3fB;  // backward ring image: floats per slot; floats of its conv3^T-operand part (0: not in the ring)
@@ -163,8 +161,6 @@ StepLayout step_layout(int c, int F) {
   size_t o = 0;
   L.K1p = o; o += pad4((size_t)NF * KS1 * 64);
   L.ep = o; o += pad4((size_t)6 * F);
-  L.K2p = o; o += (size_t)NF * NF * 1024;
-  L.K3p = o; o += (size_t)NMT * NF * 1024;
   {
     size_t k1f = (size_t)(((size_t)KS1 * 256 + 1023) / 1024) * 256;                 // conv1 MFMA operands [KS1][64], 1-KiB pieces
     if (2 * ((size_t)NF * 1024 + k1f) * 4 + (size_t)6 * F * 4 > 160 * 1024) k1f = 0;  // Ring1::K1_IN_RING == false
@@ -282,8 +278,8 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
         for (int l = 0; l < 64; ++l)
           for (int e = 0; e < 4; ++e) {
             const int i = l & 31, hh = l >> 5, fo = 4 * g + e;
-            const size_t idx = ((((size_t)fi * 16 + r) * (NF / 4) + g) * 64 + l) * 4 + e;
-            dst[L.K2p + idx] = K2[(size_t)(fi * 32 + rho(r, hh)) * F + fo * 32 + i];
+            const size_t idx = (((size_t)r * (NF / 4) + g) * 64 + l) * 4 + e;             // within ring slot fi (main part)
+            dst[L.R0p + (size_t)fi * L.slot0 + idx] = K2[(size_t)(fi * 32 + rho(r, hh)) * F + fo * 32 + i];
           }
   const float* K3 = T(GLOWK_CONV3_KERNEL);  // [tap][f][co]
   for (int mt = 0; mt < NMT; ++mt)
@@ -293,23 +289,21 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
           for (int e = 0; e < 4; ++e) {
             const int i = l & 31, hh = l >> 5, r = 4 * r4 + e;
             const int m = mt * 32 + i, f = fo * 32 + rho(r, hh);
-            const size_t idx = ((((size_t)mt * NF + fo) * 4 + r4) * 64 + l) * 4 + e;
+            const size_t idx = ((((size_t)fo) * 4 + r4) * 64 + l) * 4 + e;                  // within ring slot NF + mt
             float v = 0.0f;
             if (m < 9 * CO) {
               const int tap = m / CO, co = m % CO;
               v = K3[((size_t)tap * F + f) * CO + co];
             }
-            dst[L.K3p + idx] = v;
+            dst[L.R0p + (size_t)(NF + mt) * L.slot0 + idx] = v;
           }
-  // ring image of k_net_f32 (Ring1): slot c < NF = K2 chunk c | conv1 MFMA operands of hidden block c+1; slot NF+mt = K3 chunk mt
-  if (L.slot0) {
+  // (the K2 / K3 loops above wrote the main parts of k_net_f32's ring image (Ring1): slot c < NF = K2 chunk c, slot NF+mt = K3
+  // chunk mt);  the conv1 MFMA operands of hidden block c+1 ride behind the main part of slot c
+  if (L.k1f0) {
     const size_t mainf = (size_t)NF * 1024, k1n = (size_t)KS1 * 64;
     for (int c2 = 0; c2 < NF + NMT; ++c2) {
-      float* slot = dst + L.R0p + (size_t)c2 * L.slot0;
-      const float* main_src = (c2 < NF) ? dst + L.K2p + (size_t)c2 * mainf : dst + L.K3p + (size_t)(c2 - NF) * mainf;
-      std::memcpy(slot, main_src, mainf * 4);
       const int k1blk = (c2 < NF) ? (c2 + 1) % NF : 0;
-      if (L.k1f0) std::memcpy(slot + mainf, dst + L.K1p + (size_t)k1blk * k1n, k1n * 4);
+      std::memcpy(dst + L.R0p + (size_t)c2 * L.slot0 + mainf, dst + L.K1p + (size_t)k1blk * k1n, k1n * 4);
     }
   }
   // ---- f16x3 image (k_net_h3): weights scaled by a power of two, split hi/lo in fp16, A operands in fragment order ----
@@ -636,7 +630,7 @@ NetArgs net_args(glowk_handle* h, const Level& lv, const StepDev& sd, const floa
   NetArgs a;
   a.vin = vin; a.in_stride = in_stride; a.in_off = in_off;
   a.Q = N * lv.h * lv.w; a.h = lv.h; a.w = lv.w;
-  a.K1p = sd.K1p; a.ep = sd.ep; a.K2p = sd.K2p; a.K3p = sd.K3p; a.R0p = sd.R0p; a.mask1 = nullptr; a.mask2 = nullptr; a.P = h->bufP;
+  a.K1p = sd.K1p; a.ep = sd.ep; a.R0p = sd.R0p; a.mask1 = nullptr; a.mask2 = nullptr; a.P = h->bufP;
   a.RHp = sd.RHp; a.eph = sd.epH; a.P2 = h->bufP2; a.sc1 = sd.sc1; a.sc2 = sd.sc2; a.sc3 = sd.sc3;
   return a;
 }
@@ -984,8 +978,6 @@ int glowk_finalize_weights(glowk_handle* h) {
       d.arena_off = offs[idx];
       const float* base = h->arena + offs[idx++];
       d.K1p = base + SL.K1p; d.ep = base + SL.ep;
-      d.K2p = reinterpret_cast<const float4*>(base + SL.K2p);
-      d.K3p = reinterpret_cast<const float4*>(base + SL.K3p);
       d.R0p = reinterpret_cast<const float4*>(base + SL.R0p);
       d.RHp = SL.slotH ? reinterpret_cast<const float4*>(base + SL.RHp) : nullptr;
       d.epH = SL.slotH ? base + SL.epH : nullptr;

@@ -40,16 +40,14 @@ struct NetArgs {
   int Q, h, w;
   const float* K1p;      // [NF fi][KS1][64 lanes]
   const float* ep;       // [6][F]: b1, g1, d1, b2, g2, d2   (BN folded: g = gamma/sqrt(var+eps), d = beta - mean*g)
-  const float4* K2p;     // [NF fi][16 r][NF/4][64 lanes] float4 (4 consecutive fo)
-  const float4* K3p;     // [NMT][NF fo][4 r4][64 lanes] float4 (4 consecutive r)
   const float4* R0p;     // ring image (Ring1): [NF + NMT] slots
   unsigned short* mask1; // [blocks of 32 px][NF][64 lanes] ReLU mask bits of conv1 (NET_FWD_SAVE writes, NET_BWD reads)
   unsigned short* mask2; // same for conv2
   float* P;              // [9*CO][Q]
-  float* P2;             // f16x3: partial sums of the second pass
-  const float4* RHp;     // f16x3 ring image (RingH), or null
-  const float* eph;      // its epilogue constants [c1 | bs1 | c2 | bs2 | pb], see RingH
-  float sc1, sc2, sc3;   // f16x3: 2^-(weight scale + activation scale) of conv1 / conv2 / conv3
+  float* P2;             // f16x3: partial sums of the second hidden half
+  const float4* RHp;     // f16x3 image (RingH) of the network this launch runs (forward or backward), or null
+  const float* eph;      // forward: [conv2 accumulator init (F) | per-row constants of P (32 NMT)], see pack_step
+  float sc1, sc2, sc3;   // f16x3: 2^-S of the three layers' weight scales (sc3 also undoes the activation scale)
 };
 
 // one 64-lane LDS-DMA piece: LDS destination = wave-uniform base + lane*16, global source per lane

@@ -63,6 +63,33 @@ __global__ __launch_bounds__(512, 2) void k(const float4* src, float* out, int i
   }
 }
 
+// fp32-input MFMA (v_mfma_f32_32x32x2_f32), operand pattern of k_net_f32: A from LDS as float4 (4 k-steps per read), B in registers
+__global__ __launch_bounds__(256, 1) void kf32(const float4* src, float* out, int iters) {
+  __shared__ float4 lds[2048 * 4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < 2048 * 4; i += 256) lds[i] = src[i];
+  __syncthreads();
+  float b[16];
+  for (int j = 0; j < 16; ++j) b[j] = 0.01f * ((lane * 7 + j * 13) % 97 - 48);
+  f32x16 acc[16];
+  for (int t = 0; t < 16; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 w = lds[(((it & 7) * 16 + r * 4 + g) * 64 + lane)];
+        acc[4 * g + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, b[r], acc[4 * g + 0], 0, 0, 0);
+        acc[4 * g + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, b[r + 4], acc[4 * g + 1], 0, 0, 0);
+        acc[4 * g + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, b[r + 8], acc[4 * g + 2], 0, 0, 0);
+        acc[4 * g + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, b[r + 12], acc[4 * g + 3], 0, 0, 0);
+      }
+  }
+  float s = 0.f;
+  for (int t = 0; t < 16; ++t) for (int r = 0; r < 16; ++r) s += acc[t][r];
+  out[blockIdx.x * 256 + tid] = s;
+}
+
 int main() {
   const int n4 = 2048 * 4;
   std::vector<_Float16> h((size_t)n4 * 8);
@@ -85,5 +112,17 @@ int main() {
       const double flops = (double)L * grid * 8 /*waves*/ * iters * 48.0 * 32768.0;   // 48 x (32x32x16) or 96 x (16x16x32) per iteration
       printf("shape %dx%d: %.2f ms  %.1f TFLOP/s (f16 MFMA, LDS-fed)\n", shape, shape, ms, flops / ms * 1e-9);
     }
+  for (int rep = 0; rep < 3; ++rep) {
+    const int it32 = 1500;
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kf32, dim3(grid), dim3(256), 0, 0, src, out, it32);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    const int L = 6;
+    for (int w = 0; w < L; ++w) hipLaunchKernelGGL(kf32, dim3(grid), dim3(256), 0, 0, src, out, it32);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)L * grid * 4 /*waves*/ * it32 * 64.0 * 4096.0;   // 64 x (32x32x2) per iteration
+    printf("fp32 32x32x2: %.2f ms  %.1f TFLOP/s (fp32 MFMA, LDS-fed, 1 wave per SIMD)\n", ms, flops / ms * 1e-9);
+  }
   return 0;
 }
