@@ -37,6 +37,7 @@ struct StepDev {            // device pointers into the arena
   const float4* R0p = nullptr;
   const float4* RHp = nullptr;   // f16x3 ring image (null: shape not supported by k_net_h3)
   const float* epH = nullptr;    // its epilogue constants
+  const float4* RSp = nullptr;   // forward image for the 16x16x32 kernel (k_net_h3s), or null
   const float4* RHBp = nullptr;  // f16x3 image of the backward network (null: not supported: exact fp32 backward)
   float scb1 = 1.f, scb2 = 1.f, scb3 = 1.f;
   float sc1 = 1.f, sc2 = 1.f, sc3 = 1.f;
@@ -148,9 +149,10 @@ inline int rho(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 inline size_t pad4(size_t n) { return (n + 3) & ~size_t(3); }
 
 struct StepLayout {
-  size_t K1p, ep, R0p, K3bp, RBp, RHp, epH, RHBp, Afwd, bfwd, Ainv, binv, b3, total;
+  size_t K1p, ep, R0p, K3bp, RBp, RHp, epH, RSp, RHBp, Afwd, bfwd, Ainv, binv, b3, total;
   size_t slotH;        // floats per main chunk of the f16x3 image (0: shape not supported by k_net_h3)
   size_t slotHB;       // the same for the backward network's image
+  size_t slotS;        // and for the forward image of the 16x16x32 kernel
   size_t slotB, k3fB;  // backward ring image: floats per slot; floats of its conv3^T-operand part (0: not in the ring)
   size_t slot0, k1f0;  // floats per slot of k_net_f32's ring image; floats of its conv1 part (0: not in the ring)
 };
@@ -185,6 +187,13 @@ StepLayout step_layout(int c, int F) {
     L.slotH = fitsH ? (size_t)NFH * 1024 : 0;
     L.RHp = o; o += fitsH ? (size_t)NF * KS * 512 + (size_t)2 * (NF + NMT) * NFH * 1024 : 0;
     L.epH = o; o += fitsH ? ephn : 0;
+    {                                                                                                 // RingS<CI, NF>
+      const int KSS = (9 * CI + 1 + 31) / 32, NMS = (18 * CI + 15) / 16, NCH = (NFH * NMS + 2 * NFH - 1) / (2 * NFH);
+      const size_t ldss = (size_t)3 * NFH * 4096 + (size_t)2 * KSS * 4096 + pad4((size_t)F + 16 * NMS) * 4;
+      const bool fitsS = fitsH && ldss <= 160 * 1024 && KSS <= 3 && NMS <= 12 && NCH >= 2;
+      L.slotS = fitsS ? (size_t)NFH * 1024 : 0;
+      L.RSp = o; o += fitsS ? (size_t)NF * KSS * 1024 + (size_t)2 * (NF + NCH) * NFH * 1024 : 0;
+    }
     const int KSB = (9 * c + 15) / 16, NMB = (9 * CI + 31) / 32;                                      // RingH<c, 9 CI, NF, bwd>
     const size_t ldsb = (size_t)3 * NFH * 4096 + (size_t)2 * KSB * 2048 + pad4((size_t)F + 32 * NMB) * 4 + (size_t)2 * NF * 1024;
     const bool fitsHB = ldsb <= 160 * 1024 && NF % 4 == 0 && KSB <= 5 && NMB <= 6;
@@ -410,6 +419,51 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
                 put(row_lane, j, 1, w, S);
               }
       }
+    // ---- the same network for k_net_h3s (RingS): 16-row A tiles, one k-step of 32 per hidden block; k slot (kq, j) of an
+    //      accumulator-derived B fragment is channel 16 (j >> 2) + 4 kq + (j & 3) of the block ----
+    if (L.slotS) {
+      const int KSS = (9 * CI + 1 + 31) / 32, NMS = (18 * CI + 15) / 16, NRB = 2 * NFH, TPC = 2 * NFH, NT = NFH * NMS;
+      const int NCH = (NT + TPC - 1) / TPC, GS0 = NMS < 6 ? NMS : 6, GS1 = NMS - GS0 > 0 ? NMS - GS0 : 1;
+      const size_t k1blkS = (size_t)KSS * 4 * 256;
+      float* imgS = dst + L.RSp;
+      for (int blk = 0; blk < NF; ++blk)
+        for (int s2 = 0; s2 < KSS; ++s2)
+          for (int rb = 0; rb < 2; ++rb)
+            for (int l = 0; l < 64; ++l)
+              for (int j = 0; j < 8; ++j) {
+                const int i = l & 15, kq = l >> 4, kk = 32 * s2 + 8 * kq + j;
+                const float w = kk <= 9 * CI ? K1f[(size_t)kk * F + blk * 32 + rb * 16 + i] : 0.0f;
+                float* row_lane = imgS + (size_t)blk * k1blkS + ((size_t)((s2 * 2 + rb) * 2) * 64 + l) * 4;
+                put(row_lane, j, 0, w, S1);
+                put(row_lane, j, 1, w, S1);
+              }
+      for (int ps = 0; ps < 2; ++ps)
+        for (int ch = 0; ch < NF + NCH; ++ch) {
+          float* chunk = imgS + (size_t)NF * k1blkS + ((size_t)ps * (NF + NCH) + ch) * chunkf;
+          for (int tp = 0; tp < NRB; ++tp)      // NRB row blocks (K2 chunk) or TPC = NRB conv3 tiles
+            for (int l = 0; l < 64; ++l)
+              for (int j = 0; j < 8; ++j) {
+                const int i = l & 15, kq = l >> 4;
+                const int kloc = 16 * (j >> 2) + 4 * kq + (j & 3);
+                float w = 0.0f;
+                int S = S2;
+                if (ch < NF) w = K2f[(size_t)(ch * 32 + kloc) * F + ps * NFH * 32 + tp * 16 + i];
+                else {
+                  const int t = (ch - NF) * TPC + tp;
+                  S = S3;
+                  if (t < NT) {
+                    const int fo = t < NFH * GS0 ? t / GS0 : (t - NFH * GS0) / GS1;
+                    const int mt = t < NFH * GS0 ? t % GS0 : GS0 + (t - NFH * GS0) % GS1;
+                    const int m = mt * 16 + i, f = (ps * NFH + fo) * 32 + kloc;
+                    if (m < 9 * CO) { const int tap = m / CO, co = m % CO; w = K3f[((size_t)tap * F + f) * CO + co]; }
+                  }
+                }
+                float* row_lane = chunk + ((size_t)(tp * 2) * 64 + l) * 4;
+                put(row_lane, j, 0, w, S);
+                put(row_lane, j, 1, w, S);
+              }
+        }
+    }
   }
 
   // ---- f16x3 image of the backward network (k_net_h3, NET_BWD): g_a2 = g2 * mask2 * conv3^T(g_o), g_a1 = g1 * mask1 * K2 g_a2,
@@ -509,18 +563,27 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
 
 // ---- launch helpers ------------------------------------------------------------------------------
 int g_num_cus = 0;   // compute units of the current device (queried once)
-
-// k_net_h3: one workgroup per 256 pixels running both hidden halves, or -- when that leaves at least half of the CUs
-// without a workgroup -- one workgroup per (256 pixels, hidden half): half the latency per launch
-template <int KIN, int MOUT, int NF, int MODE>
-void launch_h3(const NetArgs& a, hipStream_t s) {
+int num_cus() {
   if (g_num_cus == 0) {
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
     if (g_num_cus <= 0) g_num_cus = 256;
   }
+  return g_num_cus;
+}
+// GLOWK_H3_SHAPE=32 keeps the forward pass on the 32x32x16 kernel (A/B timing of the two MFMA shapes); default 16x16x32
+bool h3_shape16() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("GLOWK_H3_SHAPE"); v = (e && atoi(e) == 32) ? 0 : 1; }
+  return v == 1;
+}
+
+// k_net_h3: one workgroup per 256 pixels running both hidden halves, or -- when that leaves at least half of the CUs
+// without a workgroup -- one workgroup per (256 pixels, hidden half): half the latency per launch
+template <int KIN, int MOUT, int NF, int MODE>
+void launch_h3(const NetArgs& a, hipStream_t s) {
   const int wgs = (a.Q + 255) / 256;
-  if (2 * wgs <= g_num_cus) hipLaunchKernelGGL((k_net_h3<KIN, MOUT, NF, MODE, true>), dim3(wgs, 2), dim3(512), 0, s, a);
+  if (2 * wgs <= num_cus()) hipLaunchKernelGGL((k_net_h3<KIN, MOUT, NF, MODE, true>), dim3(wgs, 2), dim3(512), 0, s, a);
   else hipLaunchKernelGGL((k_net_h3<KIN, MOUT, NF, MODE, false>), dim3(wgs), dim3(512), 0, s, a);
 }
 
@@ -532,6 +595,14 @@ int launch_net_t(const NetArgs& a, int mode, hipStream_t s) {
     case NET_FWD_SAVE: hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE>), dim3(ntiles), dim3(256), 0, s, a); break;
     case NET_BWD:      hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD>), dim3(ntiles), dim3(256), 0, s, a); break;
     case 3:   // f16x3 arithmetic: forward / forward with saves / backward; shapes without an instance run the exact fp32 kernel
+      if constexpr (RingS<CI, NF>::FITS) {
+        if (a.RSp && h3_shape16()) {
+          const int wgs = (a.Q + 255) / 256;
+          if (2 * wgs <= num_cus()) hipLaunchKernelGGL((k_net_h3s<CI, NF, true>), dim3(wgs, 2), dim3(512), 0, s, a);
+          else hipLaunchKernelGGL((k_net_h3s<CI, NF, false>), dim3(wgs), dim3(512), 0, s, a);
+          break;
+        }
+      }
       if constexpr (RingH<CI, 18 * CI, NF, NET_FWD>::FITS) {
         if (a.RHp) { launch_h3<CI, 18 * CI, NF, NET_FWD>(a, s); break; }
       }
@@ -631,7 +702,7 @@ NetArgs net_args(glowk_handle* h, const Level& lv, const StepDev& sd, const floa
   a.vin = vin; a.in_stride = in_stride; a.in_off = in_off;
   a.Q = N * lv.h * lv.w; a.h = lv.h; a.w = lv.w;
   a.K1p = sd.K1p; a.ep = sd.ep; a.R0p = sd.R0p; a.mask1 = nullptr; a.mask2 = nullptr; a.P = h->bufP;
-  a.RHp = sd.RHp; a.eph = sd.epH; a.P2 = h->bufP2; a.sc1 = sd.sc1; a.sc2 = sd.sc2; a.sc3 = sd.sc3;
+  a.RHp = sd.RHp; a.RSp = sd.RSp; a.eph = sd.epH; a.P2 = h->bufP2; a.sc1 = sd.sc1; a.sc2 = sd.sc2; a.sc3 = sd.sc3;
   return a;
 }
 
@@ -981,6 +1052,7 @@ int glowk_finalize_weights(glowk_handle* h) {
       d.R0p = reinterpret_cast<const float4*>(base + SL.R0p);
       d.RHp = SL.slotH ? reinterpret_cast<const float4*>(base + SL.RHp) : nullptr;
       d.epH = SL.slotH ? base + SL.epH : nullptr;
+      d.RSp = SL.slotS ? reinterpret_cast<const float4*>(base + SL.RSp) : nullptr;
       d.RHBp = SL.slotHB ? reinterpret_cast<const float4*>(base + SL.RHBp) : nullptr;
       d.K3bp = base + SL.K3bp;
       d.RBp = reinterpret_cast<const float4*>(base + SL.RBp);

@@ -47,6 +47,7 @@ struct NetArgs {
   float* P2;             // f16x3: partial sums of the second hidden half
   const float4* RHp;     // f16x3 image (RingH) of the network this launch runs (forward or backward), or null
   const float* eph;      // forward: [conv2 accumulator init (F) | per-row constants of P (32 NMT)], see pack_step
+  const float4* RSp;     // the forward network's image for the 16x16x32 kernel (RingS; same constants and scales), or null
   float sc1, sc2, sc3;   // f16x3: 2^-S of the three layers' weight scales (sc3 also undoes the activation scale)
 };
 
@@ -710,6 +711,324 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
     h3_pass<KIN, MOUT, NF, MODE, (G::NMT + 1) & 1, 1, false>(a, c, epl, xh, xl, g, q, qok, lane, hh);
   }
   if (!g) h3_barrier();                                    // group 0 idles through the last phase
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_net_h3s: the forward coupling network of k_net_h3 on v_mfma_f32_16x16x32_f16.  Under this chip's power management the
+// 16x16x32 shape sustains ~10 % more FLOP/s than 32x32x16 (scripts/mfma_shape.hip: 1 697 vs 1 535 TFLOP/s, LDS-fed, random
+// data), and k_net_h3 is bound by exactly that.  Same workgroup geometry, op sequence, LDS slots and DMA
+// schedule as k_net_h3 (chunks have the same size); what changes is the tiling inside an op:
+//   * a wave's 32 pixels are two 16-pixel halves; lane l = (n = l & 15, kq = l >> 4) holds pixel n of each half;
+//   * accumulators are 16 x 16 tiles (4 registers): rows 4 kq + r of a 16-row block;
+//   * a hidden block of 32 channels = two row blocks = 8 values per lane and half = exactly one B fragment of the next
+//     contraction (one k-step of 32): k slot (kq, j) <-> channel 16 (j >> 2) + 4 kq + (j & 3); the host packs A that way.
+// Forward only (NET_FWD): the gradient path keeps the 32x32 kernels, whose ReLU-mask layout the fp32 fallback shares.
+// ------------------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int CI, int NF>
+struct RingS {
+  static constexpr int NFH = NF / 2;                              // hidden 32-channel blocks per pass
+  static constexpr int NRB = 2 * NFH;                             // 16-row blocks per pass
+  static constexpr int K1 = 9 * CI;
+  static constexpr int KS = (K1 + 1 + 31) / 32;                   // conv1 k-steps of 32 (a spare row carries the bias)
+  static constexpr int MAINP = NRB * 2;                           // pieces per main chunk: NRB row blocks x (hi, lo)
+  static constexpr int MAIN4 = MAINP * 64;
+  static constexpr int K1P = KS * 4;                              // one block's conv1 operands: KS x 2 row blocks x (hi, lo)
+  static constexpr int K14 = K1P * 64;
+  static constexpr int M3 = 18 * CI;
+  static constexpr int NMT = (M3 + 15) / 16;                      // 16-row blocks of P
+  static constexpr int TPC = MAINP / 2;                           // conv3 tiles (16 rows x 32 k, hi + lo) per chunk
+  static constexpr int NT = NFH * NMT;                            // conv3 tiles per pass
+  static constexpr int NCH = (NT + TPC - 1) / TPC;                // conv3 chunks per pass (the last one may be part empty)
+  static constexpr int G0N = NMT < 6 ? NMT : 6;                   // row blocks are processed in fused groups of <= 6
+  static constexpr int G1N = NMT - G0N;
+  static constexpr int G1D = G1N > 0 ? G1N : 1;
+  static constexpr int EPN = (NF * 32 + 16 * NMT + 3) & ~3;       // conv2 accumulator init (F) | per-row constants of P
+  static constexpr size_t LDS_BYTES = (size_t)3 * MAIN4 * 16 + (size_t)2 * K14 * 16 + (size_t)EPN * 4;
+  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && KS <= 3 && G1N <= 6 && NCH >= 2;
+  static constexpr int K1TOT4 = NF * K14;
+  static constexpr int PASS4 = (NF + NCH) * MAIN4;
+  static constexpr int tile_fo(int t) { return t < NFH * G0N ? t / G0N : (t - NFH * G0N) / G1D; }
+  static constexpr int tile_mt(int t) { return t < NFH * G0N ? t % G0N : G0N + (t - NFH * G0N) % G1D; }
+};
+
+__device__ __forceinline__ f32x4 mfma3s(const h8& ahi, const h8& alo, const h8& bhi, const h8& blo, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, acc, 0, 0, 0);
+  return acc;
+}
+
+// ReLU + split of one hidden block (two row blocks) of one pixel half -> the B fragment of the next contraction
+__device__ __forceinline__ void h3s_act(const f32x4& r0, const f32x4& r1, float sc, h8& bh, h8& bl) {
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j] = fmaxf(r0[j] * sc, 0.0f);
+    v[4 + j] = fmaxf(r1[j] * sc, 0.0f);
+  }
+  split8(v, bh, bl);
+}
+
+template <int CI, int NF, int KP>
+__device__ __forceinline__ void h3s_X(const NetArgs& a, const H3Ctx& c, const h8 (&xh)[(RingS<CI, NF>::KS)][2],
+                                      const h8 (&xl)[(RingS<CI, NF>::KS)][2], int lane, h8 (&bh)[2], h8 (&bl)[2]) {
+  using G = RingS<CI, NF>;
+  f32x4 h1[2][2];   // [row block][pixel half]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h1[i >> 1][i & 1][r] = 0.0f;
+  const h8* k1 = reinterpret_cast<const h8*>(KP ? c.k1s1 : c.k1s0) + lane;   // [s][row block][hi|lo][64]
+  h8 kf[G::K1P];
+#pragma unroll
+  for (int i = 0; i < G::K1P; ++i) kf[i] = k1[i * 64];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < G::KS; ++s)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+        h1[rb][hf] = mfma3s(kf[(s * 2 + rb) * 2 + 0], kf[(s * 2 + rb) * 2 + 1], xh[s][hf], xl[s][hf], h1[rb][hf]);
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) h3s_act(h1[0][hf], h1[1][hf], a.sc1, bh[hf], bl[hf]);
+}
+
+// Y: conv2 contribution of one hidden block (one k-step of 32) to the pass's NRB x 2 accumulator tiles; same pipelining and
+// DMA duties as h3_Y (groups of 12 MFMAs = two row blocks x two pixel halves x three split terms)
+template <int CI, int NF, int TAG>
+__device__ __forceinline__ void h3s_Y(const float4* slot, const h8 (&bh)[2], const h8 (&bl)[2], f32x4 (&acc2)[(RingS<CI, NF>::NRB)][2],
+                                      int lane, int g, bool main_ok, const float4* main_src, float4* main_dst, const float4* k1_src,
+                                      float4* k1_dst, int w4, unsigned voff) {
+  using G = RingS<CI, NF>;
+  const h8* buf = reinterpret_cast<const h8*>(slot) + lane;
+  const char* mb = uniform_ptr(main_src);
+  constexpr int NG = G::NRB / 2;
+  constexpr int PPG = G::MAINP / 4 / NG;            // DMA pieces per wave and group
+  h8 A[2][4];
+  auto load = [&](h8 (&d)[4], int gi) {
+    d[0] = buf[((2 * gi) * 2 + 0) * 64];            // row block 2gi hi, lo; row block 2gi+1 hi, lo
+    d[1] = buf[((2 * gi) * 2 + 1) * 64];
+    d[2] = buf[((2 * gi + 1) * 2 + 0) * 64];
+    d[3] = buf[((2 * gi + 1) * 2 + 1) * 64];
+  };
+  load(A[0], 0);
+#pragma unroll
+  for (int gi = 0; gi < NG; ++gi) {
+    const int o0 = 2 * gi, o1 = 2 * gi + 1;
+    if (gi + 1 < NG) load(A[(gi + 1) & 1], gi + 1);
+    if (!g) {
+      if (main_ok) {
+#pragma unroll
+        for (int e = 0; e < PPG; ++e) {
+          const int piece = (gi * PPG + e) * 4 + w4;
+          glds16(reinterpret_cast<const float4*>(mb + (size_t)piece * 1024 + voff), main_dst + piece * 64);
+        }
+      }
+      asm volatile("; dma site %0" ::"n"(TAG * 16 + gi));
+    } else if (gi == 0) {
+      stage4<G::K1P, TAG * 16 + 15>(k1_src, k1_dst, w4, voff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const h8 (&af)[4] = A[gi & 1];
+    acc2[o0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1], bh[0], acc2[o0][0], 0, 0, 0);
+    acc2[o0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1], bh[1], acc2[o0][1], 0, 0, 0);
+    acc2[o1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[3], bh[0], acc2[o1][0], 0, 0, 0);
+    acc2[o1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[3], bh[1], acc2[o1][1], 0, 0, 0);
+    acc2[o0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bl[0], acc2[o0][0], 0, 0, 0);
+    acc2[o0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bl[1], acc2[o0][1], 0, 0, 0);
+    acc2[o1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2], bl[0], acc2[o1][0], 0, 0, 0);
+    acc2[o1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2], bl[1], acc2[o1][1], 0, 0, 0);
+    acc2[o0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bh[0], acc2[o0][0], 0, 0, 0);
+    acc2[o0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bh[1], acc2[o0][1], 0, 0, 0);
+    acc2[o1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2], bh[0], acc2[o1][0], 0, 0, 0);
+    acc2[o1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2], bh[1], acc2[o1][1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Z: conv3 op z of a pass = half a chunk of A tiles (16 rows x one hidden block)
+template <int CI, int NF, int P0, int PASS, bool SOLO, int Z>
+__device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const float* epl, f32x4 (&acc2)[(RingS<CI, NF>::NRB)][2],
+                                      f32x4 (&acc3)[(RingS<CI, NF>::G0N)][2], h8 (&bh)[2], h8 (&bl)[2], int g, const int (&q)[2],
+                                      const bool (&qok)[2], int lane, int kq) {
+  using G = RingS<CI, NF>;
+  constexpr int NFH = G::NFH, M3 = G::M3, TPC = G::TPC;
+  constexpr int S = Z >> 1;
+  constexpr int P0N = (G::NCH + 1 + P0) & 1;
+  if (!g) {
+    constexpr int SN = Z == 1 ? 2 : (Z >= 5 && (Z & 1)) ? (Z + 1) / 2 : 0;
+    if constexpr (SN >= 2 && SN < G::NCH)
+      stage4<G::MAINP, 16 + Z>(c.pass_img + (size_t)(NF + SN) * G::MAIN4, ((NF + SN - 1 + P0) & 1) ? c.sB : c.sA, c.w4, c.voff);
+    if constexpr (PASS == 0 && !SOLO && Z == 2 * G::NCH - 1) {
+      stage4<G::MAINP, 48>(c.next_img, P0N ? c.sB : c.sA, c.w4, c.voff);
+      stage4<G::MAINP, 49>(c.next_img + (size_t)NF * G::MAIN4, c.sD, c.w4, c.voff);
+    }
+  }
+  const float4* slot = S == 0 ? c.sD : (((NF + S - 1 + P0) & 1) ? c.sB : c.sA);
+  const h8* buf = reinterpret_cast<const h8*>(slot) + lane;
+  float* Pp = PASS == 0 ? a.P : a.P2;
+  const float* pb = epl + NF * 32;
+#pragma unroll
+  for (int i = 0; i < TPC / 2; ++i) {
+    const int tp = (Z & 1) * (TPC / 2) + i;            // tile position in the chunk
+    const int t = S * TPC + tp;
+    if (t < G::NT) {
+      const int fo = G::tile_fo(t), mt = G::tile_mt(t);
+      const int ml = t >= NFH * G::G0N ? mt - G::G0N : mt;
+      if (ml == 0) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) h3s_act(acc2[2 * fo][hf], acc2[2 * fo + 1][hf], a.sc2, bh[hf], bl[hf]);
+      }
+      if (fo == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc3[ml][0][r] = 0.0f; acc3[ml][1][r] = 0.0f; }
+      }
+      const h8 ah = buf[(tp * 2 + 0) * 64], al = buf[(tp * 2 + 1) * 64];
+      acc3[ml][0] = mfma3s(ah, al, bh[0], bl[0], acc3[ml][0]);
+      acc3[ml][1] = mfma3s(ah, al, bh[1], bl[1], acc3[ml][1]);
+      if (fo == NFH - 1) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = mt * 16 + 4 * kq + r;
+            if (m < M3 && qok[hf]) Pp[(size_t)m * a.Q + q[hf]] = PASS == 0 ? fmaf(acc3[ml][hf][r], a.sc3, pb[m]) : acc3[ml][hf][r] * a.sc3;
+          }
+      }
+    }
+  }
+  h3_wait_barrier();
+}
+
+template <int CI, int NF, int P0, int PASS, bool SOLO, int... Z>
+__device__ __forceinline__ void h3s_tail(const NetArgs& a, const H3Ctx& c, const float* epl, f32x4 (&acc2)[(RingS<CI, NF>::NRB)][2],
+                                         f32x4 (&acc3)[(RingS<CI, NF>::G0N)][2], h8 (&bh)[2], h8 (&bl)[2], int g, const int (&q)[2],
+                                         const bool (&qok)[2], int lane, int kq, std::integer_sequence<int, Z...>) {
+  (h3s_Z<CI, NF, P0, PASS, SOLO, Z>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, kq), ...);
+}
+
+template <int CI, int NF, int P0, int PASS, bool SOLO>
+__device__ __forceinline__ void h3s_pass(const NetArgs& a, const H3Ctx& c, const float* epl, const h8 (&xh)[(RingS<CI, NF>::KS)][2],
+                                         const h8 (&xl)[(RingS<CI, NF>::KS)][2], int g, const int (&q)[2], const bool (&qok)[2], int lane, int kq) {
+  using G = RingS<CI, NF>;
+  constexpr int NRB = G::NRB;
+  constexpr int f2base = PASS * G::NFH * 32;
+  f32x4 acc2[NRB][2];
+#pragma unroll
+  for (int ob = 0; ob < NRB; ++ob)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float b = epl[f2base + ob * 16 + 4 * kq + r];   // conv2 bias (scaled)
+      acc2[ob][0][r] = b;
+      acc2[ob][1][r] = b;
+    }
+  h8 bh[2], bl[2];
+#pragma nounroll
+  for (int i0 = 0; i0 < NF; i0 += 2) {
+    h3s_X<CI, NF, 0>(a, c, xh, xl, lane, bh, bl);
+    h3_wait_barrier();
+    h3s_Y<CI, NF, 1>(P0 ? c.sB : c.sA, bh, bl, acc2, lane, g, true, c.pass_img + (size_t)(i0 + 1) * G::MAIN4, P0 ? c.sA : c.sB,
+                     c.k1img + (size_t)((i0 + 2) % NF) * G::K14, c.k1s0, c.w4, c.voff);
+    h3_barrier();
+    h3s_X<CI, NF, 1>(a, c, xh, xl, lane, bh, bl);
+    h3_wait_barrier();
+    h3s_Y<CI, NF, 2>(P0 ? c.sA : c.sB, bh, bl, acc2, lane, g, true, c.pass_img + (size_t)(i0 + 2 < NF ? i0 + 2 : NF + 1) * G::MAIN4,
+                     P0 ? c.sB : c.sA, c.k1img + (size_t)((i0 + 3) % NF) * G::K14, c.k1s1, c.w4, c.voff);
+    h3_barrier();
+  }
+  f32x4 acc3[G::G0N][2];
+  h3s_tail<CI, NF, P0, PASS, SOLO>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, kq, std::make_integer_sequence<int, 2 * G::NCH>());
+}
+
+template <int CI, int NF, bool SPLIT>
+__global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
+  using G = RingS<CI, NF>;
+  constexpr int K1 = G::K1;
+  constexpr int KS = G::KS;
+  static_assert(G::FITS, "shape");
+
+  __shared__ float4 slotA[G::MAIN4];
+  __shared__ float4 slotB[G::MAIN4];
+  __shared__ float4 slotD[G::MAIN4];
+  __shared__ float4 k1slot0[G::K14];
+  __shared__ float4 k1slot1[G::K14];
+  __shared__ float epl[G::EPN];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2;
+  const int n16 = lane & 15;
+  const int kq = lane >> 4;
+  const int qbase = (blockIdx.x * 8 + (tid >> 6)) * 32;
+  const int q[2] = {qbase + n16, qbase + 16 + n16};
+  const bool qok[2] = {q[0] < a.Q, q[1] < a.Q};
+
+  H3Ctx c;
+  c.sA = slotA; c.sB = slotB; c.sD = slotD; c.k1s0 = k1slot0; c.k1s1 = k1slot1;
+  const int solo_pass = SPLIT ? (int)blockIdx.y : 0;
+  c.k1img = a.RSp;
+  c.pass_img = a.RSp + G::K1TOT4 + (size_t)solo_pass * G::PASS4;
+  c.next_img = a.RSp + G::K1TOT4 + G::PASS4;
+  c.mkl = nullptr;
+  c.wblk = (size_t)blockIdx.x * 8 + wave;
+  c.wok = (long)c.wblk * 32 < a.Q;
+  c.w4 = wave & 3;
+  c.voff = (unsigned)lane * 16u;
+
+  // im2col fragments of this lane's two pixels: k-step s holds k = 32 s + 8 kq + j (natural order), scaled and split
+  h8 xh[KS][2], xl[KS][2];
+  {
+    const int hw = a.h * a.w;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int qq = qok[hf] ? q[hf] : 0;
+      const int rem = qq % hw;
+      const int i = rem / a.w, j0 = rem % a.w;
+      const float* base = a.vin + (long)qq * a.in_stride + a.in_off;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = 32 * s + 8 * kq + j;
+          const int tap = k / CI, cin = k % CI;
+          const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+          const int ii = i + dy, jj = j0 + dx;
+          const bool ok = qok[hf] && k < K1 && ii >= 0 && ii < a.h && jj >= 0 && jj < a.w;
+          const int off = ok ? ((dy * a.w + dx) * a.in_stride + cin) : 0;
+          const float x = base[off];
+          v[j] = ok ? x * GLOWK_ACT_SCALE : (k == K1 ? GLOWK_ACT_SCALE : 0.0f);   // row K1: carries conv1's bias
+        }
+        split8(v, xh[s][hf], xl[s][hf]);
+      }
+    }
+  }
+  for (int i = tid; i < G::EPN; i += 512) epl[i] = a.eph[i];   // RingS::EPN <= RingH::EPN, same content
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!g) {
+    stage4<G::MAINP, 60>(c.pass_img, slotA, c.w4, c.voff);
+    stage4<G::MAINP, 61>(c.pass_img + (size_t)NF * G::MAIN4, slotD, c.w4, c.voff);
+  } else {
+    stage4<G::K1P, 62>(c.k1img, k1slot0, c.w4, c.voff);
+    stage4<G::K1P, 63>(c.k1img + G::K14, k1slot1, c.w4, c.voff);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  if (g) h3_barrier();
+  if constexpr (SPLIT) {
+    if (solo_pass == 0) h3s_pass<CI, NF, 0, 0, true>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+    else h3s_pass<CI, NF, 0, 1, true>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+  } else {
+    h3s_pass<CI, NF, 0, 0, false>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+    c.pass_img = c.next_img;
+    h3s_pass<CI, NF, (G::NCH + 1) & 1, 1, false>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+  }
+  if (!g) h3_barrier();
 }
 
 // ------------------------------------------------------------------------------------------------

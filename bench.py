@@ -35,6 +35,8 @@ from audiosourcesep_amd.synthetic import synthetic_params, synthetic_mel_tiles  
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md:42
 PEAK_F16_MFMA_TFLOPS = 2500.0  # :43 (dense); the split path issues 3 fp16 MFMAs per fp32-equivalent product
+SUSTAINED_F16_MFMA_TFLOPS = 1697.0   # scripts/mfma_shape.hip on this pool's MI355X: v_mfma_f32_16x16x32_f16, A from LDS, random data
+SUSTAINED_F32_MFMA_TFLOPS = 150.8    # same program: v_mfma_f32_32x32x2_f32
 PEAK_HBM_GBS = 8000.0          # :36
 
 
@@ -244,7 +246,7 @@ def main():
                 kernel, peak = "k_net_f32<CI=%d,NF=%d> (level 0)" % (c0 // 2, cfg.F // 32), PEAK_F32_MFMA_TFLOPS
                 note = "fp32-input MFMA peak"
             else:
-                kernel, peak = "k_net_h3<CI=%d,NF=%d> (level 0)" % (c0 // 2, cfg.F // 32), PEAK_F16_MFMA_TFLOPS / 3.0
+                kernel, peak = "k_net_h3s<CI=%d,NF=%d> (level 0)" % (c0 // 2, cfg.F // 32), PEAK_F16_MFMA_TFLOPS / 3.0
                 note = "fp16 dense MFMA peak / 3 (three fp16 MFMAs per fp32-equivalent product)"
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
@@ -255,9 +257,13 @@ def main():
                     traffic = t * n if t is not None else None
                 except Exception:
                     traffic = None
+            # what a bare MFMA loop with this kernel's operand pattern sustains on this chip under its power management
+            # (scripts/mfma_shape.hip, random data): 1 697 TFLOP/s for 16x16x32 f16 (/3), 150.8 TFLOP/s for 32x32x2 f32
+            sustained = SUSTAINED_F32_MFMA_TFLOPS if precision == "f32" else SUSTAINED_F16_MFMA_TFLOPS / 3.0
             return {"kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "peak_note": note, "unit": "TFLOP/s",
                     "frac": (achieved / peak) if achieved else None, "traffic": traffic, "avg_launch_ms": avg_ms,
-                    "launches": launches0, "flop_per_launch": flop_launch}
+                    "launches": launches0, "flop_per_launch": flop_launch, "sustained_mfma_rate_measured": sustained,
+                    "frac_of_sustained": (achieved / sustained) if achieved else None}
 
         passes = n * world * args.steps
         value = passes / elapsed

@@ -169,7 +169,8 @@ def test_input_gradient_in_f16x3_arithmetic():
     lp32, g32 = eng.log_prob_grad(dev(x))
     eng.set_precision(_lib.PREC_F16X3)
     lp16, g16 = eng.log_prob_grad(dev(x))
-    assert torch.equal(lp16, eng.log_prob(dev(x)))           # the saving forward pass computes the plain one's bits
+    # the saving pass runs the 32x32x16 kernel, the plain one the 16x16x32 kernel: same products, another summation order
+    np.testing.assert_allclose(lp16.cpu().numpy(), eng.log_prob(dev(x)).cpu().numpy(), rtol=1e-6)
     lp_ref, g_ref = RT.log_prob_and_grad(x.astype(np.float64), params, cfg.as_dict())
     scale = np.abs(g_ref).max()
     np.testing.assert_allclose(lp16.cpu().numpy(), lp_ref, rtol=1e-6)
