@@ -226,7 +226,7 @@ def main():
     rel_diff = float(((lp_main - lp_other).abs() / lp_other.abs()).max().item())
     # accuracy of the headline arithmetic against the fp64 CPU oracle on two tiles of the same batch (rank 0)
     acc_vs_oracle = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # (N > 1: the other ranks would idle at the barrier meanwhile)
         from oracle import glowref as R
         xs = x[:2].cpu().numpy().astype(np.float64)
         ref = R.log_prob(xs, R.cast_params(params, np.float64), cfg.as_dict())
