@@ -98,19 +98,25 @@ def basis_inner_loop(mixed, x1, x2, model1, model2, sigma_idx, sigmas, delta=2e-
 
 def basis_outer_loop(mixed, x1, x2, model1, model2, sigmas, restore_1=None, restore_2=None, T=100, delta=2e-5, noise_fn=None,
                      debug=False):
-    """run_basis_sep.py:217-260.  ``restore_k``: optional ``{sigma: state_dict or path}`` with the noise-conditioned
-    weights of model k for each noise level (the per-sigma checkpoints of train_noisy_glow.py:309-358)."""
+    """run_basis_sep.py:217-260.  ``restore_k``: optional ``{sigma: state_dict | path | GlowFlow}`` with the noise-conditioned
+    weights of model k for each noise level (the per-sigma checkpoints of train_noisy_glow.py:309-358); a ``GlowFlow`` value is
+    used as is (all ten noise levels of both priors resident: 2 x 10 x 0.5 GB of packed weights)."""
     x_arr = {"x1": [x1.cpu().numpy()], "x2": [x2.cpu().numpy()]}
     for sigma_idx, sigma in enumerate(sigmas):
+        current = []
         for model, restore in ((model1, restore_1), (model2, restore_2)):
             if restore is not None:
                 state = restore[float(sigma)] if float(sigma) in restore else restore[sigma]
-                if isinstance(state, str):
-                    model.restore(state)
+                if hasattr(state, "log_prob"):      # a resident flow for this noise level: no weight swap at all
+                    model = state
+                elif isinstance(state, str):
+                    model.restore(state)            # ~0.4 s for config B (host re-pack on 16 threads + 0.5 GB upload)
                 else:
                     model.load_state_dict(state)
+            current.append(model)
+        model1_s, model2_s = current
         nf = None if noise_fn is None else (lambda t, which, shape, _s=sigma_idx: noise_fn(_s, t, which, shape))
-        x1, x2 = basis_inner_loop(mixed, x1, x2, model1, model2, sigma_idx, sigmas, delta=delta, T=T, noise_fn=nf, debug=debug)
+        x1, x2 = basis_inner_loop(mixed, x1, x2, model1_s, model2_s, sigma_idx, sigmas, delta=delta, T=T, noise_fn=nf, debug=debug)
         x_arr["x1"].append(x1.cpu().numpy())
         x_arr["x2"].append(x2.cpu().numpy())
     return x1, x2, x_arr

@@ -3,11 +3,15 @@
 #include "../../include/glowk.h"
 #include "glowk_kernels.h"
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sched.h>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -1011,23 +1015,43 @@ int glowk_finalize_weights(glowk_handle* h) {
   std::vector<float> stage(total, 0.0f);
   h->ld_step.assign((size_t)cfg.L * cfg.K, 0.0);
   h->ld_const = 0.0;
-  size_t o = 0;
+  // every step packs into its own block of the staging arena: steps are packed by a few host threads
+  struct Job { size_t l; int k; size_t off; double ldc; float sc[6]; std::string err; bool ok; };
+  std::vector<Job> jobs;
   std::vector<size_t> offs;
-  for (size_t l = 0; l < h->levels.size(); ++l) {
-    const Level& lv = h->levels[l];
-    for (int k = 0; k < cfg.K; ++k) {
-      std::string err;
-      double ldc = 0;
-      float sc3[6];
-      if (!pack_step(cfg, lv, k, stage.data() + o, &ldc, sc3, &err))
-        return fail("level " + std::to_string(l) + " step " + std::to_string(k) + ": " + err);
-      h->ld_step[l * cfg.K + k] = ldc;
-      h->levels[l].dev[k].sc1 = sc3[0]; h->levels[l].dev[k].sc2 = sc3[1]; h->levels[l].dev[k].sc3 = sc3[2];
-      h->levels[l].dev[k].scb1 = sc3[3]; h->levels[l].dev[k].scb2 = sc3[4]; h->levels[l].dev[k].scb3 = sc3[5];
-      h->ld_const += ldc;
-      offs.push_back(o);
-      o += step_layout(lv.c, cfg.F).total;
-    }
+  {
+    size_t o = 0;
+    for (size_t l = 0; l < h->levels.size(); ++l)
+      for (int k = 0; k < cfg.K; ++k) {
+        jobs.push_back(Job{l, k, o, 0.0, {1, 1, 1, 1, 1, 1}, std::string(), false});
+        offs.push_back(o);
+        o += step_layout(h->levels[l].c, cfg.F).total;
+      }
+  }
+  {
+    std::atomic<size_t> next(0);
+    auto work = [&]() {
+      for (size_t j; (j = next.fetch_add(1)) < jobs.size();) {
+        Job& jb = jobs[j];
+        jb.ok = pack_step(cfg, h->levels[jb.l], jb.k, stage.data() + jb.off, &jb.ldc, jb.sc, &jb.err);
+      }
+    };
+    unsigned nthr = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) nthr = std::min<unsigned>(nthr ? nthr : 1, (unsigned)CPU_COUNT(&set));
+    nthr = std::max(1u, std::min<unsigned>(std::min<unsigned>(nthr, 16u), (unsigned)jobs.size()));
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread& t : pool) t.join();
+  }
+  for (const Job& jb : jobs) {
+    if (!jb.ok) return fail("level " + std::to_string(jb.l) + " step " + std::to_string(jb.k) + ": " + jb.err);
+    StepDev& d = h->levels[jb.l].dev[jb.k];
+    h->ld_step[jb.l * cfg.K + jb.k] = jb.ldc;
+    d.sc1 = jb.sc[0]; d.sc2 = jb.sc[1]; d.sc3 = jb.sc[2];
+    d.scb1 = jb.sc[3]; d.scb2 = jb.sc[4]; d.scb3 = jb.sc[5];
+    h->ld_const += jb.ldc;
   }
   std::memcpy(stage.data() + prior_off, h->prior_loc.data(), E * 4);
   std::memcpy(stage.data() + prior_off + pad4(E), h->prior_log_scale.data(), E * 4);
