@@ -93,6 +93,9 @@ def load():
         raise GlowkLibraryMissing(
             "HIP library %s not found: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
             "There is no CPU fallback for the compute path." % LIB_PATH)
+    # torch first: its wheel carries its own libamdhip64; if libglowk.so is loaded before it, the system HIP runtime gets
+    # bound instead and the two runtimes in one process end in "no ROCm-capable device is detected" at the first hipSetDevice
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
