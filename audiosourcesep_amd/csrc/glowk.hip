@@ -77,12 +77,16 @@ struct glowk_handle {
   const float* d_log_scale = nullptr;
   // workspace
   int wsN = 0;
-  float *bufA = nullptr, *bufB = nullptr, *bufP = nullptr, *bufP2 = nullptr, *bufZ = nullptr, *bufC = nullptr;
+  float *bufA = nullptr, *bufB = nullptr, *bufP = nullptr, *bufZ = nullptr, *bufC = nullptr;   // bufP: 4 partials, pstride apart
+  size_t pstride = 0;
   double* bufLd = nullptr;
   double* bufStat = nullptr;    // [STAT_BLOCKS][32] partial sums + [32] means
   // input-gradient path: per-step saves of the forward pass (v, P, ReLU masks) and gradient scratch
   int saveN = 0;
-  float *saveV = nullptr, *saveP = nullptr, *saveP2 = nullptr, *bufGz = nullptr;   // saveP2: second partial of P (f16x3 forward)
+  float *saveV = nullptr, *saveP = nullptr, *bufGz = nullptr;   // saveP: save_np partials of every step's P, save_pstride apart
+  size_t save_pstride = 0;
+  int save_np = 1;
+  std::vector<int> save_parts;   // partials actually written per step by the last forward pass with saves
   unsigned short* saveM = nullptr;
   std::vector<size_t> offV, offP, offM;   // per forward-order step
   // HIP-event profiler of k_net
@@ -199,8 +203,8 @@ StepLayout step_layout(int c, int F) {
       L.RSp = o; o += fitsS ? (size_t)NF * KSS * 1024 + (size_t)2 * (NF + NCH) * NFH * 1024 : 0;
     }
     const int KSB = (9 * c + 15) / 16, NMB = (9 * CI + 31) / 32;                                      // RingH<c, 9 CI, NF, bwd>
-    const size_t ldsb = (size_t)3 * NFH * 4096 + (size_t)2 * KSB * 2048 + pad4((size_t)F + 32 * NMB) * 4 + (size_t)2 * NF * 1024;
-    const bool fitsHB = ldsb <= 160 * 1024 && NF % 4 == 0 && KSB <= 5 && NMB <= 6;
+    const size_t ldsb = (size_t)3 * (NF / 4) * 4096 + (size_t)2 * KSB * 2048 + pad4((size_t)F + 32 * NMB) * 4 + (size_t)2 * NF * 1024;   // 4-pass form
+    const bool fitsHB = ldsb <= 160 * 1024 && NF % 4 == 0 && KSB <= 9 && NMB <= 6;
     L.slotHB = fitsHB ? (size_t)NFH * 1024 : 0;
     L.RHBp = o; o += fitsHB ? (size_t)NF * KSB * 512 + (size_t)2 * (NF + NMB) * NFH * 1024 : 0;
   }
@@ -582,64 +586,101 @@ bool h3_shape16() {
   return v == 1;
 }
 
-// k_net_h3: one workgroup per 256 pixels running both hidden halves, or -- when that leaves at least half of the CUs
-// without a workgroup -- one workgroup per (256 pixels, hidden half): half the latency per launch
+// k_net_h3 / k_net_h3s launch forms.  NP = passes over the hidden width (2, or 4 where the shape needs the registers);
+// when NP workgroups per 256 pixels still fit the CUs in one round the passes become workgroups of their own (SPLIT):
+// 1/NP of the latency per launch.  Returns the number of partial P buffers the launch writes (= NP), 0 if no instance fits.
+// dry: decide only (the consumers of P need the same answer).
 template <int KIN, int MOUT, int NF, int MODE>
-void launch_h3(const NetArgs& a, hipStream_t s) {
-  const int wgs = (a.Q + 255) / 256;
-  if (2 * wgs <= num_cus()) hipLaunchKernelGGL((k_net_h3<KIN, MOUT, NF, MODE, true>), dim3(wgs, 2), dim3(512), 0, s, a);
-  else hipLaunchKernelGGL((k_net_h3<KIN, MOUT, NF, MODE, false>), dim3(wgs), dim3(512), 0, s, a);
-}
-
-template <int CI, int NF>
-int launch_net_t(const NetArgs& a, int mode, hipStream_t s) {
-  const int ntiles = (a.Q + 127) / 128;
-  switch (mode) {
-    case NET_FWD:      hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a); break;
-    case NET_FWD_SAVE: hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE>), dim3(ntiles), dim3(256), 0, s, a); break;
-    case NET_BWD:      hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD>), dim3(ntiles), dim3(256), 0, s, a); break;
-    case 3:   // f16x3 arithmetic: forward / forward with saves / backward; shapes without an instance run the exact fp32 kernel
-      if constexpr (RingS<CI, NF>::FITS) {
-        if (a.RSp && h3_shape16()) {
-          const int wgs = (a.Q + 255) / 256;
-          if (2 * wgs <= num_cus()) hipLaunchKernelGGL((k_net_h3s<CI, NF, true>), dim3(wgs, 2), dim3(512), 0, s, a);
-          else hipLaunchKernelGGL((k_net_h3s<CI, NF, false>), dim3(wgs), dim3(512), 0, s, a);
-          break;
-        }
+int launch_h3(const NetArgs& a, hipStream_t s, bool dry) {
+  constexpr bool F2 = RingH<KIN, MOUT, NF, MODE, 2>::FITS, F4 = RingH<KIN, MOUT, NF, MODE, 4>::FITS;
+  const int wgs = (a.Q + 255) / 256, cus = num_cus();
+  if constexpr (F4) {
+    if (a.max_np >= 4 && (4 * wgs <= cus || !F2)) {
+      const bool split = 4 * wgs <= cus;
+      if (!dry) {
+        if (split) hipLaunchKernelGGL((k_net_h3<KIN, MOUT, NF, MODE, 4, true>), dim3(wgs, 4), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((k_net_h3<KIN, MOUT, NF, MODE, 4, false>), dim3(wgs), dim3(512), 0, s, a);
       }
-      if constexpr (RingH<CI, 18 * CI, NF, NET_FWD>::FITS) {
-        if (a.RHp) { launch_h3<CI, 18 * CI, NF, NET_FWD>(a, s); break; }
-      }
-      hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a);
-      break;
-    case 4:
-      if constexpr (RingH<CI, 18 * CI, NF, NET_FWD_SAVE>::FITS) {
-        if (a.RHp) { launch_h3<CI, 18 * CI, NF, NET_FWD_SAVE>(a, s); break; }
-      }
-      hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE>), dim3(ntiles), dim3(256), 0, s, a);
-      break;
-    case 5:
-      if constexpr (RingH<2 * CI, 9 * CI, NF, NET_BWD>::FITS) {
-        if (a.RHp) { launch_h3<2 * CI, 9 * CI, NF, NET_BWD>(a, s); break; }
-      }
-      hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD>), dim3(ntiles), dim3(256), 0, s, a);
-      break;
-    default: return fail("bad k_net mode");
+      return 4;
+    }
   }
-  LAUNCHCHK("k_net_f32");
+  if constexpr (F2) {
+    if (!dry) {
+      if (2 * wgs <= cus) hipLaunchKernelGGL((k_net_h3<KIN, MOUT, NF, MODE, 2, true>), dim3(wgs, 2), dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((k_net_h3<KIN, MOUT, NF, MODE, 2, false>), dim3(wgs), dim3(512), 0, s, a);
+    }
+    return 2;
+  }
   return 0;
 }
 
-int launch_net_raw(int c, int F, const NetArgs& a, int mode, hipStream_t s) {
-#define NETCASE(CI_, NF_) if (c == 2 * CI_ && F == 32 * NF_) return launch_net_t<CI_, NF_>(a, mode, s);
+template <int CI, int NF>
+int launch_h3s(const NetArgs& a, hipStream_t s, bool dry) {
+  constexpr bool F2 = RingS<CI, NF, 2>::FITS, F4 = RingS<CI, NF, 4>::FITS;
+  const int wgs = (a.Q + 255) / 256, cus = num_cus();
+  if constexpr (F4) {
+    if (a.max_np >= 4 && 4 * wgs <= cus) {
+      if (!dry) hipLaunchKernelGGL((k_net_h3s<CI, NF, 4, true>), dim3(wgs, 4), dim3(512), 0, s, a);
+      return 4;
+    }
+  }
+  if constexpr (F2) {
+    if (!dry) {
+      if (2 * wgs <= cus) hipLaunchKernelGGL((k_net_h3s<CI, NF, 2, true>), dim3(wgs, 2), dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((k_net_h3s<CI, NF, 2, false>), dim3(wgs), dim3(512), 0, s, a);
+    }
+    return 2;
+  }
+  return 0;
+}
+
+// returns the number of partial P buffers written (>= 1), or -1 on error
+template <int CI, int NF>
+int launch_net_t(const NetArgs& a, int mode, hipStream_t s, bool dry) {
+  const int ntiles = (a.Q + 127) / 128;
+  int np = 0;
+  switch (mode) {
+    case NET_FWD:      if (!dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a); break;
+    case NET_FWD_SAVE: if (!dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE>), dim3(ntiles), dim3(256), 0, s, a); break;
+    case NET_BWD:      if (!dry) hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD>), dim3(ntiles), dim3(256), 0, s, a); break;
+    case 3:   // f16x3 arithmetic: forward / forward with saves / backward; shapes without an instance run the exact fp32 kernel
+      if (a.RSp && h3_shape16()) np = launch_h3s<CI, NF>(a, s, dry);
+      if (!np && a.RHp) np = launch_h3<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
+      if (!np && !dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a);
+      break;
+    case 4:
+      if (a.RHp) np = launch_h3<CI, 18 * CI, NF, NET_FWD_SAVE>(a, s, dry);
+      if (!np && !dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE>), dim3(ntiles), dim3(256), 0, s, a);
+      break;
+    case 5:
+      if (a.RHp) np = launch_h3<2 * CI, 9 * CI, NF, NET_BWD>(a, s, dry);
+      if (!np && !dry) hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD>), dim3(ntiles), dim3(256), 0, s, a);
+      break;
+    default: fail("bad k_net mode"); return -1;
+  }
+  if (!dry) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fail(std::string("k_net: ") + hipGetErrorString(e)); return -1; }
+  }
+  return np ? np : 1;
+}
+
+int launch_net_raw(int c, int F, const NetArgs& a, int mode, hipStream_t s, bool dry = false) {
+#define NETCASE(CI_, NF_) if (c == 2 * CI_ && F == 32 * NF_) return launch_net_t<CI_, NF_>(a, mode, s, dry);
   NETCASE(2, 16) NETCASE(4, 16) NETCASE(8, 16) NETCASE(16, 16)
   NETCASE(2, 4) NETCASE(4, 4) NETCASE(8, 4) NETCASE(16, 4)
 #undef NETCASE
-  return fail("unsupported (channels, n_filters) combination: c=" + std::to_string(c) + " F=" + std::to_string(F));
+  fail("unsupported (channels, n_filters) combination: c=" + std::to_string(c) + " F=" + std::to_string(F));
+  return -1;
 }
 
-int launch_net(glowk_handle* h, int level, int c, int F, const NetArgs& a, hipStream_t s, int mode = NET_FWD) {
-  if (!h->profiling) return launch_net_raw(c, F, a, mode, s);
+// np_out: number of partial P buffers the launch wrote (P + p * pstride), for the consumer
+int launch_net(glowk_handle* h, int level, int c, int F, const NetArgs& a, hipStream_t s, int mode = NET_FWD, int* np_out = nullptr) {
+  if (!h->profiling) {
+    const int np = launch_net_raw(c, F, a, mode, s);
+    if (np_out) *np_out = np;
+    return np < 0 ? 1 : 0;
+  }
   while (h->ev_pool.size() < h->ev_used + 2) {
     hipEvent_t e;
     HIPCHK(hipEventCreate(&e));
@@ -647,11 +688,12 @@ int launch_net(glowk_handle* h, int level, int c, int F, const NetArgs& a, hipSt
   }
   hipEvent_t e0 = h->ev_pool[h->ev_used], e1 = h->ev_pool[h->ev_used + 1];
   HIPCHK(hipEventRecord(e0, s));
-  const int rc = launch_net_raw(c, F, a, mode, s);
+  const int np = launch_net_raw(c, F, a, mode, s);
   HIPCHK(hipEventRecord(e1, s));
   h->ev_used += 2;
   h->ev_level.push_back(level);
-  return rc;
+  if (np_out) *np_out = np;
+  return np < 0 ? 1 : 0;
 }
 
 #define CDISPATCH(c, CALL)                                                                     \
@@ -681,13 +723,12 @@ int ensure_ws(glowk_handle* h, int N) {
   HIPCHK(hipDeviceSynchronize());
   if (h->bufA) { hipFree(h->bufA); hipFree(h->bufB); hipFree(h->bufP); hipFree(h->bufZ); hipFree(h->bufLd); }
   if (h->bufC) hipFree(h->bufC);
-  if (h->bufP2) hipFree(h->bufP2);
-  h->bufA = h->bufB = h->bufP = h->bufP2 = h->bufZ = h->bufC = nullptr; h->bufLd = nullptr; h->wsN = 0;
+  h->bufA = h->bufB = h->bufP = h->bufZ = h->bufC = nullptr; h->bufLd = nullptr; h->wsN = 0;
   const size_t E = (size_t)h->cfg.H * h->cfg.W * h->cfg.C;
   HIPCHK(hipMalloc(&h->bufA, (size_t)N * E * 4));
   HIPCHK(hipMalloc(&h->bufB, (size_t)N * E * 4));
-  HIPCHK(hipMalloc(&h->bufP, (size_t)N * E * 9 * 4));
-  HIPCHK(hipMalloc(&h->bufP2, (size_t)N * E * 9 * 4));
+  h->pstride = (size_t)N * E * 9;
+  HIPCHK(hipMalloc(&h->bufP, 4 * h->pstride * 4));
   HIPCHK(hipMalloc(&h->bufZ, (size_t)N * E * 4));
   HIPCHK(hipMalloc(&h->bufLd, (size_t)N * 8));
   h->wsN = N;
@@ -706,7 +747,7 @@ NetArgs net_args(glowk_handle* h, const Level& lv, const StepDev& sd, const floa
   a.vin = vin; a.in_stride = in_stride; a.in_off = in_off;
   a.Q = N * lv.h * lv.w; a.h = lv.h; a.w = lv.w;
   a.K1p = sd.K1p; a.ep = sd.ep; a.R0p = sd.R0p; a.mask1 = nullptr; a.mask2 = nullptr; a.P = h->bufP;
-  a.RHp = sd.RHp; a.RSp = sd.RSp; a.eph = sd.epH; a.P2 = h->bufP2; a.sc1 = sd.sc1; a.sc2 = sd.sc2; a.sc3 = sd.sc3;
+  a.RHp = sd.RHp; a.RSp = sd.RSp; a.eph = sd.epH; a.pstride = h->pstride; a.max_np = 4; a.sc1 = sd.sc1; a.sc2 = sd.sc2; a.sc3 = sd.sc3;
   return a;
 }
 
@@ -715,8 +756,8 @@ int ensure_save(glowk_handle* h, int N) {
   if (N <= h->saveN) return 0;
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipDeviceSynchronize());
-  if (h->saveV) { hipFree(h->saveV); hipFree(h->saveP); hipFree(h->saveP2); hipFree(h->saveM); hipFree(h->bufGz); }
-  h->saveV = h->saveP = h->saveP2 = h->bufGz = nullptr; h->saveM = nullptr; h->saveN = 0;
+  if (h->saveV) { hipFree(h->saveV); hipFree(h->saveP); hipFree(h->saveM); hipFree(h->bufGz); }
+  h->saveV = h->saveP = h->bufGz = nullptr; h->saveM = nullptr; h->saveN = 0;
   const int K = h->cfg.K, L = h->cfg.L, NF = h->cfg.F / 32;
   size_t v = 0, p = 0, m = 0;
   h->offV.assign((size_t)L * K, 0); h->offP.assign((size_t)L * K, 0); h->offM.assign((size_t)L * K, 0);
@@ -733,8 +774,15 @@ int ensure_save(glowk_handle* h, int N) {
   }
   const size_t E = (size_t)h->cfg.H * h->cfg.W * h->cfg.C;
   HIPCHK(hipMalloc(&h->saveV, v * 4));
-  HIPCHK(hipMalloc(&h->saveP, p * 4));
-  HIPCHK(hipMalloc(&h->saveP2, p * 4));
+  // partial P buffers per step: as many as the forward-with-saves launches of this batch size can write
+  h->save_np = N <= 256 ? 4 : 1;   // (small batches: room for the 4-pass launches whatever the probe says)
+  for (const Level& lv : h->levels) {
+    NetArgs probe = net_args(h, lv, lv.dev[0], nullptr, lv.c, lv.c / 2, N);
+    h->save_np = std::max(h->save_np, launch_net_raw(lv.c, h->cfg.F, probe, 4, nullptr, true));
+  }
+  h->save_pstride = p;
+  h->save_parts.assign((size_t)h->cfg.L * h->cfg.K, 1);
+  HIPCHK(hipMalloc(&h->saveP, (size_t)h->save_np * p * 4));
   HIPCHK(hipMalloc(&h->saveM, m * 2));
   HIPCHK(hipMalloc(&h->bufGz, (size_t)N * E * 4));
   if (!h->bufC) HIPCHK(hipMalloc(&h->bufC, (size_t)h->wsN * E * 4));
@@ -764,16 +812,18 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
       const StepDev& sd = lv.dev[k];
       const size_t sidx = (size_t)lvl * K + (K - 1 - k);
       NetArgs na = net_args(h, lv, sd, cur, lv.c, lv.c / 2, N);
-      const bool h3 = h->precision == GLOWK_PREC_F16X3 && sd.RHp;   // two-pass kernel: P arrives as two partial sums
       if (save) {
         na.P = h->saveP + h->offP[sidx];
-        na.P2 = h->saveP2 + h->offP[sidx];
+        na.pstride = h->save_pstride;
+        na.max_np = h->save_np;
         na.mask1 = h->saveM + h->offM[sidx];
         na.mask2 = na.mask1 + blocks * NF * 64;
       }
-      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, h->precision == GLOWK_PREC_F16X3 ? (save ? 4 : 3) : (save ? NET_FWD_SAVE : NET_FWD))) return rc;
+      int np = 1;   // the f16x3 kernels leave P as np partial sums (one per pass over the hidden width)
+      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, h->precision == GLOWK_PREC_F16X3 ? (save ? 4 : 3) : (save ? NET_FWD_SAVE : NET_FWD), &np)) return rc;
+      if (save) h->save_parts[sidx] = np;
       CoupleArgs ca;
-      ca.vin = cur; ca.P = na.P; ca.P2 = h3 ? na.P2 : nullptr; ca.b3 = sd.b3; ca.logdet = h->bufLd; ca.log_s_out = nullptr; ca.t_out = nullptr;
+      ca.vin = cur; ca.P = na.P; ca.np = np; ca.pstride = na.pstride; ca.b3 = sd.b3; ca.logdet = h->bufLd; ca.log_s_out = nullptr; ca.t_out = nullptr;
       ca.Q = (int)Q; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0;
       float* next = save && k > 0 ? h->saveV + h->offV[sidx + 1] : oth;
       if (k > 0) {
@@ -822,23 +872,22 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
     const Level& lv = h->levels[lvl];
     const int Q = N * lv.h * lv.w;
     const size_t blocks = (((size_t)Q + 127) / 128) * 4;
-    bool pg2_live = false;          // the previous network launch left a second partial of Pg in bufP2
+    int npg = 1;                    // partials of Pg the previous network launch of this level left in bufP
     for (int k = 0; k < K; ++k) {   // reverse of the forward order K-1 .. 0
       const StepDev& sd = lv.dev[k];
       const size_t sidx = (size_t)lvl * K + (K - 1 - k);
       BwdArgs ba;
       ba.Q = Q; ba.h = lv.h; ba.w = lv.w;
-      const bool h3f = h->precision == GLOWK_PREC_F16X3 && sd.RHp;    // how this step's forward pass ran
-      ba.v = h->saveV + h->offV[sidx]; ba.P = h->saveP + h->offP[sidx]; ba.P2 = h3f ? h->saveP2 + h->offP[sidx] : nullptr; ba.b3 = sd.b3;
+      ba.v = h->saveV + h->offV[sidx]; ba.P = h->saveP + h->offP[sidx]; ba.np = h->save_parts[sidx]; ba.pstride = h->save_pstride; ba.b3 = sd.b3;
       ba.g_o = g_o; ba.ghalf_out = gh_b; ba.gu_out = nullptr;
       if (k == 0) {
         // gradient wrt the block output: the latent slice itself (last block) or what k_bwd_split assembled
-        ba.ghalf_in = nullptr; ba.Pg = nullptr; ba.Pg2 = nullptr; ba.A = nullptr;
+        ba.ghalf_in = nullptr; ba.Pg = nullptr; ba.npg = 1; ba.pgstride = 0; ba.A = nullptr;
         if (lvl == L - 1) { ba.gv_direct = h->bufGz; ba.gvd_stride = h->Cl; ba.gvd_off = lv.z_off; }
         else              { ba.gv_direct = gy_src;   ba.gvd_stride = lv.c;  ba.gvd_off = 0; }
       } else {
         // merge step k-1's network gradient, go through its fused ActNorm + 1x1, then this step's coupling
-        ba.ghalf_in = gh_a; ba.Pg = Pg; ba.Pg2 = pg2_live ? h->bufP2 : nullptr; ba.gv_direct = nullptr; ba.gvd_stride = 0; ba.gvd_off = 0;
+        ba.ghalf_in = gh_a; ba.Pg = Pg; ba.npg = npg; ba.pgstride = h->pstride; ba.gv_direct = nullptr; ba.gvd_stride = 0; ba.gvd_off = 0;
         ba.A = lv.dev[k - 1].Afwd;
       }
       CDISPATCH(lv.c, hipLaunchKernelGGL((k_bwd_light<CC>), dim3(N), dim3(256), 0, s, ba));
@@ -849,17 +898,16 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       na.mask1 = h->saveM + h->offM[sidx];
       na.mask2 = na.mask1 + blocks * NF * 64;
       const bool h3b = h->precision == GLOWK_PREC_F16X3 && sd.RHBp;
-      if (h3b) { na.RHp = sd.RHBp; na.eph = nullptr; na.sc1 = sd.scb1; na.sc2 = sd.scb2; na.sc3 = sd.scb3; na.P2 = h->bufP2; }
-      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, h3b ? 5 : NET_BWD)) return rc;
-      pg2_live = h3b;
+      if (h3b) { na.RHp = sd.RHBp; na.eph = nullptr; na.sc1 = sd.scb1; na.sc2 = sd.scb2; na.sc3 = sd.scb3; }
+      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, h3b ? 5 : NET_BWD, &npg)) return rc;
     }
     // first forward step of the block (k = K-1): merge, then through its ActNorm + 1x1 -> g_u of the squeezed block input
     {
       BwdArgs ba;
       ba.Q = Q; ba.h = lv.h; ba.w = lv.w;
-      ba.ghalf_in = gh_a; ba.Pg = Pg; ba.Pg2 = pg2_live ? h->bufP2 : nullptr; ba.gv_direct = nullptr; ba.gvd_stride = 0; ba.gvd_off = 0;
+      ba.ghalf_in = gh_a; ba.Pg = Pg; ba.npg = npg; ba.pgstride = h->pstride; ba.gv_direct = nullptr; ba.gvd_stride = 0; ba.gvd_off = 0;
       ba.A = lv.dev[K - 1].Afwd;
-      ba.v = nullptr; ba.P = nullptr; ba.P2 = nullptr; ba.b3 = nullptr; ba.g_o = nullptr; ba.ghalf_out = nullptr; ba.gu_out = g_o;   // reuse g_o as g_u
+      ba.v = nullptr; ba.P = nullptr; ba.np = 1; ba.pstride = 0; ba.b3 = nullptr; ba.g_o = nullptr; ba.ghalf_out = nullptr; ba.gu_out = g_o;   // reuse g_o as g_u
       CDISPATCH(lv.c, hipLaunchKernelGGL((k_bwd_light<CC>), dim3(N), dim3(256), 0, s, ba));
       LAUNCHCHK("k_bwd_light");
     }
@@ -892,9 +940,10 @@ int run_inverse(glowk_handle* h, const float* z, int N, float* x, hipStream_t s)
     std::swap(cur, oth);
     for (int k = 0; k < K; ++k) {   // Chain.inverse: step 0 first
       const StepDev& sd = lv.dev[k];
-      if (int rc = launch_net(h, lvl, lv.c, cfg.F, net_args(h, lv, sd, cur, lv.c, lv.c / 2, N), s, h->precision == GLOWK_PREC_F16X3 ? 3 : NET_FWD)) return rc;
+      int np = 1;
+      if (int rc = launch_net(h, lvl, lv.c, cfg.F, net_args(h, lv, sd, cur, lv.c, lv.c / 2, N), s, h->precision == GLOWK_PREC_F16X3 ? 3 : NET_FWD, &np)) return rc;
       CoupleArgs ca;
-      ca.vin = cur; ca.P = h->bufP; ca.P2 = (h->precision == GLOWK_PREC_F16X3 && sd.RHp) ? h->bufP2 : nullptr; ca.b3 = sd.b3; ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
+      ca.vin = cur; ca.P = h->bufP; ca.np = np; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
       ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 1;
       ca.A = sd.Ainv; ca.b = sd.binv; ca.out = oth; ca.out_stride = lv.c; ca.out_off = 0;
       if (int rc = launch_couple(lv.c, ca, N, s)) return rc;
@@ -958,9 +1007,8 @@ int glowk_destroy(glowk_handle* h) {
   if (h->arena) hipFree(h->arena);
   if (h->bufA) { hipFree(h->bufA); hipFree(h->bufB); hipFree(h->bufP); hipFree(h->bufZ); hipFree(h->bufLd); }
   if (h->bufC) hipFree(h->bufC);
-  if (h->bufP2) hipFree(h->bufP2);
   if (h->bufStat) hipFree(h->bufStat);
-  if (h->saveV) { hipFree(h->saveV); hipFree(h->saveP); hipFree(h->saveP2); hipFree(h->saveM); hipFree(h->bufGz); }
+  if (h->saveV) { hipFree(h->saveV); hipFree(h->saveP); hipFree(h->saveM); hipFree(h->bufGz); }
   for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
   delete h;
   return 0;
@@ -1102,7 +1150,7 @@ int run_step_inplace(glowk_handle* h, int lvl, int k, float* cur, float* tmp, in
   NetArgs na = net_args(h, lv, sd, tmp, lv.c, lv.c / 2, Nl);
   if (int rc = launch_net(h, lvl, lv.c, h->cfg.F, na, s)) return rc;
   CoupleArgs ca;
-  ca.vin = tmp; ca.P = h->bufP; ca.P2 = nullptr; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
+  ca.vin = tmp; ca.P = h->bufP; ca.np = 1; ca.pstride = 0; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
   ca.out = cur; ca.out_stride = lv.c; ca.out_off = 0;
   ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
   ca.Q = Q; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0;
@@ -1364,7 +1412,8 @@ int glowk_step_forward(glowk_handle* h, int level, int step, const float* u_dev,
   const int Q = N * lv.h * lv.w;
   CDISPATCH(lv.c, hipLaunchKernelGGL((k_affine<CC>), dim3((Q + 255) / 256), dim3(256), 0, s, u_dev, Q, sd.Afwd, sd.bfwd, h->bufA));
   LAUNCHCHK("k_affine");
-  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, h->bufA, lv.c, lv.c / 2, N), s, h->precision == GLOWK_PREC_F16X3 ? 3 : NET_FWD)) return rc;
+  int np = 1;
+  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, h->bufA, lv.c, lv.c / 2, N), s, h->precision == GLOWK_PREC_F16X3 ? 3 : NET_FWD, &np)) return rc;
   if (logdet_dev) {
     // logdet accumulator starts at the step's constant h*w*(sum log_scale + sum log_S)
     PreArgs p = {0, 1, 0, 0};
@@ -1374,7 +1423,7 @@ int glowk_step_forward(glowk_handle* h, int level, int step, const float* u_dev,
     HIPCHK(hipStreamSynchronize(s));
   }
   CoupleArgs ca;
-  ca.vin = h->bufA; ca.P = h->bufP; ca.P2 = (h->precision == GLOWK_PREC_F16X3 && sd.RHp) ? h->bufP2 : nullptr; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
+  ca.vin = h->bufA; ca.P = h->bufP; ca.np = np; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
   ca.out = y_dev; ca.out_stride = lv.c; ca.out_off = 0;
   ca.logdet = logdet_dev ? h->bufLd : nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
   ca.Q = Q; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0;
@@ -1394,9 +1443,10 @@ int glowk_step_inverse(glowk_handle* h, int level, int step, const float* y_dev,
   hipStream_t s = (hipStream_t)stream;
   const Level& lv = h->levels[level];
   const StepDev& sd = lv.dev[step];
-  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, y_dev, lv.c, lv.c / 2, N), s, h->precision == GLOWK_PREC_F16X3 ? 3 : NET_FWD)) return rc;
+  int np = 1;
+  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, y_dev, lv.c, lv.c / 2, N), s, h->precision == GLOWK_PREC_F16X3 ? 3 : NET_FWD, &np)) return rc;
   CoupleArgs ca;
-  ca.vin = y_dev; ca.P = h->bufP; ca.P2 = (h->precision == GLOWK_PREC_F16X3 && sd.RHp) ? h->bufP2 : nullptr; ca.b3 = sd.b3; ca.A = sd.Ainv; ca.b = sd.binv;
+  ca.vin = y_dev; ca.P = h->bufP; ca.np = np; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.A = sd.Ainv; ca.b = sd.binv;
   ca.out = u_dev; ca.out_stride = lv.c; ca.out_off = 0;
   ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
   ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 1;
@@ -1410,9 +1460,10 @@ int glowk_coupling_net(glowk_handle* h, int level, int step, const float* xb_dev
   hipStream_t s = (hipStream_t)stream;
   const Level& lv = h->levels[level];
   const StepDev& sd = lv.dev[step];
-  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, xb_dev, lv.c / 2, 0, N), s, h->precision == GLOWK_PREC_F16X3 ? 3 : NET_FWD)) return rc;
+  int np = 1;
+  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, xb_dev, lv.c / 2, 0, N), s, h->precision == GLOWK_PREC_F16X3 ? 3 : NET_FWD, &np)) return rc;
   CoupleArgs ca;
-  ca.vin = nullptr; ca.P = h->bufP; ca.P2 = (h->precision == GLOWK_PREC_F16X3 && sd.RHp) ? h->bufP2 : nullptr; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
+  ca.vin = nullptr; ca.P = h->bufP; ca.np = np; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
   ca.out = nullptr; ca.out_stride = 0; ca.out_off = 0;
   ca.logdet = nullptr; ca.log_s_out = log_s_dev; ca.t_out = t_dev;
   ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0;

@@ -44,7 +44,8 @@ struct NetArgs {
   unsigned short* mask1; // [blocks of 32 px][NF][64 lanes] ReLU mask bits of conv1 (NET_FWD_SAVE writes, NET_BWD reads)
   unsigned short* mask2; // same for conv2
   float* P;              // [9*CO][Q]
-  float* P2;             // f16x3: partial sums of the second hidden half
+  size_t pstride;        // f16x3: the pass-p partial sums of P go to P + p * pstride (the consumer adds the partials)
+  int max_np;            // host side: how many partial buffers P has room for (caps the number of passes)
   const float4* RHp;     // f16x3 image (RingH) of the network this launch runs (forward or backward), or null
   const float* eph;      // forward: [conv2 accumulator init (F) | per-row constants of P (32 NMT)], see pack_step
   const float4* RSp;     // the forward network's image for the 16x16x32 kernel (RingS; same constants and scales), or null
@@ -77,13 +78,18 @@ struct Ring1 {
   static constexpr int KS1 = (9 * KIN) / 2;
   static constexpr int MAIN4 = NF * 256;
   static constexpr int K1PIECES_FULL = (KS1 * 256 + 1023) / 1024;
-  // the small conv's operands ride in the ring when the LDS allows it; otherwise (9*KIN = 144 at n_filters 512 only)
-  // they are loaded from global memory per step, each load serialised behind the DMA in flight (slow path)
+  // the small conv's operands ride in the ring when the LDS allows it; otherwise (9*KIN = 144 at n_filters 512 only) they
+  // get ONE buffer of their own, refilled during the main contraction of the previous block, at the price of a second
+  // barrier per step (the buffer is requested and consumed between the same two ring barriers)
   static constexpr bool K1_IN_RING = (size_t)2 * (MAIN4 + K1PIECES_FULL * 64) * 16 + (size_t)6 * NF * 32 * 4 <= 160 * 1024;
   static constexpr int K1PIECES = K1_IN_RING ? K1PIECES_FULL : 0;
+  // (K = 288 at c = 32 fits neither: those operands are loaded from global memory per step, each load serialised behind
+  // the DMA in flight -- the 4-level graphs' last level only)
+  static constexpr bool K1_IN_BUF = !K1_IN_RING && (size_t)2 * MAIN4 * 16 + (size_t)6 * NF * 32 * 4 + (size_t)K1PIECES_FULL * 1024 <= 160 * 1024;
+  static constexpr int K1BUF4 = K1_IN_BUF ? K1PIECES_FULL * 64 : 1;   // float4 of the separate buffer
   static constexpr int SLOT4 = MAIN4 + K1PIECES * 64;
   static constexpr int PIECES = NF * 4 + K1PIECES;
-  static constexpr size_t LDS_BYTES = (size_t)2 * SLOT4 * 16 + (size_t)6 * NF * 32 * 4;
+  static constexpr size_t LDS_BYTES = (size_t)2 * SLOT4 * 16 + (size_t)6 * NF * 32 * 4 + (K1_IN_BUF ? (size_t)K1BUF4 * 16 : 0);
   static constexpr bool FITS = LDS_BYTES <= 160 * 1024;
 };
 
@@ -118,7 +124,7 @@ __device__ __forceinline__ unsigned pick_word(const unsigned (&w)[N], int j) {
 // with the DMA of the next chunk into slot P^1.  The small conv's A operands were published with the PREVIOUS chunk
 // (slot P^1, read before the barrier that frees it).
 template <int KIN, int NF, int P, int MODE>
-__device__ __forceinline__ void net_step(const NetArgs& a, int fi, bool first, const float4* nsrc, float4* s0, float4* s1,
+__device__ __forceinline__ void net_step(const NetArgs& a, int fi, bool first, const float4* nsrc, float4* s0, float4* s1, float4* k1buf,
                                          const float* epl, const float (&xcol)[(9 * KIN) / 2], f32x16 (&acc2)[NF],
                                          const unsigned (&mk)[NF / 2], size_t wblk, int wave, unsigned voff, int lane, int hh) {
   using G = Ring1<KIN, NF>;
@@ -128,8 +134,13 @@ __device__ __forceinline__ void net_step(const NetArgs& a, int fi, bool first, c
 #pragma unroll
   for (int r = 0; r < 16; ++r) h1[r] = 0.0f;
   {
+    if (G::K1_IN_BUF && !first) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();   // chunk fi and this block's small-conv operands landed in every wave's view
+    }
     const float* k1 = G::K1_IN_RING ? reinterpret_cast<const float*>(ring_slot<P ^ 1>(s0, s1) + G::MAIN4) + lane
-                                    : a.K1p + (size_t)fi * KS1 * 64 + lane;
+                      : G::K1_IN_BUF ? reinterpret_cast<const float*>(k1buf) + lane
+                                     : a.K1p + (size_t)fi * KS1 * 64 + lane;
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[ks * 64], xcol[ks], h1, 0, 0, 0);
   }
@@ -152,11 +163,13 @@ __device__ __forceinline__ void net_step(const NetArgs& a, int fi, bool first, c
     }
     if (MODE == NET_FWD_SAVE) a.mask1[(wblk * NF + fi) * 64 + lane] = (unsigned short)bits;
   }
-  if (!first) {
+  if (!first || G::K1_IN_BUF) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // chunk fi landed in every wave's view; slot P^1 is no longer read
+    __syncthreads();   // chunk fi landed in every wave's view; slot P^1 (and the separate operand buffer) is no longer read
   }
   stage_range<0, G::PIECES>(nsrc, ring_slot<P ^ 1>(s0, s1), wave, voff);
+  if (G::K1_IN_BUF && fi + 1 < NF)
+    stage_range<0, G::K1PIECES_FULL>(reinterpret_cast<const float4*>(a.K1p + (size_t)(fi + 1) * KS1 * 64), k1buf, wave, voff);
   const float4* buf = ring_slot<P>(s0, s1);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -189,6 +202,7 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
   __shared__ float4 slot0[SLOT4];     // weight ring: two distinct objects (see ring_slot)
   __shared__ float4 slot1[SLOT4];
   __shared__ float epl[6 * F];        // b1, g1, d1, b2, g2, d2
+  __shared__ float4 k1buf[G::K1BUF4];  // small-conv operands of one block when they do not fit the ring slots
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -237,6 +251,7 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the gathers above are done before any DMA is issued
   stage_range<0, G::PIECES>(ring, slot0, wave, voff);                                           // chunk 0 -> slot 0
   if (G::K1_IN_RING) stage_range<NF * 4, (G::K1PIECES > 0 ? G::K1PIECES : 1)>(ring + (size_t)(NF - 1) * SLOT4, slot1, wave, voff);   // small-conv operands of block 0
+  else if (G::K1_IN_BUF) stage_range<0, G::K1PIECES_FULL>(reinterpret_cast<const float4*>(a.K1p), k1buf, wave, voff);
 
   f32x16 acc2[NF];
 #pragma unroll
@@ -249,8 +264,8 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
 
 #pragma nounroll
   for (int fi = 0; fi < NF; fi += 2) {   // chunk fi lives in slot fi & 1 (NF is even)
-    net_step<KIN, NF, 0, MODE>(a, fi, fi == 0, ring + (size_t)(fi + 1) * SLOT4, slot0, slot1, epl, xcol, acc2, mk2, wblk, wave, voff, lane, hh);
-    net_step<KIN, NF, 1, MODE>(a, fi + 1, false, ring + (size_t)(fi + 2) * SLOT4, slot0, slot1, epl, xcol, acc2, mk2, wblk, wave, voff, lane, hh);
+    net_step<KIN, NF, 0, MODE>(a, fi, fi == 0, ring + (size_t)(fi + 1) * SLOT4, slot0, slot1, k1buf, epl, xcol, acc2, mk2, wblk, wave, voff, lane, hh);
+    net_step<KIN, NF, 1, MODE>(a, fi + 1, false, ring + (size_t)(fi + 2) * SLOT4, slot0, slot1, k1buf, epl, xcol, acc2, mk2, wblk, wave, voff, lane, hh);
   }
 
   // ---- epilogue on the 16 accumulator tiles, in place ----
@@ -339,10 +354,12 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 // KIN = input channels of the small 3x3 convolution (c/2 forward: conv1; c backward: conv3^T), MOUT = rows of the per-tap
 // output (18 ci forward: conv3; 9 ci backward: conv1^T), MODE as for k_net_f32.
-template <int KIN, int MOUT, int NF, int MODE>
+// NP = passes over the hidden width (2, or 4: a quarter of the accumulators per pass -- for shapes whose small-conv fragments
+// need the registers, and for small grids, where each pass becomes a workgroup of its own).
+template <int KIN, int MOUT, int NF, int MODE, int NP>
 struct RingH {
   static constexpr bool BWD = MODE == NET_BWD;
-  static constexpr int NFH = NF / 2;
+  static constexpr int NFH = NF / NP;                             // accumulator tiles (hidden 32-blocks) per pass
   static constexpr int K1 = 9 * KIN;
   static constexpr int KROWS = K1 + (BWD ? 0 : 1);                // forward: a spare k row carries conv1's bias
   static constexpr int KS = (KROWS + 15) / 16;                    // small-conv k-steps of 16
@@ -358,10 +375,22 @@ struct RingH {
   static constexpr int EPN = (NF * 32 + 32 * NMT + 3) & ~3;       // conv2 accumulator init (F) | per-row constants of P (32 NMT)
   static constexpr int MASK2B = BWD ? 2 * NF * 512 * 2 : 0;       // backward: both ReLU masks of the workgroup's 8 column blocks
   static constexpr size_t LDS_BYTES = (size_t)3 * MAIN4 * 16 + (size_t)2 * K14 * 16 + (size_t)EPN * 4 + MASK2B;
-  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && KS <= 5 && G1N <= 3;
-  // image: small-conv operands of all blocks, then per pass main chunks 0..NF-1 and output chunks 0..NMT-1
+  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && NFH >= 2 && NFH % 2 == 0 && KS <= (NP == 2 ? 4 : 9) && G1N <= 3;   // (5 k-steps of fragments next to 128 accumulator registers spill)
+  // image (one for every NP): small-conv operands of all blocks, then per HALF of the hidden width main chunks 0..NF-1 and
+  // output chunks, tiles of NF/2 hidden blocks each; a pass of NP = 4 reads its half of every chunk
   static constexpr int K1TOT4 = NF * K14;
-  static constexpr int PASS4 = (NF + NMT) * MAIN4;
+  static constexpr int IMGH = NF / 2;                             // tiles per image chunk
+  static constexpr int IMG_MAIN4 = IMGH * 256;
+  static constexpr int IMG_PASS4 = (NF + NMT) * IMG_MAIN4;
+  static constexpr int SUBS = NP / 2;                             // passes per image half
+  __device__ static const float4* main_chunk(const float4* img, int pass, int ch) {
+    return img + K1TOT4 + (size_t)(pass / SUBS) * IMG_PASS4 + (size_t)ch * IMG_MAIN4 + (size_t)(pass % SUBS) * MAIN4;
+  }
+  __device__ static const float4* out_chunk(const float4* img, int pass, int s) {   // output chunk s of a pass (NFH tiles)
+    const int sub = pass % SUBS;
+    const int t2 = s < G0N ? sub * NFH * G0N + s * NFH : IMGH * G0N + sub * NFH * G1N + (s - G0N) * NFH;
+    return img + K1TOT4 + (size_t)(pass / SUBS) * IMG_PASS4 + (size_t)NF * IMG_MAIN4 + (size_t)t2 * 256;
+  }
   // output A tile t of a pass -> (hidden block, row tile); tiles of a group are ordered (hidden block, row tile)
   static constexpr int tile_fo(int t) { return t < NFH * G0N ? t / G0N : (t - NFH * G0N) / G1D; }
   static constexpr int tile_mt(int t) { return t < NFH * G0N ? t % G0N : G0N + (t - NFH * G0N) % G1D; }
@@ -413,7 +442,7 @@ __device__ __forceinline__ void h3_wait_barrier() {
 
 struct H3Ctx {                      // wave-uniform pointers of the kernel (LDS arrays are distinct statics: see ring_slot)
   float4 *sA, *sB, *sD, *k1s0, *k1s1;
-  const float4 *k1img, *pass_img, *next_img;
+  const float4 *k1img, *img;
   const unsigned short* mkl;        // backward: LDS copy of the masks, [which][hidden block][512 threads]
   size_t wblk;                      // 32-pixel column block of this wave
   bool wok;                         // it holds at least one pixel
@@ -445,10 +474,10 @@ __device__ __forceinline__ unsigned h3_act(const f32x16& acc, float sc, unsigned
 
 // X: small convolution of one hidden block (operands in slot KP) + activation, as the split B fragments of the main
 // contraction's two k-steps
-template <int KIN, int MOUT, int NF, int MODE, int KP, int PASS>
-__device__ __forceinline__ void h3_X(const NetArgs& a, const H3Ctx& c, int fi, const h8 (&xh)[(RingH<KIN, MOUT, NF, MODE>::KS)],
-                                     const h8 (&xl)[(RingH<KIN, MOUT, NF, MODE>::KS)], int lane, h8 (&bh)[2], h8 (&bl)[2]) {
-  using G = RingH<KIN, MOUT, NF, MODE>;
+template <int KIN, int MOUT, int NF, int MODE, int NP, int KP, int PASS>
+__device__ __forceinline__ void h3_X(const NetArgs& a, const H3Ctx& c, int fi, const h8 (&xh)[(RingH<KIN, MOUT, NF, MODE, NP>::KS)],
+                                     const h8 (&xl)[(RingH<KIN, MOUT, NF, MODE, NP>::KS)], int lane, h8 (&bh)[2], h8 (&bl)[2]) {
+  using G = RingH<KIN, MOUT, NF, MODE, NP>;
   f32x16 h1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) h1[r] = 0.0f;
@@ -476,11 +505,11 @@ __device__ __forceinline__ void h3_X(const NetArgs& a, const H3Ctx& c, int fi, c
 // reads each fragment right before its MFMA and waits: ~1000 exposed cycles per Y), and the DMA this wave owes (group 0:
 // its NFH pieces of the next main chunk, group 1: its piece of the next-but-one block's small-conv operands) is spread over
 // the groups instead of delaying the first MFMA.
-template <int KIN, int MOUT, int NF, int MODE, int TAG>
-__device__ __forceinline__ void h3_Y(const float4* slot, const h8 (&bh)[2], const h8 (&bl)[2], f32x16 (&acc2)[NF / 2], int lane, int g,
+template <int KIN, int MOUT, int NF, int MODE, int NP, int TAG>
+__device__ __forceinline__ void h3_Y(const float4* slot, const h8 (&bh)[2], const h8 (&bl)[2], f32x16 (&acc2)[NF / NP], int lane, int g,
                                      bool main_ok, const float4* main_src, float4* main_dst, const float4* k1_src, float4* k1_dst,
                                      int w4, unsigned voff) {
-  using G = RingH<KIN, MOUT, NF, MODE>;
+  using G = RingH<KIN, MOUT, NF, MODE, NP>;
   const h8* buf = reinterpret_cast<const h8*>(slot) + lane;
   const char* mb = uniform_ptr(main_src);
   constexpr int NG = G::NFH;        // groups of 6 MFMAs = (tile pair p, k-step s)
@@ -520,26 +549,26 @@ __device__ __forceinline__ void h3_Y(const float4* slot, const h8 (&bh)[2], cons
 
 // Z: output op z of a pass = half a chunk of per-tap A tiles.  The activation + split of hidden block fo happens once per
 // fused group of row tiles; a row tile is stored when its last hidden block has been added.
-template <int KIN, int MOUT, int NF, int MODE, int P0, int PASS, bool SOLO, int Z>
-__device__ __forceinline__ void h3_Z(const NetArgs& a, const H3Ctx& c, const float* epl, f32x16 (&acc2)[NF / 2],
-                                     f32x16 (&acc3)[(RingH<KIN, MOUT, NF, MODE>::G0N)], h8 (&bh)[2], h8 (&bl)[2], int g, int q, bool qok,
+template <int KIN, int MOUT, int NF, int MODE, int NP, int P0, int PASS, bool SOLO, int Z>
+__device__ __forceinline__ void h3_Z(const NetArgs& a, const H3Ctx& c, const float* epl, f32x16 (&acc2)[NF / NP],
+                                     f32x16 (&acc3)[(RingH<KIN, MOUT, NF, MODE, NP>::G0N)], h8 (&bh)[2], h8 (&bl)[2], int g, int q, bool qok,
                                      int lane, int hh) {
-  using G = RingH<KIN, MOUT, NF, MODE>;
+  using G = RingH<KIN, MOUT, NF, MODE, NP>;
   constexpr int NFH = G::NFH, M3 = G::M3;
   constexpr int S = Z >> 1;
   constexpr int P0N = (G::NMT + 1 + P0) & 1;                       // main slot of the next pass's chunk 0
   if (!g) {   // group 0 requests the later output chunks (chunk 2 as soon as the last main chunk is dead, chunk s >= 3 when chunk s-2 is) ...
     constexpr int SN = Z == 1 ? 2 : (Z >= 5 && (Z & 1)) ? (Z + 1) / 2 : 0;
     if constexpr (SN >= 2 && SN < G::NMT)
-      stage4<G::MAINP, 16 + Z>(c.pass_img + (size_t)(NF + SN) * G::MAIN4, ((NF + SN - 1 + P0) & 1) ? c.sB : c.sA, c.w4, c.voff);
-    if constexpr (PASS == 0 && !SOLO && Z == 2 * G::NMT - 1) {      // ... and, in its last op, the next pass's first chunks
-      stage4<G::MAINP, 48>(c.next_img, P0N ? c.sB : c.sA, c.w4, c.voff);
-      if constexpr (G::NMT >= 2) stage4<G::MAINP, 49>(c.next_img + (size_t)NF * G::MAIN4, c.sD, c.w4, c.voff);   // (NMT = 1: slot D still read; see h3_pass)
+      stage4<G::MAINP, 16 + Z>(G::out_chunk(c.img, PASS, SN), ((NF + SN - 1 + P0) & 1) ? c.sB : c.sA, c.w4, c.voff);
+    if constexpr (PASS + 1 < NP && !SOLO && Z == 2 * G::NMT - 1) {  // ... and, in its last op, the next pass's first chunks
+      stage4<G::MAINP, 48>(G::main_chunk(c.img, PASS + 1, 0), P0N ? c.sB : c.sA, c.w4, c.voff);
+      if constexpr (G::NMT >= 2) stage4<G::MAINP, 49>(G::out_chunk(c.img, PASS + 1, 0), c.sD, c.w4, c.voff);   // (NMT = 1: slot D still read; see h3_pass)
     }
   }
   const float4* slot = S == 0 ? c.sD : (((NF + S - 1 + P0) & 1) ? c.sB : c.sA);
   const h8* buf = reinterpret_cast<const h8*>(slot) + lane;
-  float* Pp = PASS == 0 ? a.P : a.P2;
+  float* Pp = a.P + (size_t)PASS * a.pstride;
   const float* pb = epl + NF * 32;
 #pragma unroll
   for (int i = 0; i < NFH / 2; ++i) {
@@ -571,20 +600,20 @@ __device__ __forceinline__ void h3_Z(const NetArgs& a, const H3Ctx& c, const flo
   h3_wait_barrier();
 }
 
-template <int KIN, int MOUT, int NF, int MODE, int P0, int PASS, bool SOLO, int... Z>
-__device__ __forceinline__ void h3_tail(const NetArgs& a, const H3Ctx& c, const float* epl, f32x16 (&acc2)[NF / 2],
-                                        f32x16 (&acc3)[(RingH<KIN, MOUT, NF, MODE>::G0N)], h8 (&bh)[2], h8 (&bl)[2], int g, int q, bool qok,
+template <int KIN, int MOUT, int NF, int MODE, int NP, int P0, int PASS, bool SOLO, int... Z>
+__device__ __forceinline__ void h3_tail(const NetArgs& a, const H3Ctx& c, const float* epl, f32x16 (&acc2)[NF / NP],
+                                        f32x16 (&acc3)[(RingH<KIN, MOUT, NF, MODE, NP>::G0N)], h8 (&bh)[2], h8 (&bl)[2], int g, int q, bool qok,
                                         int lane, int hh, std::integer_sequence<int, Z...>) {
-  (h3_Z<KIN, MOUT, NF, MODE, P0, PASS, SOLO, Z>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, hh), ...);
+  (h3_Z<KIN, MOUT, NF, MODE, NP, P0, PASS, SOLO, Z>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, hh), ...);
 }
 
 // one pass (hidden half PASS) of the workgroup's 256 pixels.  g = this wave's group: its ops run in phase (op index + g).
 // SOLO: the workgroup runs this pass only (the other half belongs to another workgroup).
-template <int KIN, int MOUT, int NF, int MODE, int P0, int PASS, bool SOLO>
+template <int KIN, int MOUT, int NF, int MODE, int NP, int P0, int PASS, bool SOLO>
 __device__ __forceinline__ void h3_pass(const NetArgs& a, const H3Ctx& c, const float* epl,
-                                        const h8 (&xh)[(RingH<KIN, MOUT, NF, MODE>::KS)], const h8 (&xl)[(RingH<KIN, MOUT, NF, MODE>::KS)],
+                                        const h8 (&xh)[(RingH<KIN, MOUT, NF, MODE, NP>::KS)], const h8 (&xl)[(RingH<KIN, MOUT, NF, MODE, NP>::KS)],
                                         int g, int q, bool qok, int lane, int hh) {
-  using G = RingH<KIN, MOUT, NF, MODE>;
+  using G = RingH<KIN, MOUT, NF, MODE, NP>;
   constexpr int NFH = G::NFH, NMT = G::NMT;
   constexpr int f2base = PASS * NFH * 32;
   f32x16 acc2[NFH];
@@ -599,30 +628,40 @@ __device__ __forceinline__ void h3_pass(const NetArgs& a, const H3Ctx& c, const 
     // X_i0 | Y_i0 | X_i0+1 | Y_i0+1.  During its Y ops group 0 requests the next main chunk (after the last one the second
     // output chunk) into the other main slot, group 1 the small-conv operands of block i+2 (wrapping into the next pass)
     // into the slot its X_i has just finished with.
-    h3_X<KIN, MOUT, NF, MODE, 0, PASS>(a, c, i0, xh, xl, lane, bh, bl);
+    h3_X<KIN, MOUT, NF, MODE, NP, 0, PASS>(a, c, i0, xh, xl, lane, bh, bl);
     h3_wait_barrier();
-    if (PASS == 1 && !SOLO && NMT == 1 && i0 == 0 && !g)   // single output chunk: slot D of pass 0 is read until the phase before this one
-      stage4<G::MAINP, 50>(c.pass_img + (size_t)NF * G::MAIN4, c.sD, c.w4, c.voff);
-    h3_Y<KIN, MOUT, NF, MODE, 1>(P0 ? c.sB : c.sA, bh, bl, acc2, lane, g, true, c.pass_img + (size_t)(i0 + 1) * G::MAIN4, P0 ? c.sA : c.sB,
-                                 c.k1img + (size_t)((i0 + 2) % NF) * G::K14, c.k1s0, c.w4, c.voff);
+    if (PASS >= 1 && !SOLO && NMT == 1 && i0 == 0 && !g)   // single output chunk: slot D of the previous pass is read until the phase before this one
+      stage4<G::MAINP, 50>(G::out_chunk(c.img, PASS, 0), c.sD, c.w4, c.voff);
+    h3_Y<KIN, MOUT, NF, MODE, NP, 1>(P0 ? c.sB : c.sA, bh, bl, acc2, lane, g, true, G::main_chunk(c.img, PASS, i0 + 1), P0 ? c.sA : c.sB,
+                                     c.k1img + (size_t)((i0 + 2) % NF) * G::K14, c.k1s0, c.w4, c.voff);
     h3_barrier();
-    h3_X<KIN, MOUT, NF, MODE, 1, PASS>(a, c, i0 + 1, xh, xl, lane, bh, bl);
+    h3_X<KIN, MOUT, NF, MODE, NP, 1, PASS>(a, c, i0 + 1, xh, xl, lane, bh, bl);
     h3_wait_barrier();
-    h3_Y<KIN, MOUT, NF, MODE, 2>(P0 ? c.sA : c.sB, bh, bl, acc2, lane, g, i0 + 2 < NF || NMT >= 2,
-                                 c.pass_img + (size_t)(i0 + 2 < NF ? i0 + 2 : NF + 1) * G::MAIN4, P0 ? c.sB : c.sA,
-                                 c.k1img + (size_t)((i0 + 3) % NF) * G::K14, c.k1s1, c.w4, c.voff);
+    h3_Y<KIN, MOUT, NF, MODE, NP, 2>(P0 ? c.sA : c.sB, bh, bl, acc2, lane, g, i0 + 2 < NF || NMT >= 2,
+                                     i0 + 2 < NF ? G::main_chunk(c.img, PASS, i0 + 2) : G::out_chunk(c.img, PASS, 1), P0 ? c.sB : c.sA,
+                                     c.k1img + (size_t)((i0 + 3) % NF) * G::K14, c.k1s1, c.w4, c.voff);
     h3_barrier();
   }
 
   // the 3x3 output convolution as per-tap 1x1 partial sums over this pass's hidden half (the consumer adds the two passes)
   f32x16 acc3[G::G0N];
-  h3_tail<KIN, MOUT, NF, MODE, P0, PASS, SOLO>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, hh, std::make_integer_sequence<int, 2 * NMT>());
+  h3_tail<KIN, MOUT, NF, MODE, NP, P0, PASS, SOLO>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, hh, std::make_integer_sequence<int, 2 * NMT>());
 }
 
-// SPLIT: grid.y = 2 and each workgroup runs ONE pass (small grids: half the latency per launch on twice the workgroups)
-template <int KIN, int MOUT, int NF, int MODE, bool SPLIT>
+// all passes of a workgroup, one after the other (the slot parity of a pass's first chunk follows from the previous pass)
+template <int KIN, int MOUT, int NF, int MODE, int NP, int PASS, int P0>
+__device__ __forceinline__ void h3_passes(const NetArgs& a, const H3Ctx& c, const float* epl,
+                                          const h8 (&xh)[(RingH<KIN, MOUT, NF, MODE, NP>::KS)], const h8 (&xl)[(RingH<KIN, MOUT, NF, MODE, NP>::KS)],
+                                          int g, int q, bool qok, int lane, int hh) {
+  h3_pass<KIN, MOUT, NF, MODE, NP, P0, PASS, false>(a, c, epl, xh, xl, g, q, qok, lane, hh);
+  if constexpr (PASS + 1 < NP)
+    h3_passes<KIN, MOUT, NF, MODE, NP, PASS + 1, (RingH<KIN, MOUT, NF, MODE, NP>::NMT + 1 + P0) & 1>(a, c, epl, xh, xl, g, q, qok, lane, hh);
+}
+
+// SPLIT: grid.y = NP and each workgroup runs ONE pass (small grids: 1/NP of the latency per launch on NP times the workgroups)
+template <int KIN, int MOUT, int NF, int MODE, int NP, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
-  using G = RingH<KIN, MOUT, NF, MODE>;
+  using G = RingH<KIN, MOUT, NF, MODE, NP>;
   constexpr int K1 = G::K1;
   constexpr int KS = G::KS;
   constexpr int SGN = (MODE == NET_BWD) ? -1 : 1;   // backward gathers at q - d(tap)
@@ -649,8 +688,7 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
   c.sA = slotA; c.sB = slotB; c.sD = slotD; c.k1s0 = k1slot0; c.k1s1 = k1slot1;
   c.k1img = a.RHp;
   const int solo_pass = SPLIT ? (int)blockIdx.y : 0;
-  c.pass_img = a.RHp + G::K1TOT4 + (size_t)solo_pass * G::PASS4;
-  c.next_img = a.RHp + G::K1TOT4 + G::PASS4;
+  c.img = a.RHp;
   c.mkl = mkl;
   c.wblk = (size_t)blockIdx.x * 8 + wave;
   c.wok = (long)c.wblk * 32 < a.Q;
@@ -692,8 +730,8 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // gathers done before any DMA is issued
   if (!g) {
-    stage4<G::MAINP, 60>(c.pass_img, slotA, c.w4, c.voff);                                // main chunk 0
-    stage4<G::MAINP, 61>(c.pass_img + (size_t)NF * G::MAIN4, slotD, c.w4, c.voff);        // first output chunk
+    stage4<G::MAINP, 60>(G::main_chunk(c.img, solo_pass, 0), slotA, c.w4, c.voff);       // main chunk 0
+    stage4<G::MAINP, 61>(G::out_chunk(c.img, solo_pass, 0), slotD, c.w4, c.voff);        // first output chunk
   } else {
     stage4<G::K1P, 62>(c.k1img, k1slot0, c.w4, c.voff);                                   // small-conv operands of blocks 0, 1
     stage4<G::K1P, 63>(c.k1img + G::K14, k1slot1, c.w4, c.voff);
@@ -703,12 +741,14 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
 
   if (g) h3_barrier();                                     // group 1 runs one phase behind group 0
   if constexpr (SPLIT) {
-    if (solo_pass == 0) h3_pass<KIN, MOUT, NF, MODE, 0, 0, true>(a, c, epl, xh, xl, g, q, qok, lane, hh);
-    else h3_pass<KIN, MOUT, NF, MODE, 0, 1, true>(a, c, epl, xh, xl, g, q, qok, lane, hh);
+    if (solo_pass == 0) h3_pass<KIN, MOUT, NF, MODE, NP, 0, 0, true>(a, c, epl, xh, xl, g, q, qok, lane, hh);
+    else if (solo_pass == 1) h3_pass<KIN, MOUT, NF, MODE, NP, 0, 1, true>(a, c, epl, xh, xl, g, q, qok, lane, hh);
+    else if constexpr (NP > 2) {
+      if (solo_pass == 2) h3_pass<KIN, MOUT, NF, MODE, NP, 0, 2, true>(a, c, epl, xh, xl, g, q, qok, lane, hh);
+      else h3_pass<KIN, MOUT, NF, MODE, NP, 0, 3, true>(a, c, epl, xh, xl, g, q, qok, lane, hh);
+    }
   } else {
-    h3_pass<KIN, MOUT, NF, MODE, 0, 0, false>(a, c, epl, xh, xl, g, q, qok, lane, hh);
-    c.pass_img = c.next_img;
-    h3_pass<KIN, MOUT, NF, MODE, (G::NMT + 1) & 1, 1, false>(a, c, epl, xh, xl, g, q, qok, lane, hh);
+    h3_passes<KIN, MOUT, NF, MODE, NP, 0, 0>(a, c, epl, xh, xl, g, q, qok, lane, hh);
   }
   if (!g) h3_barrier();                                    // group 0 idles through the last phase
 }
@@ -726,9 +766,9 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int CI, int NF>
+template <int CI, int NF, int NP>
 struct RingS {
-  static constexpr int NFH = NF / 2;                              // hidden 32-channel blocks per pass
+  static constexpr int NFH = NF / NP;                             // hidden 32-channel blocks per pass
   static constexpr int NRB = 2 * NFH;                             // 16-row blocks per pass
   static constexpr int K1 = 9 * CI;
   static constexpr int KS = (K1 + 1 + 31) / 32;                   // conv1 k-steps of 32 (a spare row carries the bias)
@@ -746,9 +786,24 @@ struct RingS {
   static constexpr int G1D = G1N > 0 ? G1N : 1;
   static constexpr int EPN = (NF * 32 + 16 * NMT + 3) & ~3;       // conv2 accumulator init (F) | per-row constants of P
   static constexpr size_t LDS_BYTES = (size_t)3 * MAIN4 * 16 + (size_t)2 * K14 * 16 + (size_t)EPN * 4;
-  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && KS <= 3 && G1N <= 6 && NCH >= 2;
+  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && NFH >= 2 && KS <= 3 && G1N <= 6 && NCH >= 2 &&
+                               (G1N == 0 || (NFH * G0N) % TPC == 0);
+  // image (one for every NP, laid out for NP = 2): conv1 operands of all blocks, then per half of the hidden width the main
+  // chunks (NF row blocks) and the conv3 tiles of NF/2 hidden blocks, 16 tiles per chunk; a pass of NP = 4 reads its half
   static constexpr int K1TOT4 = NF * K14;
-  static constexpr int PASS4 = (NF + NCH) * MAIN4;
+  static constexpr int IMGH = NF / 2;
+  static constexpr int IMG_MAIN4 = IMGH * 256;
+  static constexpr int IMG_NCH = (IMGH * NMT + 2 * IMGH - 1) / (2 * IMGH);
+  static constexpr int IMG_PASS4 = (NF + IMG_NCH) * IMG_MAIN4;
+  static constexpr int SUBS = NP / 2;
+  __device__ static const float4* main_chunk(const float4* img, int pass, int ch) {
+    return img + K1TOT4 + (size_t)(pass / SUBS) * IMG_PASS4 + (size_t)ch * IMG_MAIN4 + (size_t)(pass % SUBS) * MAIN4;
+  }
+  __device__ static const float4* out_chunk(const float4* img, int pass, int s) {   // conv3 chunk s of a pass (TPC tiles)
+    const int sub = pass % SUBS, t4 = s * TPC;
+    const int t2 = t4 < NFH * G0N ? sub * NFH * G0N + t4 : IMGH * G0N + sub * NFH * G1N + (t4 - NFH * G0N);
+    return img + K1TOT4 + (size_t)(pass / SUBS) * IMG_PASS4 + (size_t)NF * IMG_MAIN4 + (size_t)t2 * 128;
+  }
   static constexpr int tile_fo(int t) { return t < NFH * G0N ? t / G0N : (t - NFH * G0N) / G1D; }
   static constexpr int tile_mt(int t) { return t < NFH * G0N ? t % G0N : G0N + (t - NFH * G0N) % G1D; }
 };
@@ -771,10 +826,10 @@ __device__ __forceinline__ void h3s_act(const f32x4& r0, const f32x4& r1, float 
   split8(v, bh, bl);
 }
 
-template <int CI, int NF, int KP>
-__device__ __forceinline__ void h3s_X(const NetArgs& a, const H3Ctx& c, const h8 (&xh)[(RingS<CI, NF>::KS)][2],
-                                      const h8 (&xl)[(RingS<CI, NF>::KS)][2], int lane, h8 (&bh)[2], h8 (&bl)[2]) {
-  using G = RingS<CI, NF>;
+template <int CI, int NF, int NP, int KP>
+__device__ __forceinline__ void h3s_X(const NetArgs& a, const H3Ctx& c, const h8 (&xh)[(RingS<CI, NF, NP>::KS)][2],
+                                      const h8 (&xl)[(RingS<CI, NF, NP>::KS)][2], int lane, h8 (&bh)[2], h8 (&bl)[2]) {
+  using G = RingS<CI, NF, NP>;
   f32x4 h1[2][2];   // [row block][pixel half]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -798,11 +853,11 @@ __device__ __forceinline__ void h3s_X(const NetArgs& a, const H3Ctx& c, const h8
 
 // Y: conv2 contribution of one hidden block (one k-step of 32) to the pass's NRB x 2 accumulator tiles; same pipelining and
 // DMA duties as h3_Y (groups of 12 MFMAs = two row blocks x two pixel halves x three split terms)
-template <int CI, int NF, int TAG>
-__device__ __forceinline__ void h3s_Y(const float4* slot, const h8 (&bh)[2], const h8 (&bl)[2], f32x4 (&acc2)[(RingS<CI, NF>::NRB)][2],
+template <int CI, int NF, int NP, int TAG>
+__device__ __forceinline__ void h3s_Y(const float4* slot, const h8 (&bh)[2], const h8 (&bl)[2], f32x4 (&acc2)[(RingS<CI, NF, NP>::NRB)][2],
                                       int lane, int g, bool main_ok, const float4* main_src, float4* main_dst, const float4* k1_src,
                                       float4* k1_dst, int w4, unsigned voff) {
-  using G = RingS<CI, NF>;
+  using G = RingS<CI, NF, NP>;
   const h8* buf = reinterpret_cast<const h8*>(slot) + lane;
   const char* mb = uniform_ptr(main_src);
   constexpr int NG = G::NRB / 2;
@@ -850,26 +905,26 @@ __device__ __forceinline__ void h3s_Y(const float4* slot, const h8 (&bh)[2], con
 }
 
 // Z: conv3 op z of a pass = half a chunk of A tiles (16 rows x one hidden block)
-template <int CI, int NF, int P0, int PASS, bool SOLO, int Z>
-__device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const float* epl, f32x4 (&acc2)[(RingS<CI, NF>::NRB)][2],
-                                      f32x4 (&acc3)[(RingS<CI, NF>::G0N)][2], h8 (&bh)[2], h8 (&bl)[2], int g, const int (&q)[2],
+template <int CI, int NF, int NP, int P0, int PASS, bool SOLO, int Z>
+__device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const float* epl, f32x4 (&acc2)[(RingS<CI, NF, NP>::NRB)][2],
+                                      f32x4 (&acc3)[(RingS<CI, NF, NP>::G0N)][2], h8 (&bh)[2], h8 (&bl)[2], int g, const int (&q)[2],
                                       const bool (&qok)[2], int lane, int kq) {
-  using G = RingS<CI, NF>;
+  using G = RingS<CI, NF, NP>;
   constexpr int NFH = G::NFH, M3 = G::M3, TPC = G::TPC;
   constexpr int S = Z >> 1;
   constexpr int P0N = (G::NCH + 1 + P0) & 1;
   if (!g) {
     constexpr int SN = Z == 1 ? 2 : (Z >= 5 && (Z & 1)) ? (Z + 1) / 2 : 0;
     if constexpr (SN >= 2 && SN < G::NCH)
-      stage4<G::MAINP, 16 + Z>(c.pass_img + (size_t)(NF + SN) * G::MAIN4, ((NF + SN - 1 + P0) & 1) ? c.sB : c.sA, c.w4, c.voff);
-    if constexpr (PASS == 0 && !SOLO && Z == 2 * G::NCH - 1) {
-      stage4<G::MAINP, 48>(c.next_img, P0N ? c.sB : c.sA, c.w4, c.voff);
-      stage4<G::MAINP, 49>(c.next_img + (size_t)NF * G::MAIN4, c.sD, c.w4, c.voff);
+      stage4<G::MAINP, 16 + Z>(G::out_chunk(c.img, PASS, SN), ((NF + SN - 1 + P0) & 1) ? c.sB : c.sA, c.w4, c.voff);
+    if constexpr (PASS + 1 < NP && !SOLO && Z == 2 * G::NCH - 1) {
+      stage4<G::MAINP, 48>(G::main_chunk(c.img, PASS + 1, 0), P0N ? c.sB : c.sA, c.w4, c.voff);
+      stage4<G::MAINP, 49>(G::out_chunk(c.img, PASS + 1, 0), c.sD, c.w4, c.voff);
     }
   }
   const float4* slot = S == 0 ? c.sD : (((NF + S - 1 + P0) & 1) ? c.sB : c.sA);
   const h8* buf = reinterpret_cast<const h8*>(slot) + lane;
-  float* Pp = PASS == 0 ? a.P : a.P2;
+  float* Pp = a.P + (size_t)PASS * a.pstride;
   const float* pb = epl + NF * 32;
 #pragma unroll
   for (int i = 0; i < TPC / 2; ++i) {
@@ -903,17 +958,17 @@ __device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const fl
   h3_wait_barrier();
 }
 
-template <int CI, int NF, int P0, int PASS, bool SOLO, int... Z>
-__device__ __forceinline__ void h3s_tail(const NetArgs& a, const H3Ctx& c, const float* epl, f32x4 (&acc2)[(RingS<CI, NF>::NRB)][2],
-                                         f32x4 (&acc3)[(RingS<CI, NF>::G0N)][2], h8 (&bh)[2], h8 (&bl)[2], int g, const int (&q)[2],
+template <int CI, int NF, int NP, int P0, int PASS, bool SOLO, int... Z>
+__device__ __forceinline__ void h3s_tail(const NetArgs& a, const H3Ctx& c, const float* epl, f32x4 (&acc2)[(RingS<CI, NF, NP>::NRB)][2],
+                                         f32x4 (&acc3)[(RingS<CI, NF, NP>::G0N)][2], h8 (&bh)[2], h8 (&bl)[2], int g, const int (&q)[2],
                                          const bool (&qok)[2], int lane, int kq, std::integer_sequence<int, Z...>) {
-  (h3s_Z<CI, NF, P0, PASS, SOLO, Z>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, kq), ...);
+  (h3s_Z<CI, NF, NP, P0, PASS, SOLO, Z>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, kq), ...);
 }
 
-template <int CI, int NF, int P0, int PASS, bool SOLO>
-__device__ __forceinline__ void h3s_pass(const NetArgs& a, const H3Ctx& c, const float* epl, const h8 (&xh)[(RingS<CI, NF>::KS)][2],
-                                         const h8 (&xl)[(RingS<CI, NF>::KS)][2], int g, const int (&q)[2], const bool (&qok)[2], int lane, int kq) {
-  using G = RingS<CI, NF>;
+template <int CI, int NF, int NP, int P0, int PASS, bool SOLO>
+__device__ __forceinline__ void h3s_pass(const NetArgs& a, const H3Ctx& c, const float* epl, const h8 (&xh)[(RingS<CI, NF, NP>::KS)][2],
+                                         const h8 (&xl)[(RingS<CI, NF, NP>::KS)][2], int g, const int (&q)[2], const bool (&qok)[2], int lane, int kq) {
+  using G = RingS<CI, NF, NP>;
   constexpr int NRB = G::NRB;
   constexpr int f2base = PASS * G::NFH * 32;
   f32x4 acc2[NRB][2];
@@ -928,24 +983,31 @@ __device__ __forceinline__ void h3s_pass(const NetArgs& a, const H3Ctx& c, const
   h8 bh[2], bl[2];
 #pragma nounroll
   for (int i0 = 0; i0 < NF; i0 += 2) {
-    h3s_X<CI, NF, 0>(a, c, xh, xl, lane, bh, bl);
+    h3s_X<CI, NF, NP, 0>(a, c, xh, xl, lane, bh, bl);
     h3_wait_barrier();
-    h3s_Y<CI, NF, 1>(P0 ? c.sB : c.sA, bh, bl, acc2, lane, g, true, c.pass_img + (size_t)(i0 + 1) * G::MAIN4, P0 ? c.sA : c.sB,
-                     c.k1img + (size_t)((i0 + 2) % NF) * G::K14, c.k1s0, c.w4, c.voff);
+    h3s_Y<CI, NF, NP, 1>(P0 ? c.sB : c.sA, bh, bl, acc2, lane, g, true, G::main_chunk(c.img, PASS, i0 + 1), P0 ? c.sA : c.sB,
+                         c.k1img + (size_t)((i0 + 2) % NF) * G::K14, c.k1s0, c.w4, c.voff);
     h3_barrier();
-    h3s_X<CI, NF, 1>(a, c, xh, xl, lane, bh, bl);
+    h3s_X<CI, NF, NP, 1>(a, c, xh, xl, lane, bh, bl);
     h3_wait_barrier();
-    h3s_Y<CI, NF, 2>(P0 ? c.sA : c.sB, bh, bl, acc2, lane, g, true, c.pass_img + (size_t)(i0 + 2 < NF ? i0 + 2 : NF + 1) * G::MAIN4,
-                     P0 ? c.sB : c.sA, c.k1img + (size_t)((i0 + 3) % NF) * G::K14, c.k1s1, c.w4, c.voff);
+    h3s_Y<CI, NF, NP, 2>(P0 ? c.sA : c.sB, bh, bl, acc2, lane, g, true, i0 + 2 < NF ? G::main_chunk(c.img, PASS, i0 + 2) : G::out_chunk(c.img, PASS, 1),
+                         P0 ? c.sB : c.sA, c.k1img + (size_t)((i0 + 3) % NF) * G::K14, c.k1s1, c.w4, c.voff);
     h3_barrier();
   }
   f32x4 acc3[G::G0N][2];
-  h3s_tail<CI, NF, P0, PASS, SOLO>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, kq, std::make_integer_sequence<int, 2 * G::NCH>());
+  h3s_tail<CI, NF, NP, P0, PASS, SOLO>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, kq, std::make_integer_sequence<int, 2 * G::NCH>());
 }
 
-template <int CI, int NF, bool SPLIT>
+template <int CI, int NF, int NP, int PASS, int P0>
+__device__ __forceinline__ void h3s_passes(const NetArgs& a, const H3Ctx& c, const float* epl, const h8 (&xh)[(RingS<CI, NF, NP>::KS)][2],
+                                           const h8 (&xl)[(RingS<CI, NF, NP>::KS)][2], int g, const int (&q)[2], const bool (&qok)[2], int lane, int kq) {
+  h3s_pass<CI, NF, NP, P0, PASS, false>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+  if constexpr (PASS + 1 < NP) h3s_passes<CI, NF, NP, PASS + 1, (RingS<CI, NF, NP>::NCH + 1 + P0) & 1>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+}
+
+template <int CI, int NF, int NP, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
-  using G = RingS<CI, NF>;
+  using G = RingS<CI, NF, NP>;
   constexpr int K1 = G::K1;
   constexpr int KS = G::KS;
   static_assert(G::FITS, "shape");
@@ -971,8 +1033,7 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
   c.sA = slotA; c.sB = slotB; c.sD = slotD; c.k1s0 = k1slot0; c.k1s1 = k1slot1;
   const int solo_pass = SPLIT ? (int)blockIdx.y : 0;
   c.k1img = a.RSp;
-  c.pass_img = a.RSp + G::K1TOT4 + (size_t)solo_pass * G::PASS4;
-  c.next_img = a.RSp + G::K1TOT4 + G::PASS4;
+  c.img = a.RSp;
   c.mkl = nullptr;
   c.wblk = (size_t)blockIdx.x * 8 + wave;
   c.wok = (long)c.wblk * 32 < a.Q;
@@ -1010,8 +1071,8 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
   for (int i = tid; i < G::EPN; i += 512) epl[i] = a.eph[i];   // RingS::EPN <= RingH::EPN, same content
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (!g) {
-    stage4<G::MAINP, 60>(c.pass_img, slotA, c.w4, c.voff);
-    stage4<G::MAINP, 61>(c.pass_img + (size_t)NF * G::MAIN4, slotD, c.w4, c.voff);
+    stage4<G::MAINP, 60>(G::main_chunk(c.img, solo_pass, 0), slotA, c.w4, c.voff);
+    stage4<G::MAINP, 61>(G::out_chunk(c.img, solo_pass, 0), slotD, c.w4, c.voff);
   } else {
     stage4<G::K1P, 62>(c.k1img, k1slot0, c.w4, c.voff);
     stage4<G::K1P, 63>(c.k1img + G::K14, k1slot1, c.w4, c.voff);
@@ -1021,12 +1082,14 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
 
   if (g) h3_barrier();
   if constexpr (SPLIT) {
-    if (solo_pass == 0) h3s_pass<CI, NF, 0, 0, true>(a, c, epl, xh, xl, g, q, qok, lane, kq);
-    else h3s_pass<CI, NF, 0, 1, true>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+    if (solo_pass == 0) h3s_pass<CI, NF, NP, 0, 0, true>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+    else if (solo_pass == 1) h3s_pass<CI, NF, NP, 0, 1, true>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+    else if constexpr (NP > 2) {
+      if (solo_pass == 2) h3s_pass<CI, NF, NP, 0, 2, true>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+      else h3s_pass<CI, NF, NP, 0, 3, true>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+    }
   } else {
-    h3s_pass<CI, NF, 0, 0, false>(a, c, epl, xh, xl, g, q, qok, lane, kq);
-    c.pass_img = c.next_img;
-    h3s_pass<CI, NF, (G::NCH + 1) & 1, 1, false>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+    h3s_passes<CI, NF, NP, 0, 0>(a, c, epl, xh, xl, g, q, qok, lane, kq);
   }
   if (!g) h3_barrier();
 }
@@ -1154,7 +1217,8 @@ __global__ __launch_bounds__(256) void k_pre_only(const float* __restrict__ x, i
 struct CoupleArgs {
   const float* vin;     // [Q][C]: forward: v = 1x1(actnorm(u)); inverse: y
   const float* P;       // [9C][Q] per-tap partial conv3 outputs of the network evaluated on vin[.., C/2:]
-  const float* P2;      // optional second partial (f16x3 path: the conv3 contraction is split over two passes)
+  int np;               // number of partial P buffers (f16x3 kernels: one per pass over the hidden width), >= 1
+  size_t pstride;       // floats between them
   const float* b3;      // [C] conv3 bias
   const float* A;       // post affine [C][C] or null: forward = NEXT step's ActNorm+1x1, inverse = this step's inverse 1x1+ActNorm
   const float* b;       // [C]
@@ -1176,28 +1240,41 @@ __global__ __launch_bounds__(256) void k_couple(CoupleArgs a) {
   const int n = blockIdx.x;
   const int hw = a.h * a.w;
   float lsum = 0.0f;
-  for (int pp = threadIdx.x; pp < hw; pp += 256) {
+  // four lanes per pixel: lane r of the quad gathers taps r, r + 4, r + 8 (all partial buffers), the quad adds up, lane 0
+  // does the coupling.  (One lane per pixel left the deep levels -- 64 pixels per sample -- with 64 busy lanes per workgroup
+  // and hundreds of dependent-address loads each.)
+  const int r4 = threadIdx.x & 3;
+  for (int pp0 = threadIdx.x >> 2; pp0 < ((hw + 63) & ~63); pp0 += 64) {
+    const bool live = pp0 < hw;
+    const int pp = live ? pp0 : hw - 1;
     const int q = n * hw + pp;
     const int i = pp / a.w, j = pp % a.w;
     float v[C], o[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) o[c] = a.b3[c];
+    for (int c = 0; c < C; ++c) o[c] = 0.0f;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int u = 0; u < 3; ++u) {
+      const int tap = r4 + 4 * u;
       const int dy = tap / 3 - 1, dx = tap % 3 - 1;
       const int ii = i + dy, jj = j + dx;
-      if (ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) {
+      if (tap < 9 && ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) {
         const size_t off = (size_t)(tap * C) * a.Q + (q + dy * a.w + dx);
-        const float* src = a.P + off;
 #pragma unroll
-        for (int c = 0; c < C; ++c) o[c] += src[(size_t)c * a.Q];
-        if (a.P2) {
-          const float* src2 = a.P2 + off;
+        for (int part = 0; part < 4; ++part)      // all partials' loads in flight together
+          if (part < a.np) {
+            const float* src = a.P + (size_t)part * a.pstride + off;
 #pragma unroll
-          for (int c = 0; c < C; ++c) o[c] += src2[(size_t)c * a.Q];
-        }
+            for (int c = 0; c < C; ++c) o[c] += src[(size_t)c * a.Q];
+          }
       }
     }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      o[c] += __shfl_xor(o[c], 1, 64);
+      o[c] += __shfl_xor(o[c], 2, 64);
+      o[c] += a.b3[c];
+    }
+    if (r4 != 0 || !live) continue;
     if (a.vin) {
 #pragma unroll
       for (int c = 0; c < C; ++c) v[c] = a.vin[(size_t)q * C + c];
@@ -1389,7 +1466,8 @@ struct BwdArgs {
   //     direct: g_v = gv_direct[q*gvd_stride + gvd_off + .]             (Pg == null)
   const float* ghalf_in;
   const float* Pg;
-  const float* Pg2;        // second partial of Pg (two-pass f16x3 backward kernel), or null
+  int npg;                 // number of partial Pg buffers (f16x3 backward kernel: one per pass), >= 1
+  size_t pgstride;
   const float* gv_direct;
   int gvd_stride, gvd_off;
   // (2) through step s's fused ActNorm + 1x1: g_y = g_v . A^T (null: g_y = g_v)
@@ -1397,7 +1475,8 @@ struct BwdArgs {
   // (3) coupling backward of the step that produced y (forward order: the step before s), or none (v == null)
   const float* v;          // [Q][C] saved coupling input
   const float* P;          // [9C][Q] saved per-tap conv3 outputs
-  const float* P2;         // their second partial (two-pass f16x3 forward kernel), or null
+  int np;                  // number of partials of P (f16x3 forward kernel), >= 1
+  size_t pstride;
   const float* b3;
   float* g_o;              // [Q][C] gradient wrt the network output o = [pre-tanh log_s, t]
   float* ghalf_out;        // [Q][C] [g_va, g_yb]
@@ -1410,23 +1489,60 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
   constexpr int CI = C / 2;
   const int n = blockIdx.x;
   const int hw = a.h * a.w;
-  for (int pp = threadIdx.x; pp < hw; pp += 256) {
+  // four lanes per pixel, as in k_couple: lane r of the quad gathers taps r, r + 4, r + 8 of both per-tap buffers (all their
+  // partials), the quad adds up, lane 0 does the per-pixel algebra
+  const int r4 = threadIdx.x & 3;
+  for (int pp0 = threadIdx.x >> 2; pp0 < ((hw + 63) & ~63); pp0 += 64) {
+    const bool live = pp0 < hw;
+    const int pp = live ? pp0 : hw - 1;
     const int q = n * hw + pp;
     const int i = pp / a.w, j = pp % a.w;
+    float gsum[CI], o[CI];   // merged network gradient (second half of g_v); log_s half of the saved network output
+#pragma unroll
+    for (int c = 0; c < CI; ++c) { gsum[c] = 0.0f; o[c] = 0.0f; }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int tap = r4 + 4 * u;
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+      if (tap < 9 && a.Pg) {
+        const int ii = i - dy, jj = j - dx;   // Pg[q'] contributes at q' + d(tap)
+        if (ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) {
+          const size_t po = (size_t)(tap * CI) * a.Q + (q - dy * a.w - dx);
+#pragma unroll
+          for (int part = 0; part < 4; ++part)
+            if (part < a.npg) {
+#pragma unroll
+              for (int c = 0; c < CI; ++c) gsum[c] += a.Pg[(size_t)part * a.pgstride + po + (size_t)c * a.Q];
+            }
+        }
+      }
+      if (tap < 9 && a.v) {
+        const int ii = i + dy, jj = j + dx;
+        if (ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) {
+          const size_t po = (size_t)(tap * C) * a.Q + (q + dy * a.w + dx);
+#pragma unroll
+          for (int part = 0; part < 4; ++part)
+            if (part < a.np) {
+#pragma unroll
+              for (int c = 0; c < CI; ++c) o[c] += a.P[(size_t)part * a.pstride + po + (size_t)c * a.Q];
+            }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CI; ++c) {
+      gsum[c] += __shfl_xor(gsum[c], 1, 64);
+      gsum[c] += __shfl_xor(gsum[c], 2, 64);
+      o[c] += __shfl_xor(o[c], 1, 64);
+      o[c] += __shfl_xor(o[c], 2, 64);
+    }
+    if (r4 != 0 || !live) continue;
     float gv[C];
     if (a.Pg) {
 #pragma unroll
       for (int c = 0; c < C; ++c) gv[c] = a.ghalf_in[(size_t)q * C + c];
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        const int ii = i - dy, jj = j - dx;   // Pg[q'] contributes at q' + d(tap)
-        if (ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) {
-          const size_t po = (size_t)(tap * CI) * a.Q + (q - dy * a.w - dx);
-#pragma unroll
-          for (int c = 0; c < CI; ++c) gv[CI + c] += a.Pg[po + (size_t)c * a.Q] + (a.Pg2 ? a.Pg2[po + (size_t)c * a.Q] : 0.0f);
-        }
-      }
+      for (int c = 0; c < CI; ++c) gv[CI + c] += gsum[c];
     } else {
 #pragma unroll
       for (int c = 0; c < C; ++c) gv[c] = a.gv_direct[(size_t)q * a.gvd_stride + a.gvd_off + c];
@@ -1445,19 +1561,8 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
       for (int c = 0; c < C; ++c) gy[c] = gv[c];
     }
     if (a.v) {
-      float o[CI];   // only the log_s half of the network output is needed
 #pragma unroll
-      for (int c = 0; c < CI; ++c) o[c] = a.b3[c];
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        const int ii = i + dy, jj = j + dx;
-        if (ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) {
-          const size_t po = (size_t)(tap * C) * a.Q + (q + dy * a.w + dx);
-#pragma unroll
-          for (int c = 0; c < CI; ++c) o[c] += a.P[po + (size_t)c * a.Q] + (a.P2 ? a.P2[po + (size_t)c * a.Q] : 0.0f);
-        }
-      }
+      for (int c = 0; c < CI; ++c) o[c] += a.b3[c];   // only the log_s half of the network output is needed
       float* go = a.g_o + (size_t)q * C;
       float* gh = a.ghalf_out + (size_t)q * C;
 #pragma unroll

@@ -184,3 +184,34 @@ def test_input_gradient_in_f16x3_arithmetic():
     lpl32, gl32 = eng.log_prob_grad(xl)
     np.testing.assert_allclose(lpl16.cpu().numpy(), lpl32.cpu().numpy(), rtol=2e-6)
     np.testing.assert_allclose(gl16.cpu().numpy(), gl32.cpu().numpy(), atol=2e-4 * float(gl32.abs().max()), rtol=2e-3)   # the bar vs fp64
+
+
+def test_input_gradient_f16x3_full_width():
+    """n_filters = 512 (the width the 4-pass kernel forms exist for: level-3 backward with K = 144, split launches of small
+    grids): gradient in both arithmetics against the fp64 autograd of the oracle, 64x64 tiles, L = 3, K = 2."""
+    from audiosourcesep_amd import _lib
+    from audiosourcesep_amd.synthetic import calibrated_engine
+    from oracle import glowref_torch as RT
+    cfg = GlowConfig(H=64, W=64, C=1, L=3, K=2, F=512)
+    eng, params = calibrated_engine(cfg, device=0, init_tiles=8)
+    x = synthetic_mel_tiles(3, cfg, seed=11)
+    lp_ref, g_ref = RT.log_prob_and_grad(x.astype(np.float64), params, cfg.as_dict())
+    scale = np.abs(g_ref).max()
+    errs = {}
+    for prec in (_lib.PREC_F32, _lib.PREC_F16X3):
+        eng.set_precision(prec)
+        lp, g = eng.log_prob_grad(dev(x))
+        np.testing.assert_allclose(lp.cpu().numpy(), lp_ref, rtol=1e-6)
+        errs[prec] = float(np.abs(g.cpu().numpy() - g_ref).max() / scale)
+        np.testing.assert_allclose(eng.log_prob(dev(x)).cpu().numpy(), lp_ref, rtol=1e-6)
+    print("max |grad - fp64 autograd| / max|grad|: fp32 kernels %.2e, fp16x3 kernels %.2e" % (errs[_lib.PREC_F32], errs[_lib.PREC_F16X3]))
+    # 512-wide fp32 contractions through 6 steps: a few 1e-4 of the largest gradient entry, in either arithmetic
+    assert errs[_lib.PREC_F32] < 1e-3 and errs[_lib.PREC_F16X3] < 1e-3
+    assert errs[_lib.PREC_F16X3] < 3 * errs[_lib.PREC_F32] + 1e-5
+    # a batch whose level-1 grid takes the unsplit launch while the deeper levels split 2- and 4-way
+    xl = dev(synthetic_mel_tiles(80, cfg, seed=12))
+    lp16, g16 = eng.log_prob_grad(xl)
+    eng.set_precision(_lib.PREC_F32)
+    lp32, g32 = eng.log_prob_grad(xl)
+    np.testing.assert_allclose(lp16.cpu().numpy(), lp32.cpu().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(g16.cpu().numpy(), g32.cpu().numpy(), atol=1e-3 * float(g32.abs().max()), rtol=5e-3)
