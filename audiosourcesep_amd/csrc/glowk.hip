@@ -706,7 +706,9 @@ int launch_net(glowk_handle* h, int level, int c, int F, const NetArgs& a, hipSt
   }
 
 int launch_couple(int c, const CoupleArgs& a, int N, hipStream_t s) {
-  CDISPATCH(c, hipLaunchKernelGGL((k_couple<CC>), dim3(N), dim3(256), 0, s, a));
+  const int hw = a.h * a.w;
+  const int threads = hw >= 256 ? 1024 : hw > 64 ? 512 : 256;   // four lanes per pixel, one workgroup per sample (log-det sum)
+  CDISPATCH(c, hipLaunchKernelGGL((k_couple<CC>), dim3(N), dim3(threads), 0, s, a));
   LAUNCHCHK("k_couple");
   return 0;
 }
@@ -890,7 +892,7 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
         ba.ghalf_in = gh_a; ba.Pg = Pg; ba.npg = npg; ba.pgstride = h->pstride; ba.gv_direct = nullptr; ba.gvd_stride = 0; ba.gvd_off = 0;
         ba.A = lv.dev[k - 1].Afwd;
       }
-      CDISPATCH(lv.c, hipLaunchKernelGGL((k_bwd_light<CC>), dim3(N), dim3(256), 0, s, ba));
+      CDISPATCH(lv.c, hipLaunchKernelGGL((k_bwd_light<CC>), dim3((Q + 63) / 64), dim3(256), 0, s, ba));
       LAUNCHCHK("k_bwd_light");
       std::swap(gh_a, gh_b);   // gh_a now holds this step's [g_va, g_yb]
       NetArgs na = net_args(h, lv, sd, g_o, lv.c, 0, N);
@@ -908,7 +910,7 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       ba.ghalf_in = gh_a; ba.Pg = Pg; ba.npg = npg; ba.pgstride = h->pstride; ba.gv_direct = nullptr; ba.gvd_stride = 0; ba.gvd_off = 0;
       ba.A = lv.dev[K - 1].Afwd;
       ba.v = nullptr; ba.P = nullptr; ba.np = 1; ba.pstride = 0; ba.b3 = nullptr; ba.g_o = nullptr; ba.ghalf_out = nullptr; ba.gu_out = g_o;   // reuse g_o as g_u
-      CDISPATCH(lv.c, hipLaunchKernelGGL((k_bwd_light<CC>), dim3(N), dim3(256), 0, s, ba));
+      CDISPATCH(lv.c, hipLaunchKernelGGL((k_bwd_light<CC>), dim3((Q + 63) / 64), dim3(256), 0, s, ba));
       LAUNCHCHK("k_bwd_light");
     }
     if (lvl > 0) {

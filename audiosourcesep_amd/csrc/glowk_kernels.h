@@ -1097,6 +1097,19 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
 // ------------------------------------------------------------------------------------------------
 // light kernels: one 256-thread workgroup per sample (deterministic per-sample reductions, no atomics)
 // ------------------------------------------------------------------------------------------------
+// same for any workgroup of whole waves up to 1024 threads (deterministic: fixed order over the waves)
+__device__ __forceinline__ double block_sum_any(double v, double* red /* [16] in LDS */) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  const int nw = (int)blockDim.x >> 6;
+  for (int w = 0; w < nw; ++w) t += red[w];
+  return t;
+}
+
 __device__ __forceinline__ double block_sum_256(double v, double* red /* [4] in LDS */) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -1234,8 +1247,8 @@ struct CoupleArgs {
 // gather conv3 (9 taps), split + tanh (flow_tfk_layers.py:80-84), affine coupling
 // (flow_tfp_bijectors.py:134-148), per-sample log-det (:150-153), then the following per-pixel affine
 template <int C>
-__global__ __launch_bounds__(256) void k_couple(CoupleArgs a) {
-  __shared__ double red[4];
+__global__ __launch_bounds__(1024) void k_couple(CoupleArgs a) {   // 256 .. 1024 threads: 64 .. 256 pixels in flight per sample
+  __shared__ double red[16];
   constexpr int CI = C / 2;
   const int n = blockIdx.x;
   const int hw = a.h * a.w;
@@ -1244,7 +1257,8 @@ __global__ __launch_bounds__(256) void k_couple(CoupleArgs a) {
   // does the coupling.  (One lane per pixel left the deep levels -- 64 pixels per sample -- with 64 busy lanes per workgroup
   // and hundreds of dependent-address loads each.)
   const int r4 = threadIdx.x & 3;
-  for (int pp0 = threadIdx.x >> 2; pp0 < ((hw + 63) & ~63); pp0 += 64) {
+  const int qpb = (int)blockDim.x >> 2;   // quads per workgroup
+  for (int pp0 = threadIdx.x >> 2; pp0 < (hw + qpb - 1) / qpb * qpb; pp0 += qpb) {
     const bool live = pp0 < hw;
     const int pp = live ? pp0 : hw - 1;
     const int q = n * hw + pp;
@@ -1306,7 +1320,7 @@ __global__ __launch_bounds__(256) void k_couple(CoupleArgs a) {
     }
   }
   if (a.logdet) {
-    const double tot = block_sum_256((double)lsum, red);
+    const double tot = block_sum_any((double)lsum, red);
     if (threadIdx.x == 0) a.logdet[n] += tot;
   }
 }
@@ -1487,15 +1501,15 @@ struct BwdArgs {
 template <int C>
 __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
   constexpr int CI = C / 2;
-  const int n = blockIdx.x;
   const int hw = a.h * a.w;
   // four lanes per pixel, as in k_couple: lane r of the quad gathers taps r, r + 4, r + 8 of both per-tap buffers (all their
-  // partials), the quad adds up, lane 0 does the per-pixel algebra
+  // partials), the quad adds up, lane 0 does the per-pixel algebra.  Flat grid over the Q pixels (nothing is reduced per sample).
   const int r4 = threadIdx.x & 3;
-  for (int pp0 = threadIdx.x >> 2; pp0 < ((hw + 63) & ~63); pp0 += 64) {
-    const bool live = pp0 < hw;
-    const int pp = live ? pp0 : hw - 1;
-    const int q = n * hw + pp;
+  {
+    const int q0 = (int)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const bool live = q0 < a.Q;
+    const int q = live ? q0 : a.Q - 1;
+    const int pp = q % hw;
     const int i = pp / a.w, j = pp % a.w;
     float gsum[CI], o[CI];   // merged network gradient (second half of g_v); log_s half of the saved network output
 #pragma unroll
@@ -1536,7 +1550,7 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
       o[c] += __shfl_xor(o[c], 1, 64);
       o[c] += __shfl_xor(o[c], 2, 64);
     }
-    if (r4 != 0 || !live) continue;
+    if (r4 != 0 || !live) return;
     float gv[C];
     if (a.Pg) {
 #pragma unroll
