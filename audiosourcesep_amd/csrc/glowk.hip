@@ -707,8 +707,12 @@ int launch_net(glowk_handle* h, int level, int c, int F, const NetArgs& a, hipSt
 
 int launch_couple(int c, const CoupleArgs& a, int N, hipStream_t s) {
   const int hw = a.h * a.w;
-  const int threads = hw >= 256 ? 1024 : hw > 64 ? 512 : 256;   // four lanes per pixel, one workgroup per sample (log-det sum)
-  CDISPATCH(c, hipLaunchKernelGGL((k_couple<CC>), dim3(N), dim3(threads), 0, s, a));
+  if (N >= 2 * num_cus()) {   // enough per-sample workgroups to fill the chip: one lane per pixel
+    CDISPATCH(c, hipLaunchKernelGGL((k_couple<CC, false>), dim3(N), dim3(256), 0, s, a));
+  } else {                    // four lanes per pixel, up to 256 pixels in flight per sample
+    const int threads = hw >= 256 ? 1024 : hw > 64 ? 512 : 256;
+    CDISPATCH(c, hipLaunchKernelGGL((k_couple<CC, true>), dim3(N), dim3(threads), 0, s, a));
+  }
   LAUNCHCHK("k_couple");
   return 0;
 }

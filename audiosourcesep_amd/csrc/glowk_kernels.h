@@ -1246,8 +1246,10 @@ struct CoupleArgs {
 
 // gather conv3 (9 taps), split + tanh (flow_tfk_layers.py:80-84), affine coupling
 // (flow_tfp_bijectors.py:134-148), per-sample log-det (:150-153), then the following per-pixel affine
-template <int C>
-__global__ __launch_bounds__(1024) void k_couple(CoupleArgs a) {   // 256 .. 1024 threads: 64 .. 256 pixels in flight per sample
+// QUAD: four lanes per pixel (small batches: the per-sample workgroups cannot fill the chip, so parallelism has to come from
+// inside the pixel); otherwise one lane per pixel (large batches: fewer, fully used lanes -- 47 vs 80 us at 1024 tiles)
+template <int C, bool QUAD>
+__global__ __launch_bounds__(1024) void k_couple(CoupleArgs a) {   // 256 .. 1024 threads
   __shared__ double red[16];
   constexpr int CI = C / 2;
   const int n = blockIdx.x;
@@ -1256,9 +1258,9 @@ __global__ __launch_bounds__(1024) void k_couple(CoupleArgs a) {   // 256 .. 102
   // four lanes per pixel: lane r of the quad gathers taps r, r + 4, r + 8 (all partial buffers), the quad adds up, lane 0
   // does the coupling.  (One lane per pixel left the deep levels -- 64 pixels per sample -- with 64 busy lanes per workgroup
   // and hundreds of dependent-address loads each.)
-  const int r4 = threadIdx.x & 3;
-  const int qpb = (int)blockDim.x >> 2;   // quads per workgroup
-  for (int pp0 = threadIdx.x >> 2; pp0 < (hw + qpb - 1) / qpb * qpb; pp0 += qpb) {
+  const int r4 = QUAD ? (threadIdx.x & 3) : 0;
+  const int qpb = QUAD ? (int)blockDim.x >> 2 : (int)blockDim.x;   // pixels per workgroup and iteration
+  for (int pp0 = QUAD ? threadIdx.x >> 2 : threadIdx.x; pp0 < (hw + qpb - 1) / qpb * qpb; pp0 += qpb) {
     const bool live = pp0 < hw;
     const int pp = live ? pp0 : hw - 1;
     const int q = n * hw + pp;
@@ -1267,8 +1269,8 @@ __global__ __launch_bounds__(1024) void k_couple(CoupleArgs a) {   // 256 .. 102
 #pragma unroll
     for (int c = 0; c < C; ++c) o[c] = 0.0f;
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int tap = r4 + 4 * u;
+    for (int u = 0; u < (QUAD ? 3 : 9); ++u) {
+      const int tap = QUAD ? r4 + 4 * u : u;
       const int dy = tap / 3 - 1, dx = tap % 3 - 1;
       const int ii = i + dy, jj = j + dx;
       if (tap < 9 && ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) {
@@ -1284,8 +1286,10 @@ __global__ __launch_bounds__(1024) void k_couple(CoupleArgs a) {   // 256 .. 102
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      o[c] += __shfl_xor(o[c], 1, 64);
-      o[c] += __shfl_xor(o[c], 2, 64);
+      if (QUAD) {
+        o[c] += __shfl_xor(o[c], 1, 64);
+        o[c] += __shfl_xor(o[c], 2, 64);
+      }
       o[c] += a.b3[c];
     }
     if (r4 != 0 || !live) continue;
