@@ -333,21 +333,25 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
 // 16s + 8(j>>2) + 4h + (j&3) of the tile: the host packs the A operands in that order.
 //
 // Geometry: 8 waves per workgroup, one 32-pixel column block each (256 pixels per workgroup); the hidden width is covered
-// in 2 passes of NFH = NF/2 accumulator tiles (128 registers per wave).  A pass is a sequence of OPS, one per phase:
-//     X_i  conv1 of hidden block i + ReLU + split                  (6..15 MFMAs, then ~80 VALU: MFMA pipe mostly idle)
-//     Y_i  conv2 contribution of block i to the NFH accumulators   (6 NFH MFMAs, no VALU)
-//     Z_z  half a chunk of conv3 A tiles                           (3 NFH MFMAs + ReLU/split of the accumulators)
+// in NP passes of NFH = NF/NP accumulator tiles (NP = 2: 128 registers per wave; NP = 4: 64, for shapes whose small-conv
+// fragments need the room and for small grids, where a pass becomes a workgroup of its own).  The same kernel runs the
+// forward network, the forward network with saves (ReLU masks) and the backward network (MODE, as k_net_f32).
+// A pass is a sequence of OPS, one per phase:
+//     X_i  small conv of hidden block i + activation + split       (3 KS MFMAs, then ~80 VALU: MFMA pipe mostly idle)
+//     Y_i  main contraction's contribution of block i to the NFH accumulators   (6 NFH MFMAs, no VALU)
+//     Z_z  half a chunk of per-tap output A tiles                  (3 NFH MFMAs + activation/split of the accumulators)
 // in the order X_0 Y_0 X_1 Y_1 ... Z_0 Z_1 ...; phases are separated by one workgroup barrier.  The two waves of a SIMD
 // (wave w and w+4, "groups" 0 and 1) run the SAME op sequence ONE PHASE APART: while one is in the VALU-heavy X the
 // other is in the MFMA-only Y, so the matrix pipe sees one Y per phase instead of idling while both waves do epilogues
 // (measured before this: 5450 cycles per X+Y step against 3456 cycles of MFMA).
 //
-// LDS: main slots A/B (K2 chunks, and the later conv3 chunks) 32 KiB each, slot D (first conv3 chunk, loaded early),
-// two small slots for the conv1 operands.  What phase r of a pass starts (all 8 waves issue their share of the pieces):
-//     r = 2i-2: conv1 operands of block i       r = 2i-1: main chunk i (K2(i), or conv3 chunk i-NF+1)       r = 2: slot D
-// i.e. everything is requested two phases before its first reader; a phase ends with "wait until only this phase's own
-// DMA is in flight" + barrier, so a piece has two phases to land and every slot is rewritten only after the barrier that
-// follows its last reader (group 1 of the phase before).
+// LDS: main slots A/B (main chunks, and the later output chunks), slot D (first output chunk, loaded early), two small
+// slots for the small-conv operands (+ the masks of the 8 column blocks in backward mode).  DMA is requested only during Y
+// ops, spread between the MFMA groups: group 0 asks for the next main chunk (into the slot its partner group finished
+// reading one phase ago), group 1 for the small-conv operands of block i+2 (into the slot its own X_i has just left); the
+// op after a Y (X or Z) ends with vmcnt(0) + barrier, so a piece has two phases to land, every wait is static, and every
+// slot is rewritten only after the barrier that follows its last reader.  Output chunks beyond the first are requested
+// during the Z ops as soon as their slot is free; the last Z op of a pass requests the next pass's first chunks.
 // ------------------------------------------------------------------------------------------------------------------
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define GLOWK_ACT_SCALE 32.0f
