@@ -770,7 +770,7 @@ int ensure_save(glowk_handle* h, int N) {
   for (int lvl = 0; lvl < L; ++lvl) {
     const Level& lv = h->levels[lvl];
     const size_t Q = (size_t)N * lv.h * lv.w;
-    const size_t blocks = ((Q + 127) / 128) * 4;
+    const size_t blocks = ((Q + 255) / 256) * 8;
     for (int j = 0; j < K; ++j) {
       const size_t sidx = (size_t)lvl * K + j;
       h->offV[sidx] = v; v += Q * lv.c;
@@ -813,7 +813,7 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
   for (int lvl = 0; lvl < L; ++lvl) {
     const Level& lv = h->levels[lvl];
     const size_t Q = (size_t)N * lv.h * lv.w;
-    const size_t blocks = ((Q + 127) / 128) * 4;
+    const size_t blocks = ((Q + 255) / 256) * 8;
     for (int k = K - 1; k >= 0; --k) {   // tfb.Chain applies right to left: step K-1 first (flow_glow.py:51-52)
       const StepDev& sd = lv.dev[k];
       const size_t sidx = (size_t)lvl * K + (K - 1 - k);
@@ -877,7 +877,7 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
   for (int lvl = L - 1; lvl >= 0; --lvl) {
     const Level& lv = h->levels[lvl];
     const int Q = N * lv.h * lv.w;
-    const size_t blocks = (((size_t)Q + 127) / 128) * 4;
+    const size_t blocks = (((size_t)Q + 255) / 256) * 8;
     int npg = 1;                    // partials of Pg the previous network launch of this level left in bufP
     for (int k = 0; k < K; ++k) {   // reverse of the forward order K-1 .. 0
       const StepDev& sd = lv.dev[k];

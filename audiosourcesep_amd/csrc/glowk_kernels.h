@@ -431,6 +431,39 @@ __device__ __forceinline__ f32x16 mfma3(const h8& ahi, const h8& alo, const h8& 
   return acc;
 }
 
+// 8 consecutive im2col entries k0 .. k0+7 (k = tap * KIN + channel, k0 a multiple of 8) of one pixel, scaled for the split:
+// they are G = min(KIN, 8) consecutive channels of 8 / G taps, fetched as one or two vector loads per tap (the scalar form
+// -- 8 loads with their own address arithmetic -- made the prologue 15-30 us of a 45-65 us launch at small batches).
+// base = the pixel's row + channel offset, aligned to G floats.  BIAS: entry k == K1 is the constant that carries conv1's bias.
+template <int KIN, bool BIAS, int SGN>
+__device__ __forceinline__ void gather8(const float* base, int i, int j0, int h, int w, int in_stride, bool qok, int k0, float (&v)[8]) {
+  constexpr int K1 = 9 * KIN;
+  constexpr int G = KIN < 8 ? KIN : 8;
+  static_assert(G == 2 || G == 4 || G == 8, "channel group");
+#pragma unroll
+  for (int t = 0; t < 8 / G; ++t) {
+    const int k = k0 + t * G;
+    const int tap = k / KIN, cin = k % KIN;
+    const int dy = SGN * (tap / 3 - 1), dx = SGN * (tap % 3 - 1);
+    const int ii = i + dy, jj = j0 + dx;
+    const bool ok = qok && k < K1 && ii >= 0 && ii < h && jj >= 0 && jj < w;
+    const float* p = base + (ok ? (dy * w + dx) * in_stride + cin : 0);     // clamped: always in bounds
+    float x[G];
+    if constexpr (G == 8) {
+      const float4 a = *reinterpret_cast<const float4*>(p), b = *(reinterpret_cast<const float4*>(p) + 1);
+      x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    } else if constexpr (G == 4) {
+      const float4 a = *reinterpret_cast<const float4*>(p);
+      x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
+    } else {
+      const float2 a = *reinterpret_cast<const float2*>(p);
+      x[0] = a.x; x[1] = a.y;
+    }
+#pragma unroll
+    for (int e = 0; e < G; ++e) v[t * G + e] = ok ? x[e] * GLOWK_ACT_SCALE : ((BIAS && k + e == K1) ? GLOWK_ACT_SCALE : 0.0f);
+  }
+}
+
 // end of a phase.  DMA is only issued by ops that end with the bare barrier (Y); the op after it (X, Z) ends with
 // "everything of this wave has landed" + barrier, so a piece has two phases to land and is published by the second barrier.
 // The waits are builtins so that the compiler's own wait-count bookkeeping sees them.
@@ -447,7 +480,7 @@ __device__ __forceinline__ void h3_wait_barrier() {
 struct H3Ctx {                      // wave-uniform pointers of the kernel (LDS arrays are distinct statics: see ring_slot)
   float4 *sA, *sB, *sD, *k1s0, *k1s1;
   const float4 *k1img, *img;
-  const unsigned short* mkl;        // backward: LDS copy of the masks, [which][hidden block][512 threads]
+  const unsigned short* mkl;        // backward: LDS copy of the masks, [mask1 | mask2][wave][hidden block][lane] (the global order)
   size_t wblk;                      // 32-pixel column block of this wave
   bool wok;                         // it holds at least one pixel
   int w4;
@@ -487,7 +520,7 @@ __device__ __forceinline__ void h3_X(const NetArgs& a, const H3Ctx& c, int fi, c
   for (int r = 0; r < 16; ++r) h1[r] = 0.0f;
   const h8* k1 = reinterpret_cast<const h8*>(KP ? c.k1s1 : c.k1s0) + lane;   // [s][hi|lo][64]
   unsigned mask = 0;
-  if (MODE == NET_BWD) mask = c.mkl[(size_t)(NF + fi) * 512 + threadIdx.x];  // mask2: the ReLU after conv2
+  if (MODE == NET_BWD) mask = c.mkl[((size_t)(8 + (threadIdx.x >> 6)) * NF + fi) * 64 + lane];  // mask2: the ReLU after conv2
   if constexpr (G::KS <= 3) {       // all operand reads in flight before the first MFMA
     h8 kf[2 * G::KS];
 #pragma unroll
@@ -583,7 +616,7 @@ __device__ __forceinline__ void h3_Z(const NetArgs& a, const H3Ctx& c, const flo
     const int ml = first_group ? mt : mt - G::G0N;     // this row tile's accumulator within its group
     if (ml == 0) {
       unsigned mask = 0;
-      if (MODE == NET_BWD) mask = c.mkl[(size_t)(PASS * NFH + fo) * 512 + threadIdx.x];   // mask1: the ReLU after conv1
+      if (MODE == NET_BWD) mask = c.mkl[((size_t)(threadIdx.x >> 6) * NF + PASS * NFH + fo) * 64 + lane];   // mask1: the ReLU after conv1
       const unsigned bits = h3_act<MODE>(acc2[fo], a.sc2, mask, bh, bl);
       if (MODE == NET_FWD_SAVE && first_group && c.wok) a.mask2[(c.wblk * NF + PASS * NFH + fo) * 64 + lane] = (unsigned short)bits;
     }
@@ -677,7 +710,7 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
   __shared__ float4 k1slot0[G::K14];
   __shared__ float4 k1slot1[G::K14];
   __shared__ float epl[G::EPN];
-  __shared__ unsigned short mkl[G::MASK2B / 2 + 2];
+  __shared__ __attribute__((aligned(16))) unsigned short mkl[G::MASK2B / 2 + 8];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -699,6 +732,18 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
   c.w4 = wave & 3;
   c.voff = (unsigned)lane * 16u;
 
+  // first the DMA of everything the first phases need (it has the longest latency of the prologue), then the gathers
+  if (!g) {
+    stage4<G::MAINP, 60>(G::main_chunk(c.img, solo_pass, 0), slotA, c.w4, c.voff);       // main chunk 0
+    stage4<G::MAINP, 61>(G::out_chunk(c.img, solo_pass, 0), slotD, c.w4, c.voff);        // first output chunk
+    if (MODE == NET_BWD)   // the forward pass's ReLU decisions of this workgroup's 8 column blocks: [mask1 | mask2][wave][block][lane]
+      stage4<NF, 64>(reinterpret_cast<const float4*>(a.mask1 + (size_t)blockIdx.x * 8 * NF * 64), reinterpret_cast<float4*>(mkl), c.w4, c.voff);
+  } else {
+    stage4<G::K1P, 62>(c.k1img, k1slot0, c.w4, c.voff);                                   // small-conv operands of blocks 0, 1
+    stage4<G::K1P, 63>(c.k1img + G::K14, k1slot1, c.w4, c.voff);
+    if (MODE == NET_BWD)
+      stage4<NF, 65>(reinterpret_cast<const float4*>(a.mask2 + (size_t)blockIdx.x * 8 * NF * 64), reinterpret_cast<float4*>(mkl + 8 * NF * 64), c.w4, c.voff);
+  }
   // im2col fragments of this lane's pixel: k-step s holds k = 16 s + 8 hh + j (natural order), scaled and split
   h8 xh[KS], xl[KS];
   {
@@ -710,36 +755,12 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int k = 16 * s + 8 * hh + j;
-        const int tap = k / KIN, cin = k % KIN;
-        const int dy = SGN * (tap / 3 - 1), dx = SGN * (tap % 3 - 1);
-        const int ii = i + dy, jj = j0 + dx;
-        const bool ok = qok && k < K1 && ii >= 0 && ii < a.h && jj >= 0 && jj < a.w;
-        const int off = ok ? ((dy * a.w + dx) * a.in_stride + cin) : 0;
-        const float x = base[off];
-        v[j] = ok ? x * GLOWK_ACT_SCALE : ((MODE != NET_BWD && k == K1) ? GLOWK_ACT_SCALE : 0.0f);   // forward, row K1: carries conv1's bias
-      }
+      gather8<KIN, MODE != NET_BWD, SGN>(base, i, j0, a.h, a.w, a.in_stride, qok, 16 * s + 8 * hh, v);
       split8(v, xh[s], xl[s]);
     }
   }
-  if (MODE == NET_BWD) {   // the forward pass's ReLU decisions of this workgroup's column blocks: [mask1 | mask2][block][thread]
-    for (int f = 0; f < NF; ++f) {
-      mkl[(size_t)f * 512 + tid] = c.wok ? a.mask1[(c.wblk * NF + f) * 64 + lane] : (unsigned short)0;
-      mkl[(size_t)(NF + f) * 512 + tid] = c.wok ? a.mask2[(c.wblk * NF + f) * 64 + lane] : (unsigned short)0;
-    }
-  } else {
+  if (MODE != NET_BWD)
     for (int i = tid; i < G::EPN; i += 512) epl[i] = a.eph[i];
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // gathers done before any DMA is issued
-  if (!g) {
-    stage4<G::MAINP, 60>(G::main_chunk(c.img, solo_pass, 0), slotA, c.w4, c.voff);       // main chunk 0
-    stage4<G::MAINP, 61>(G::out_chunk(c.img, solo_pass, 0), slotD, c.w4, c.voff);        // first output chunk
-  } else {
-    stage4<G::K1P, 62>(c.k1img, k1slot0, c.w4, c.voff);                                   // small-conv operands of blocks 0, 1
-    stage4<G::K1P, 63>(c.k1img + G::K14, k1slot1, c.w4, c.voff);
-  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                         // constants and the first chunks visible to every wave
 
@@ -1044,6 +1065,13 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
   c.w4 = wave & 3;
   c.voff = (unsigned)lane * 16u;
 
+  if (!g) {
+    stage4<G::MAINP, 60>(G::main_chunk(c.img, solo_pass, 0), slotA, c.w4, c.voff);
+    stage4<G::MAINP, 61>(G::out_chunk(c.img, solo_pass, 0), slotD, c.w4, c.voff);
+  } else {
+    stage4<G::K1P, 62>(c.k1img, k1slot0, c.w4, c.voff);
+    stage4<G::K1P, 63>(c.k1img + G::K14, k1slot1, c.w4, c.voff);
+  }
   // im2col fragments of this lane's two pixels: k-step s holds k = 32 s + 8 kq + j (natural order), scaled and split
   h8 xh[KS][2], xl[KS][2];
   {
@@ -1057,30 +1085,12 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int k = 32 * s + 8 * kq + j;
-          const int tap = k / CI, cin = k % CI;
-          const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-          const int ii = i + dy, jj = j0 + dx;
-          const bool ok = qok[hf] && k < K1 && ii >= 0 && ii < a.h && jj >= 0 && jj < a.w;
-          const int off = ok ? ((dy * a.w + dx) * a.in_stride + cin) : 0;
-          const float x = base[off];
-          v[j] = ok ? x * GLOWK_ACT_SCALE : (k == K1 ? GLOWK_ACT_SCALE : 0.0f);   // row K1: carries conv1's bias
-        }
+        gather8<CI, true, 1>(base, i, j0, a.h, a.w, a.in_stride, qok[hf], 32 * s + 8 * kq, v);
         split8(v, xh[s][hf], xl[s][hf]);
       }
     }
   }
   for (int i = tid; i < G::EPN; i += 512) epl[i] = a.eph[i];   // RingS::EPN <= RingH::EPN, same content
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (!g) {
-    stage4<G::MAINP, 60>(G::main_chunk(c.img, solo_pass, 0), slotA, c.w4, c.voff);
-    stage4<G::MAINP, 61>(G::out_chunk(c.img, solo_pass, 0), slotD, c.w4, c.voff);
-  } else {
-    stage4<G::K1P, 62>(c.k1img, k1slot0, c.w4, c.voff);
-    stage4<G::K1P, 63>(c.k1img + G::K14, k1slot1, c.w4, c.voff);
-  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
