@@ -60,7 +60,7 @@ def initial_variables(cfg: GlowConfig, rng):
 
 
 def build_glow(minibatch, data_shape, L=3, K=32, n_filters=512, learntop=True, l2_reg=None,
-               mirrored_strategy=None, data_type="image", seed=None, device=None, **kwargs):
+               mirrored_strategy=None, data_type="image", seed=None, device=None, precision=None, **kwargs):
     """Same arguments as the reference (flow_builder.py:60-61).
 
     * ``L`` outside {2,3,4} raises ``ValueError("L should be 2, 3 or 4")`` (:76-77).
@@ -71,6 +71,8 @@ def build_glow(minibatch, data_shape, L=3, K=32, n_filters=512, learntop=True, l
       (SURVEY section 3.1): accepted and ignored.
     * ``mirrored_strategy``: the reference only uses it to place variables; here each process owns one GPU
       (see audiosourcesep_amd.distributed) so it is accepted and ignored.
+    * ``precision`` (extension): ``None`` / ``"f32"`` = exact fp32 kernels, ``"f16x3"`` = the fp16-split kernels (fp32-class
+      accuracy, ~3x the speed).  ``seed`` / ``device`` are extensions too.
     * ``minibatch`` drives the data-dependent ActNorm init exactly like the reference constructor, including the
       raw-minibatch quirk of the 3/4-level graphs (flow_glow.py:162-165), on the GPU.
     """
@@ -93,4 +95,7 @@ def build_glow(minibatch, data_shape, L=3, K=32, n_filters=512, learntop=True, l
     if tuple(minibatch.shape[1:]) != (H, W, C):
         raise ValueError("minibatch must be [N, %d, %d, %d]" % (H, W, C))     # ActNorm asserts, flow_tfp_bijectors.py:218-220
     eng.actnorm_data_init(minibatch, runtime_order=False, raw_minibatch_quirk=True)
-    return GlowFlow(eng)
+    flow = GlowFlow(eng)
+    if precision is not None:
+        flow.set_precision(precision)
+    return flow

@@ -202,6 +202,14 @@ class GlowFlow:
         eps = torch.randn((int(n),) + tuple(self.cfg.latent_shape()), device=self.engine.device, dtype=torch.float32, generator=g)
         return self.engine.sample_from_eps(eps)
 
+    def set_precision(self, precision):
+        """``"f32"`` (exact fp32 MFMA) or ``"f16x3"`` (error-compensated fp16 split) for every later call."""
+        modes = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3}
+        if precision not in modes:
+            raise ValueError("precision must be 'f32' or 'f16x3'")
+        self.engine.set_precision(modes[precision])
+        return self
+
     @property
     def variables(self):
         return self._variables

@@ -89,6 +89,11 @@ def test_build_glow_matches_reference_construction(L):
     p = R.cast_params(flow.state_dict(), np.float64)
     lp = flow.log_prob(dev(x))
     np.testing.assert_allclose(lp.cpu().numpy(), R.log_prob(x.astype(np.float64), p, cfg.as_dict()), rtol=1e-5)
+    # the precision switch (extension): same numbers to fp32 class in the fp16-split arithmetic, and back
+    np.testing.assert_allclose(flow.set_precision("f16x3").log_prob(dev(x)).cpu().numpy(), lp.cpu().numpy(), rtol=2e-6)
+    assert torch.equal(flow.set_precision("f32").log_prob(dev(x)), lp)
+    with pytest.raises(ValueError):
+        flow.set_precision("bf16")
     # tfb.Invert semantics: flow.bijector.inverse is data -> latent, forward is latent -> data
     z = flow.bijector.inverse(dev(x))
     assert tuple(z.shape[1:]) == cfg.latent_shape() == tuple(flow.chain.forward_event_shape(shape))
