@@ -379,7 +379,7 @@ struct RingH {
   static constexpr int EPN = (NF * 32 + 32 * NMT + 3) & ~3;       // conv2 accumulator init (F) | per-row constants of P (32 NMT)
   static constexpr int MASK2B = BWD ? 2 * NF * 512 * 2 : 0;       // backward: both ReLU masks of the workgroup's 8 column blocks
   static constexpr size_t LDS_BYTES = (size_t)3 * MAIN4 * 16 + (size_t)2 * K14 * 16 + (size_t)EPN * 4 + MASK2B;
-  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && NFH >= 2 && NFH % 2 == 0 && KS <= (NP == 2 ? 4 : 9) && G1N <= 3;   // (5 k-steps of fragments next to 128 accumulator registers spill)
+  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && NFH >= 2 && NFH % 2 == 0 && KS <= (NP == 2 ? 5 : 9) && G1N <= 3;   // (KS = 5 with NP = 2 spills a few registers outside the main loop: still 3 % faster than four passes at large batches)
   // image (one for every NP): small-conv operands of all blocks, then per HALF of the hidden width main chunks 0..NF-1 and
   // output chunks, tiles of NF/2 hidden blocks each; a pass of NP = 4 reads its half of every chunk
   static constexpr int K1TOT4 = NF * K14;
