@@ -138,6 +138,8 @@ class GlowEngine:
         n = x.shape[0]
         z = self._new(n, *self.cfg.latent_shape())
         ld = self._new(n) if with_logdet else None
+        if n == 0:   # an empty batch is an empty result (TF semantics), not a launch
+            return (z, ld) if with_logdet else z
         _lib.check(self.lib.glowk_forward(self.h, _ptr(x), n, _ptr(z), _ptr(ld), _stream_ptr()))
         return (z, ld) if with_logdet else z
 
@@ -145,6 +147,8 @@ class GlowEngine:
         z = self._in(z, self.cfg.latent_shape())
         n = z.shape[0]
         x = self._new(n, *self.data_shape)
+        if n == 0:
+            return x
         _lib.check(self.lib.glowk_inverse(self.h, _ptr(z), n, _ptr(x), _stream_ptr()))
         return x
 
@@ -153,6 +157,8 @@ class GlowEngine:
         n = x.shape[0]
         lp = out if out is not None else self._new(n)
         z = self._new(n, *self.cfg.latent_shape()) if return_latent else None
+        if n == 0:
+            return (lp, z) if return_latent else lp
         _lib.check(self.lib.glowk_log_prob(self.h, _ptr(x), n, _ptr(lp), _ptr(z), _stream_ptr()))
         return (lp, z) if return_latent else lp
 
@@ -160,6 +166,8 @@ class GlowEngine:
         x = self._in(x, self.data_shape)
         n = x.shape[0]
         lp, dx = self._new(n), torch.empty_like(x)
+        if n == 0:
+            return lp, dx
         _lib.check(self.lib.glowk_log_prob_grad(self.h, _ptr(x), n, _ptr(lp), _ptr(dx), _stream_ptr()))
         return lp, dx
 
@@ -167,6 +175,8 @@ class GlowEngine:
         eps = self._in(eps, self.cfg.latent_shape())
         n = eps.shape[0]
         x = self._new(n, *self.data_shape)
+        if n == 0:
+            return x
         _lib.check(self.lib.glowk_sample(self.h, _ptr(eps), n, _ptr(x), _stream_ptr()))
         return x
 

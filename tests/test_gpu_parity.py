@@ -274,3 +274,27 @@ def test_f16x3_full_size_accuracy(gpu):
         np.abs(lp16 - lp_ref) / np.abs(lp_ref), np.max(np.abs(lp16b - lp32) / np.abs(lp32))))
     np.testing.assert_allclose(lp16, lp_ref, rtol=5e-6)          # north-star bar: 1e-4
     np.testing.assert_allclose(lp16b, lp32, rtol=5e-6)
+
+
+def test_empty_and_single_tile_batches(gpu):
+    """Edge cases of the batch dimension: N = 0 returns empty results without a launch, N = 1 (one ragged workgroup at every
+    level) agrees with the same tile inside a larger batch."""
+    from audiosourcesep_amd import _lib
+    cfg = GlowConfig(H=16, W=16, C=1, L=3, K=2, F=128)
+    eng, _ = calibrated_engine(cfg, device=0, init_tiles=8)
+    x = torch.from_numpy(synthetic_mel_tiles(5, cfg, seed=3)).cuda()
+    e = x[:0]
+    assert tuple(eng.log_prob(e).shape) == (0,)
+    z, ld = eng.forward(e)
+    assert tuple(z.shape) == (0,) + tuple(cfg.latent_shape()) and tuple(ld.shape) == (0,)
+    assert tuple(eng.inverse(z).shape) == (0, 16, 16, 1)
+    lp0, g0 = eng.log_prob_grad(e)
+    assert tuple(lp0.shape) == (0,) and tuple(g0.shape) == (0, 16, 16, 1)
+    for prec in (_lib.PREC_F32, _lib.PREC_F16X3):
+        eng.set_precision(prec)
+        lp = eng.log_prob(x)
+        lp1 = eng.log_prob(x[2:3])
+        np.testing.assert_allclose(lp1.cpu().numpy(), lp[2:3].cpu().numpy(), rtol=1e-6)
+        l1, g1 = eng.log_prob_grad(x[2:3])
+        l5, g5 = eng.log_prob_grad(x)
+        np.testing.assert_allclose(g1.cpu().numpy(), g5[2:3].cpu().numpy(), atol=2e-4 * float(g5.abs().max()), rtol=2e-3)
