@@ -42,6 +42,7 @@ struct StepDev {            // device pointers into the arena
   const float4* RHp = nullptr;   // f16x3 ring image (null: shape not supported by k_net_h3)
   const float* epH = nullptr;    // its epilogue constants
   const float4* RSp = nullptr;   // forward image for the 16x16x32 kernel (k_net_h3s), or null
+  const float4* RSBp = nullptr;  // backward image for it (only packed together with RSp: a level uses one kernel family)
   const float4* RHBp = nullptr;  // f16x3 image of the backward network (null: not supported: exact fp32 backward)
   float scb1 = 1.f, scb2 = 1.f, scb3 = 1.f;
   float sc1 = 1.f, sc2 = 1.f, sc3 = 1.f;
@@ -157,10 +158,11 @@ inline int rho(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 inline size_t pad4(size_t n) { return (n + 3) & ~size_t(3); }
 
 struct StepLayout {
-  size_t K1p, ep, R0p, K3bp, RBp, RHp, epH, RSp, RHBp, Afwd, bfwd, Ainv, binv, b3, total;
+  size_t K1p, ep, R0p, K3bp, RBp, RHp, epH, RSp, RSBp, RHBp, Afwd, bfwd, Ainv, binv, b3, total;
   size_t slotH;        // floats per main chunk of the f16x3 image (0: shape not supported by k_net_h3)
   size_t slotHB;       // the same for the backward network's image
   size_t slotS;        // and for the forward image of the 16x16x32 kernel
+  size_t slotSB;       // ... its backward image
   size_t slotB, k3fB;  // backward ring image: floats per slot; floats of its conv3^T-operand part (0: not in the ring)
   size_t slot0, k1f0;  // floats per slot of k_net_f32's ring image; floats of its conv1 part (0: not in the ring)
 };
@@ -201,6 +203,11 @@ StepLayout step_layout(int c, int F) {
       const bool fitsS = fitsH && ldss <= 160 * 1024 && KSS <= 3 && NMS <= 12 && NCH >= 2;
       L.slotS = fitsS ? (size_t)NFH * 1024 : 0;
       L.RSp = o; o += fitsS ? (size_t)NF * KSS * 1024 + (size_t)2 * (NF + NCH) * NFH * 1024 : 0;
+      // RingS<c, 9 CI, NF, bwd>: K = 9c in k-steps of 32, 9 CI output rows in blocks of 16
+      const int KSSB = (9 * c + 31) / 32, NMSB = (9 * CI + 15) / 16, NCHB = (NFH * NMSB + 2 * NFH - 1) / (2 * NFH);
+      const bool fitsSB = fitsS && KSSB <= 5 && NMSB <= 12;
+      L.slotSB = fitsSB ? (size_t)NFH * 1024 : 0;
+      L.RSBp = o; o += fitsSB ? (size_t)NF * KSSB * 1024 + (size_t)2 * (NF + NCHB) * NFH * 1024 : 0;
     }
     const int KSB = (9 * c + 15) / 16, NMB = (9 * CI + 31) / 32;                                      // RingH<c, 9 CI, NF, bwd>
     const size_t ldsb = (size_t)3 * (NF / 4) * 4096 + (size_t)2 * KSB * 2048 + pad4((size_t)F + 32 * NMB) * 4 + (size_t)2 * NF * 1024;   // 4-pass form
@@ -476,7 +483,7 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
 
   // ---- f16x3 image of the backward network (k_net_h3, NET_BWD): g_a2 = g2 * mask2 * conv3^T(g_o), g_a1 = g1 * mask1 * K2 g_a2,
   //      per-tap conv1^T.  The BatchNorm factors multiply the producing layer's output rows (a weight change, any sign). ----
-  if (L.slotHB) {
+  if (L.slotHB || L.slotSB) {
     const int KSB = (9 * c + 15) / 16, NMB = (9 * CI + 31) / 32, NFH = NF / 2;
     const int G0N = NMB < 3 ? NMB : 3, G1N = NMB - G0N > 0 ? NMB - G0N : 1;
     const float* ep = dst + L.ep;       // [b1 | g1 | d1 | b2 | g2 | d2]
@@ -489,6 +496,7 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
     scales3[3] = std::ldexp(1.0f, -S1); scales3[4] = std::ldexp(1.0f, -S2); scales3[5] = std::ldexp(1.0f, -S3) / 32.0f;
     const size_t k1blk = (size_t)KSB * 2 * 256, chunkf = (size_t)NFH * 1024;
     float* img = dst + L.RHBp;
+    if (L.slotHB)
     for (int blk = 0; blk < NF; ++blk)
       for (int s2 = 0; s2 < KSB; ++s2)
         for (int l = 0; l < 64; ++l)
@@ -499,6 +507,7 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
             put(row_lane, j, 0, w, S1);
             put(row_lane, j, 1, w, S1);
           }
+    if (L.slotHB)
     for (int ps = 0; ps < 2; ++ps)
       for (int ch = 0; ch < NF + NMB; ++ch) {
         float* chunk = img + (size_t)NF * k1blk + ((size_t)ps * (NF + NMB) + ch) * chunkf;
@@ -524,6 +533,50 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
                 put(row_lane, j, 1, w, S);
               }
       }
+    // ---- the same backward network for k_net_h3s (RingS<c, 9 CI, NF, bwd>) ----
+    if (L.slotSB) {
+      const int KSSB = (9 * c + 31) / 32, NMSB = (9 * CI + 15) / 16, NRB = 2 * NFH, TPC = 2 * NFH, NT = NFH * NMSB;
+      const int NCHB = (NT + TPC - 1) / TPC, GS0 = NMSB < 6 ? NMSB : 6, GS1 = NMSB - GS0 > 0 ? NMSB - GS0 : 1;
+      const size_t k1blkS = (size_t)KSSB * 4 * 256;
+      float* imgS = dst + L.RSBp;
+      for (int blk = 0; blk < NF; ++blk)
+        for (int s2 = 0; s2 < KSSB; ++s2)
+          for (int rb = 0; rb < 2; ++rb)
+            for (int l = 0; l < 64; ++l)
+              for (int j = 0; j < 8; ++j) {
+                const int i = l & 15, kq = l >> 4, kk = 32 * s2 + 8 * kq + j;
+                const float w = kk < 9 * c ? W3b[(size_t)kk * F + blk * 32 + rb * 16 + i] : 0.0f;
+                float* row_lane = imgS + (size_t)blk * k1blkS + ((size_t)((s2 * 2 + rb) * 2) * 64 + l) * 4;
+                put(row_lane, j, 0, w, S1);
+                put(row_lane, j, 1, w, S1);
+              }
+      for (int ps = 0; ps < 2; ++ps)
+        for (int ch = 0; ch < NF + NCHB; ++ch) {
+          float* chunk = imgS + (size_t)NF * k1blkS + ((size_t)ps * (NF + NCHB) + ch) * chunkf;
+          for (int tp = 0; tp < NRB; ++tp)
+            for (int l = 0; l < 64; ++l)
+              for (int j = 0; j < 8; ++j) {
+                const int i = l & 15, kq = l >> 4;
+                const int kloc = 16 * (j >> 2) + 4 * kq + (j & 3);
+                float w = 0.0f;
+                int S = S2;
+                if (ch < NF) w = W2b[(size_t)(ch * 32 + kloc) * F + ps * NFH * 32 + tp * 16 + i];
+                else {
+                  const int t = (ch - NF) * TPC + tp;
+                  S = S3;
+                  if (t < NT) {
+                    const int fo = t < NFH * GS0 ? t / GS0 : (t - NFH * GS0) / GS1;
+                    const int mt = t < NFH * GS0 ? t % GS0 : GS0 + (t - NFH * GS0) % GS1;
+                    const int m = mt * 16 + i, f = (ps * NFH + fo) * 32 + kloc;
+                    if (m < 9 * CI) w = K1[(size_t)m * F + f];
+                  }
+                }
+                float* row_lane = chunk + ((size_t)(tp * 2) * 64 + l) * 4;
+                put(row_lane, j, 0, w, S);
+                put(row_lane, j, 1, w, S);
+              }
+        }
+    }
   }
 
   // ---- backward images (input-gradient path): same kernel structure, transposed weights ----
@@ -614,24 +667,40 @@ int launch_h3(const NetArgs& a, hipStream_t s, bool dry) {
   return 0;
 }
 
-template <int CI, int NF>
+template <int KIN, int MOUT, int NF, int MODE>
 int launch_h3s(const NetArgs& a, hipStream_t s, bool dry) {
-  constexpr bool F2 = RingS<CI, NF, 2>::FITS, F4 = RingS<CI, NF, 4>::FITS;
+  constexpr bool F2 = RingS<KIN, MOUT, NF, MODE, 2>::FITS, F4 = RingS<KIN, MOUT, NF, MODE, 4>::FITS;
   const int wgs = (a.Q + 255) / 256, cus = num_cus();
   if constexpr (F4) {
-    if (a.max_np >= 4 && 4 * wgs <= cus) {
-      if (!dry) hipLaunchKernelGGL((k_net_h3s<CI, NF, 4, true>), dim3(wgs, 4), dim3(512), 0, s, a);
+    if (a.max_np >= 4 && (4 * wgs <= cus || !F2)) {
+      const bool split = 4 * wgs <= cus;
+      if (!dry) {
+        if (split) hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE, 4, true>), dim3(wgs, 4), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE, 4, false>), dim3(wgs), dim3(512), 0, s, a);
+      }
       return 4;
     }
   }
   if constexpr (F2) {
     if (!dry) {
-      if (2 * wgs <= cus) hipLaunchKernelGGL((k_net_h3s<CI, NF, 2, true>), dim3(wgs, 2), dim3(512), 0, s, a);
-      else hipLaunchKernelGGL((k_net_h3s<CI, NF, 2, false>), dim3(wgs), dim3(512), 0, s, a);
+      if (2 * wgs <= cus) hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE, 2, true>), dim3(wgs, 2), dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE, 2, false>), dim3(wgs), dim3(512), 0, s, a);
     }
     return 2;
   }
   return 0;
+}
+
+// a level's saving forward pass and its backward pass run in ONE kernel family (their ReLU-mask layouts differ): the
+// 16x16x32 family if both have an instance that works whatever the batch size (NP = 4 if NP = 2 does not fit needs room
+// for four partial buffers, which the save buffers may not have)
+// ... and only where the grid fills the chip (measured: +3.3 % at 1024 tiles, -2.5 % at 30, where the launches are split
+// into passes and latency-bound).  Both launches of a level see the same pixel count, so they decide alike.
+inline bool big_grid(const NetArgs& a) { return 2 * ((a.Q + 255) / 256) > num_cus(); }
+
+template <int CI, int NF>
+constexpr bool fam16_ok() {
+  return RingS<CI, 18 * CI, NF, NET_FWD_SAVE, 2>::FITS && (RingS<2 * CI, 9 * CI, NF, NET_BWD, 2>::FITS || RingS<2 * CI, 9 * CI, NF, NET_BWD, 4>::FITS);
 }
 
 // returns the number of partial P buffers written (>= 1), or -1 on error
@@ -644,16 +713,22 @@ int launch_net_t(const NetArgs& a, int mode, hipStream_t s, bool dry) {
     case NET_FWD_SAVE: if (!dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE>), dim3(ntiles), dim3(256), 0, s, a); break;
     case NET_BWD:      if (!dry) hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD>), dim3(ntiles), dim3(256), 0, s, a); break;
     case 3:   // f16x3 arithmetic: forward / forward with saves / backward; shapes without an instance run the exact fp32 kernel
-      if (a.RSp && h3_shape16()) np = launch_h3s<CI, NF>(a, s, dry);
+      if (a.RSp && h3_shape16()) np = launch_h3s<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
       if (!np && a.RHp) np = launch_h3<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
       if (!np && !dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a);
       break;
     case 4:
-      if (a.RHp) np = launch_h3<CI, 18 * CI, NF, NET_FWD_SAVE>(a, s, dry);
+      if constexpr (fam16_ok<CI, NF>()) {
+        if (a.fam16 && h3_shape16() && big_grid(a)) np = launch_h3s<CI, 18 * CI, NF, NET_FWD_SAVE>(a, s, dry);
+      }
+      if (!np && a.RHp) np = launch_h3<CI, 18 * CI, NF, NET_FWD_SAVE>(a, s, dry);
       if (!np && !dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE>), dim3(ntiles), dim3(256), 0, s, a);
       break;
     case 5:
-      if (a.RHp) np = launch_h3<2 * CI, 9 * CI, NF, NET_BWD>(a, s, dry);
+      if constexpr (fam16_ok<CI, NF>()) {
+        if (a.fam16 && h3_shape16() && big_grid(a)) np = launch_h3s<2 * CI, 9 * CI, NF, NET_BWD>(a, s, dry);
+      }
+      if (!np && a.RHp) np = launch_h3<2 * CI, 9 * CI, NF, NET_BWD>(a, s, dry);
       if (!np && !dry) hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD>), dim3(ntiles), dim3(256), 0, s, a);
       break;
     default: fail("bad k_net mode"); return -1;
@@ -753,7 +828,7 @@ NetArgs net_args(glowk_handle* h, const Level& lv, const StepDev& sd, const floa
   a.vin = vin; a.in_stride = in_stride; a.in_off = in_off;
   a.Q = N * lv.h * lv.w; a.h = lv.h; a.w = lv.w;
   a.K1p = sd.K1p; a.ep = sd.ep; a.R0p = sd.R0p; a.mask1 = nullptr; a.mask2 = nullptr; a.P = h->bufP;
-  a.RHp = sd.RHp; a.RSp = sd.RSp; a.eph = sd.epH; a.pstride = h->pstride; a.max_np = 4; a.sc1 = sd.sc1; a.sc2 = sd.sc2; a.sc3 = sd.sc3;
+  a.RHp = sd.RHp; a.RSp = sd.RSp; a.fam16 = (sd.RSp && sd.RSBp) ? 1 : 0; a.eph = sd.epH; a.pstride = h->pstride; a.max_np = 4; a.sc1 = sd.sc1; a.sc2 = sd.sc2; a.sc3 = sd.sc3;
   return a;
 }
 
@@ -904,7 +979,7 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       na.mask1 = h->saveM + h->offM[sidx];
       na.mask2 = na.mask1 + blocks * NF * 64;
       const bool h3b = h->precision == GLOWK_PREC_F16X3 && sd.RHBp;
-      if (h3b) { na.RHp = sd.RHBp; na.eph = nullptr; na.sc1 = sd.scb1; na.sc2 = sd.scb2; na.sc3 = sd.scb3; }
+      if (h3b) { na.RHp = sd.RHBp; na.RSp = sd.RSBp; na.eph = nullptr; na.sc1 = sd.scb1; na.sc2 = sd.scb2; na.sc3 = sd.scb3; }
       if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, h3b ? 5 : NET_BWD, &npg)) return rc;
     }
     // first forward step of the block (k = K-1): merge, then through its ActNorm + 1x1 -> g_u of the squeezed block input
@@ -1131,6 +1206,7 @@ int glowk_finalize_weights(glowk_handle* h) {
       d.RHp = SL.slotH ? reinterpret_cast<const float4*>(base + SL.RHp) : nullptr;
       d.epH = SL.slotH ? base + SL.epH : nullptr;
       d.RSp = SL.slotS ? reinterpret_cast<const float4*>(base + SL.RSp) : nullptr;
+      d.RSBp = SL.slotSB ? reinterpret_cast<const float4*>(base + SL.RSBp) : nullptr;
       d.RHBp = SL.slotHB ? reinterpret_cast<const float4*>(base + SL.RHBp) : nullptr;
       d.K3bp = base + SL.K3bp;
       d.RBp = reinterpret_cast<const float4*>(base + SL.RBp);

@@ -48,7 +48,8 @@ struct NetArgs {
   int max_np;            // host side: how many partial buffers P has room for (caps the number of passes)
   const float4* RHp;     // f16x3 image (RingH) of the network this launch runs (forward or backward), or null
   const float* eph;      // forward: [conv2 accumulator init (F) | per-row constants of P (32 NMT)], see pack_step
-  const float4* RSp;     // the forward network's image for the 16x16x32 kernel (RingS; same constants and scales), or null
+  const float4* RSp;     // image for the 16x16x32 kernel (RingS; same constants and scales) of the network this launch runs, or null
+  int fam16;             // host side: this level's saving forward and backward launches both have a 16x16x32 image
   float sc1, sc2, sc3;   // f16x3: 2^-S of the three layers' weight scales (sc3 also undoes the activation scale)
 };
 
@@ -791,17 +792,19 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int CI, int NF, int NP>
+// KIN / MOUT / MODE / NP as for RingH
+template <int KIN, int MOUT, int NF, int MODE, int NP>
 struct RingS {
+  static constexpr bool BWD = MODE == NET_BWD;
   static constexpr int NFH = NF / NP;                             // hidden 32-channel blocks per pass
   static constexpr int NRB = 2 * NFH;                             // 16-row blocks per pass
-  static constexpr int K1 = 9 * CI;
-  static constexpr int KS = (K1 + 1 + 31) / 32;                   // conv1 k-steps of 32 (a spare row carries the bias)
+  static constexpr int K1 = 9 * KIN;
+  static constexpr int KS = (K1 + (BWD ? 0 : 1) + 31) / 32;       // small-conv k-steps of 32 (forward: a spare row carries the bias)
   static constexpr int MAINP = NRB * 2;                           // pieces per main chunk: NRB row blocks x (hi, lo)
   static constexpr int MAIN4 = MAINP * 64;
   static constexpr int K1P = KS * 4;                              // one block's conv1 operands: KS x 2 row blocks x (hi, lo)
   static constexpr int K14 = K1P * 64;
-  static constexpr int M3 = 18 * CI;
+  static constexpr int M3 = MOUT;
   static constexpr int NMT = (M3 + 15) / 16;                      // 16-row blocks of P
   static constexpr int TPC = MAINP / 2;                           // conv3 tiles (16 rows x 32 k, hi + lo) per chunk
   static constexpr int NT = NFH * NMT;                            // conv3 tiles per pass
@@ -810,8 +813,9 @@ struct RingS {
   static constexpr int G1N = NMT - G0N;
   static constexpr int G1D = G1N > 0 ? G1N : 1;
   static constexpr int EPN = (NF * 32 + 16 * NMT + 3) & ~3;       // conv2 accumulator init (F) | per-row constants of P
-  static constexpr size_t LDS_BYTES = (size_t)3 * MAIN4 * 16 + (size_t)2 * K14 * 16 + (size_t)EPN * 4;
-  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && NFH >= 2 && KS <= 3 && G1N <= 6 && NCH >= 2 &&
+  static constexpr int MASK2B = BWD ? 2 * NF * 512 * 2 : 0;       // backward: both ReLU masks of the workgroup's 8 column blocks
+  static constexpr size_t LDS_BYTES = (size_t)3 * MAIN4 * 16 + (size_t)2 * K14 * 16 + (size_t)EPN * 4 + MASK2B;
+  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && NFH >= 2 && KS <= (NP == 2 ? 3 : 5) && G1N <= 6 &&
                                (G1N == 0 || (NFH * G0N) % TPC == 0);
   // image (one for every NP, laid out for NP = 2): conv1 operands of all blocks, then per half of the hidden width the main
   // chunks (NF row blocks) and the conv3 tiles of NF/2 hidden blocks, 16 tiles per chunk; a pass of NP = 4 reads its half
@@ -840,49 +844,73 @@ __device__ __forceinline__ f32x4 mfma3s(const h8& ahi, const h8& alo, const h8& 
   return acc;
 }
 
-// ReLU + split of one hidden block (two row blocks) of one pixel half -> the B fragment of the next contraction
-__device__ __forceinline__ void h3s_act(const f32x4& r0, const f32x4& r1, float sc, h8& bh, h8& bl) {
+// activation + split of one hidden block (two row blocks) of one pixel half -> the B fragment of the next contraction.
+// Forward: ReLU (returns the 8 decisions as bits j = 4 * row block + r); backward: pass where the forward ReLU was open.
+template <int MODE>
+__device__ __forceinline__ unsigned h3s_act(const f32x4& r0, const f32x4& r1, float sc, unsigned mask8, h8& bh, h8& bl) {
   float v[8];
+  unsigned bits = 0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    v[j] = fmaxf(r0[j] * sc, 0.0f);
-    v[4 + j] = fmaxf(r1[j] * sc, 0.0f);
+  for (int j = 0; j < 8; ++j) {
+    const float acc = j < 4 ? r0[j] : r1[j - 4];
+    if (MODE == NET_BWD) v[j] = ((mask8 >> j) & 1u) ? acc * sc : 0.0f;
+    else {
+      v[j] = fmaxf(acc * sc, 0.0f);
+      if (MODE == NET_FWD_SAVE) bits |= (acc > 0.0f ? 1u : 0u) << j;
+    }
   }
   split8(v, bh, bl);
+  return bits;
 }
 
-template <int CI, int NF, int NP, int KP>
-__device__ __forceinline__ void h3s_X(const NetArgs& a, const H3Ctx& c, const h8 (&xh)[(RingS<CI, NF, NP>::KS)][2],
-                                      const h8 (&xl)[(RingS<CI, NF, NP>::KS)][2], int lane, h8 (&bh)[2], h8 (&bl)[2]) {
-  using G = RingS<CI, NF, NP>;
+// (the ReLU masks of this kernel family: per lane and hidden block 16 bits, bit 8 * pixel half + 4 * row block + r)
+template <int KIN, int MOUT, int NF, int MODE, int NP, int KP, int PASS>
+__device__ __forceinline__ void h3s_X(const NetArgs& a, const H3Ctx& c, int fi, const h8 (&xh)[(RingS<KIN, MOUT, NF, MODE, NP>::KS)][2],
+                                      const h8 (&xl)[(RingS<KIN, MOUT, NF, MODE, NP>::KS)][2], int lane, h8 (&bh)[2], h8 (&bl)[2]) {
+  using G = RingS<KIN, MOUT, NF, MODE, NP>;
+  unsigned mask = 0;
+  if (MODE == NET_BWD) mask = c.mkl[((size_t)(8 + (threadIdx.x >> 6)) * NF + fi) * 64 + lane];   // mask2: the ReLU after conv2
   f32x4 h1[2][2];   // [row block][pixel half]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) h1[i >> 1][i & 1][r] = 0.0f;
   const h8* k1 = reinterpret_cast<const h8*>(KP ? c.k1s1 : c.k1s0) + lane;   // [s][row block][hi|lo][64]
-  h8 kf[G::K1P];
+  if constexpr (G::KS <= 3) {       // all operand reads in flight before the first MFMA
+    h8 kf[G::K1P];
 #pragma unroll
-  for (int i = 0; i < G::K1P; ++i) kf[i] = k1[i * 64];
-  __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < G::K1P; ++i) kf[i] = k1[i * 64];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int s = 0; s < G::KS; ++s)
+    for (int s = 0; s < G::KS; ++s)
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+      for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-        h1[rb][hf] = mfma3s(kf[(s * 2 + rb) * 2 + 0], kf[(s * 2 + rb) * 2 + 1], xh[s][hf], xl[s][hf], h1[rb][hf]);
+        for (int hf = 0; hf < 2; ++hf)
+          h1[rb][hf] = mfma3s(kf[(s * 2 + rb) * 2 + 0], kf[(s * 2 + rb) * 2 + 1], xh[s][hf], xl[s][hf], h1[rb][hf]);
+  } else {
 #pragma unroll
-  for (int hf = 0; hf < 2; ++hf) h3s_act(h1[0][hf], h1[1][hf], a.sc1, bh[hf], bl[hf]);
+    for (int s = 0; s < G::KS; ++s)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const h8 ah = k1[((s * 2 + rb) * 2 + 0) * 64], al = k1[((s * 2 + rb) * 2 + 1) * 64];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) h1[rb][hf] = mfma3s(ah, al, xh[s][hf], xl[s][hf], h1[rb][hf]);
+      }
+  }
+  unsigned bits = 0;
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) bits |= h3s_act<MODE>(h1[0][hf], h1[1][hf], a.sc1, mask >> (8 * hf), bh[hf], bl[hf]) << (8 * hf);
+  if (MODE == NET_FWD_SAVE && PASS == 0 && c.wok) a.mask1[(c.wblk * NF + fi) * 64 + lane] = (unsigned short)bits;
 }
 
 // Y: conv2 contribution of one hidden block (one k-step of 32) to the pass's NRB x 2 accumulator tiles; same pipelining and
 // DMA duties as h3_Y (groups of 12 MFMAs = two row blocks x two pixel halves x three split terms)
-template <int CI, int NF, int NP, int TAG>
-__device__ __forceinline__ void h3s_Y(const float4* slot, const h8 (&bh)[2], const h8 (&bl)[2], f32x4 (&acc2)[(RingS<CI, NF, NP>::NRB)][2],
+template <int KIN, int MOUT, int NF, int MODE, int NP, int TAG>
+__device__ __forceinline__ void h3s_Y(const float4* slot, const h8 (&bh)[2], const h8 (&bl)[2], f32x4 (&acc2)[(RingS<KIN, MOUT, NF, MODE, NP>::NRB)][2],
                                       int lane, int g, bool main_ok, const float4* main_src, float4* main_dst, const float4* k1_src,
                                       float4* k1_dst, int w4, unsigned voff) {
-  using G = RingS<CI, NF, NP>;
+  using G = RingS<KIN, MOUT, NF, MODE, NP>;
   const h8* buf = reinterpret_cast<const h8*>(slot) + lane;
   const char* mb = uniform_ptr(main_src);
   constexpr int NG = G::NRB / 2;
@@ -930,11 +958,11 @@ __device__ __forceinline__ void h3s_Y(const float4* slot, const h8 (&bh)[2], con
 }
 
 // Z: conv3 op z of a pass = half a chunk of A tiles (16 rows x one hidden block)
-template <int CI, int NF, int NP, int P0, int PASS, bool SOLO, int Z>
-__device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const float* epl, f32x4 (&acc2)[(RingS<CI, NF, NP>::NRB)][2],
-                                      f32x4 (&acc3)[(RingS<CI, NF, NP>::G0N)][2], h8 (&bh)[2], h8 (&bl)[2], int g, const int (&q)[2],
+template <int KIN, int MOUT, int NF, int MODE, int NP, int P0, int PASS, bool SOLO, int Z>
+__device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const float* epl, f32x4 (&acc2)[(RingS<KIN, MOUT, NF, MODE, NP>::NRB)][2],
+                                      f32x4 (&acc3)[(RingS<KIN, MOUT, NF, MODE, NP>::G0N)][2], h8 (&bh)[2], h8 (&bl)[2], int g, const int (&q)[2],
                                       const bool (&qok)[2], int lane, int kq) {
-  using G = RingS<CI, NF, NP>;
+  using G = RingS<KIN, MOUT, NF, MODE, NP>;
   constexpr int NFH = G::NFH, M3 = G::M3, TPC = G::TPC;
   constexpr int S = Z >> 1;
   constexpr int P0N = (G::NCH + 1 + P0) & 1;
@@ -944,7 +972,7 @@ __device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const fl
       stage4<G::MAINP, 16 + Z>(G::out_chunk(c.img, PASS, SN), ((NF + SN - 1 + P0) & 1) ? c.sB : c.sA, c.w4, c.voff);
     if constexpr (PASS + 1 < NP && !SOLO && Z == 2 * G::NCH - 1) {
       stage4<G::MAINP, 48>(G::main_chunk(c.img, PASS + 1, 0), P0N ? c.sB : c.sA, c.w4, c.voff);
-      stage4<G::MAINP, 49>(G::out_chunk(c.img, PASS + 1, 0), c.sD, c.w4, c.voff);
+      if constexpr (G::NCH >= 2) stage4<G::MAINP, 49>(G::out_chunk(c.img, PASS + 1, 0), c.sD, c.w4, c.voff);   // (NCH = 1: slot D still read; see h3s_pass)
     }
   }
   const float4* slot = S == 0 ? c.sD : (((NF + S - 1 + P0) & 1) ? c.sB : c.sA);
@@ -959,8 +987,12 @@ __device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const fl
       const int fo = G::tile_fo(t), mt = G::tile_mt(t);
       const int ml = t >= NFH * G::G0N ? mt - G::G0N : mt;
       if (ml == 0) {
+        unsigned mask = 0, bits = 0;
+        if (MODE == NET_BWD) mask = c.mkl[((size_t)(threadIdx.x >> 6) * NF + PASS * NFH + fo) * 64 + lane];   // mask1: the ReLU after conv1
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) h3s_act(acc2[2 * fo][hf], acc2[2 * fo + 1][hf], a.sc2, bh[hf], bl[hf]);
+        for (int hf = 0; hf < 2; ++hf)
+          bits |= h3s_act<MODE>(acc2[2 * fo][hf], acc2[2 * fo + 1][hf], a.sc2, mask >> (8 * hf), bh[hf], bl[hf]) << (8 * hf);
+        if (MODE == NET_FWD_SAVE && t < NFH * G::G0N && c.wok) a.mask2[(c.wblk * NF + PASS * NFH + fo) * 64 + lane] = (unsigned short)bits;
       }
       if (fo == 0) {
 #pragma unroll
@@ -975,7 +1007,7 @@ __device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const fl
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = mt * 16 + 4 * kq + r;
-            if (m < M3 && qok[hf]) Pp[(size_t)m * a.Q + q[hf]] = PASS == 0 ? fmaf(acc3[ml][hf][r], a.sc3, pb[m]) : acc3[ml][hf][r] * a.sc3;
+            if (m < M3 && qok[hf]) Pp[(size_t)m * a.Q + q[hf]] = (PASS == 0 && MODE != NET_BWD) ? fmaf(acc3[ml][hf][r], a.sc3, pb[m]) : acc3[ml][hf][r] * a.sc3;
           }
       }
     }
@@ -983,17 +1015,17 @@ __device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const fl
   h3_wait_barrier();
 }
 
-template <int CI, int NF, int NP, int P0, int PASS, bool SOLO, int... Z>
-__device__ __forceinline__ void h3s_tail(const NetArgs& a, const H3Ctx& c, const float* epl, f32x4 (&acc2)[(RingS<CI, NF, NP>::NRB)][2],
-                                         f32x4 (&acc3)[(RingS<CI, NF, NP>::G0N)][2], h8 (&bh)[2], h8 (&bl)[2], int g, const int (&q)[2],
+template <int KIN, int MOUT, int NF, int MODE, int NP, int P0, int PASS, bool SOLO, int... Z>
+__device__ __forceinline__ void h3s_tail(const NetArgs& a, const H3Ctx& c, const float* epl, f32x4 (&acc2)[(RingS<KIN, MOUT, NF, MODE, NP>::NRB)][2],
+                                         f32x4 (&acc3)[(RingS<KIN, MOUT, NF, MODE, NP>::G0N)][2], h8 (&bh)[2], h8 (&bl)[2], int g, const int (&q)[2],
                                          const bool (&qok)[2], int lane, int kq, std::integer_sequence<int, Z...>) {
-  (h3s_Z<CI, NF, NP, P0, PASS, SOLO, Z>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, kq), ...);
+  (h3s_Z<KIN, MOUT, NF, MODE, NP, P0, PASS, SOLO, Z>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, kq), ...);
 }
 
-template <int CI, int NF, int NP, int P0, int PASS, bool SOLO>
-__device__ __forceinline__ void h3s_pass(const NetArgs& a, const H3Ctx& c, const float* epl, const h8 (&xh)[(RingS<CI, NF, NP>::KS)][2],
-                                         const h8 (&xl)[(RingS<CI, NF, NP>::KS)][2], int g, const int (&q)[2], const bool (&qok)[2], int lane, int kq) {
-  using G = RingS<CI, NF, NP>;
+template <int KIN, int MOUT, int NF, int MODE, int NP, int P0, int PASS, bool SOLO>
+__device__ __forceinline__ void h3s_pass(const NetArgs& a, const H3Ctx& c, const float* epl, const h8 (&xh)[(RingS<KIN, MOUT, NF, MODE, NP>::KS)][2],
+                                         const h8 (&xl)[(RingS<KIN, MOUT, NF, MODE, NP>::KS)][2], int g, const int (&q)[2], const bool (&qok)[2], int lane, int kq) {
+  using G = RingS<KIN, MOUT, NF, MODE, NP>;
   constexpr int NRB = G::NRB;
   constexpr int f2base = PASS * G::NFH * 32;
   f32x4 acc2[NRB][2];
@@ -1001,40 +1033,43 @@ __device__ __forceinline__ void h3s_pass(const NetArgs& a, const H3Ctx& c, const
   for (int ob = 0; ob < NRB; ++ob)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float b = epl[f2base + ob * 16 + 4 * kq + r];   // conv2 bias (scaled)
+      const float b = MODE == NET_BWD ? 0.0f : epl[f2base + ob * 16 + 4 * kq + r];   // conv2 bias (scaled)
       acc2[ob][0][r] = b;
       acc2[ob][1][r] = b;
     }
   h8 bh[2], bl[2];
 #pragma nounroll
   for (int i0 = 0; i0 < NF; i0 += 2) {
-    h3s_X<CI, NF, NP, 0>(a, c, xh, xl, lane, bh, bl);
+    h3s_X<KIN, MOUT, NF, MODE, NP, 0, PASS>(a, c, i0, xh, xl, lane, bh, bl);
     h3_wait_barrier();
-    h3s_Y<CI, NF, NP, 1>(P0 ? c.sB : c.sA, bh, bl, acc2, lane, g, true, G::main_chunk(c.img, PASS, i0 + 1), P0 ? c.sA : c.sB,
+    if (PASS >= 1 && !SOLO && G::NCH == 1 && i0 == 0 && !g)   // single output chunk: slot D of the previous pass is read until the phase before this one
+      stage4<G::MAINP, 50>(G::out_chunk(c.img, PASS, 0), c.sD, c.w4, c.voff);
+    h3s_Y<KIN, MOUT, NF, MODE, NP, 1>(P0 ? c.sB : c.sA, bh, bl, acc2, lane, g, true, G::main_chunk(c.img, PASS, i0 + 1), P0 ? c.sA : c.sB,
                          c.k1img + (size_t)((i0 + 2) % NF) * G::K14, c.k1s0, c.w4, c.voff);
     h3_barrier();
-    h3s_X<CI, NF, NP, 1>(a, c, xh, xl, lane, bh, bl);
+    h3s_X<KIN, MOUT, NF, MODE, NP, 1, PASS>(a, c, i0 + 1, xh, xl, lane, bh, bl);
     h3_wait_barrier();
-    h3s_Y<CI, NF, NP, 2>(P0 ? c.sA : c.sB, bh, bl, acc2, lane, g, true, i0 + 2 < NF ? G::main_chunk(c.img, PASS, i0 + 2) : G::out_chunk(c.img, PASS, 1),
+    h3s_Y<KIN, MOUT, NF, MODE, NP, 2>(P0 ? c.sA : c.sB, bh, bl, acc2, lane, g, i0 + 2 < NF || G::NCH >= 2,
+                         i0 + 2 < NF ? G::main_chunk(c.img, PASS, i0 + 2) : G::out_chunk(c.img, PASS, 1),
                          P0 ? c.sB : c.sA, c.k1img + (size_t)((i0 + 3) % NF) * G::K14, c.k1s1, c.w4, c.voff);
     h3_barrier();
   }
   f32x4 acc3[G::G0N][2];
-  h3s_tail<CI, NF, NP, P0, PASS, SOLO>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, kq, std::make_integer_sequence<int, 2 * G::NCH>());
+  h3s_tail<KIN, MOUT, NF, MODE, NP, P0, PASS, SOLO>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, kq, std::make_integer_sequence<int, 2 * G::NCH>());
 }
 
-template <int CI, int NF, int NP, int PASS, int P0>
-__device__ __forceinline__ void h3s_passes(const NetArgs& a, const H3Ctx& c, const float* epl, const h8 (&xh)[(RingS<CI, NF, NP>::KS)][2],
-                                           const h8 (&xl)[(RingS<CI, NF, NP>::KS)][2], int g, const int (&q)[2], const bool (&qok)[2], int lane, int kq) {
-  h3s_pass<CI, NF, NP, P0, PASS, false>(a, c, epl, xh, xl, g, q, qok, lane, kq);
-  if constexpr (PASS + 1 < NP) h3s_passes<CI, NF, NP, PASS + 1, (RingS<CI, NF, NP>::NCH + 1 + P0) & 1>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+template <int KIN, int MOUT, int NF, int MODE, int NP, int PASS, int P0>
+__device__ __forceinline__ void h3s_passes(const NetArgs& a, const H3Ctx& c, const float* epl, const h8 (&xh)[(RingS<KIN, MOUT, NF, MODE, NP>::KS)][2],
+                                           const h8 (&xl)[(RingS<KIN, MOUT, NF, MODE, NP>::KS)][2], int g, const int (&q)[2], const bool (&qok)[2], int lane, int kq) {
+  h3s_pass<KIN, MOUT, NF, MODE, NP, P0, PASS, false>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+  if constexpr (PASS + 1 < NP) h3s_passes<KIN, MOUT, NF, MODE, NP, PASS + 1, (RingS<KIN, MOUT, NF, MODE, NP>::NCH + 1 + P0) & 1>(a, c, epl, xh, xl, g, q, qok, lane, kq);
 }
 
-template <int CI, int NF, int NP, bool SPLIT>
+template <int KIN, int MOUT, int NF, int MODE, int NP, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
-  using G = RingS<CI, NF, NP>;
-  constexpr int K1 = G::K1;
+  using G = RingS<KIN, MOUT, NF, MODE, NP>;
   constexpr int KS = G::KS;
+  constexpr int SGN = (MODE == NET_BWD) ? -1 : 1;   // backward gathers at q - d(tap)
   static_assert(G::FITS, "shape");
 
   __shared__ float4 slotA[G::MAIN4];
@@ -1043,6 +1078,7 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
   __shared__ float4 k1slot0[G::K14];
   __shared__ float4 k1slot1[G::K14];
   __shared__ float epl[G::EPN];
+  __shared__ __attribute__((aligned(16))) unsigned short mkl[G::MASK2B / 2 + 8];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1059,7 +1095,7 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
   const int solo_pass = SPLIT ? (int)blockIdx.y : 0;
   c.k1img = a.RSp;
   c.img = a.RSp;
-  c.mkl = nullptr;
+  c.mkl = mkl;
   c.wblk = (size_t)blockIdx.x * 8 + wave;
   c.wok = (long)c.wblk * 32 < a.Q;
   c.w4 = wave & 3;
@@ -1068,9 +1104,13 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
   if (!g) {
     stage4<G::MAINP, 60>(G::main_chunk(c.img, solo_pass, 0), slotA, c.w4, c.voff);
     stage4<G::MAINP, 61>(G::out_chunk(c.img, solo_pass, 0), slotD, c.w4, c.voff);
+    if (MODE == NET_BWD)   // the forward pass's ReLU decisions of this workgroup's 8 column blocks: [mask1 | mask2][wave][block][lane]
+      stage4<NF, 64>(reinterpret_cast<const float4*>(a.mask1 + (size_t)blockIdx.x * 8 * NF * 64), reinterpret_cast<float4*>(mkl), c.w4, c.voff);
   } else {
     stage4<G::K1P, 62>(c.k1img, k1slot0, c.w4, c.voff);
     stage4<G::K1P, 63>(c.k1img + G::K14, k1slot1, c.w4, c.voff);
+    if (MODE == NET_BWD)
+      stage4<NF, 65>(reinterpret_cast<const float4*>(a.mask2 + (size_t)blockIdx.x * 8 * NF * 64), reinterpret_cast<float4*>(mkl + 8 * NF * 64), c.w4, c.voff);
   }
   // im2col fragments of this lane's two pixels: k-step s holds k = 32 s + 8 kq + j (natural order), scaled and split
   h8 xh[KS][2], xl[KS][2];
@@ -1085,25 +1125,26 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         float v[8];
-        gather8<CI, true, 1>(base, i, j0, a.h, a.w, a.in_stride, qok[hf], 32 * s + 8 * kq, v);
+        gather8<KIN, MODE != NET_BWD, SGN>(base, i, j0, a.h, a.w, a.in_stride, qok[hf], 32 * s + 8 * kq, v);
         split8(v, xh[s][hf], xl[s][hf]);
       }
     }
   }
-  for (int i = tid; i < G::EPN; i += 512) epl[i] = a.eph[i];   // RingS::EPN <= RingH::EPN, same content
+  if (MODE != NET_BWD)
+    for (int i = tid; i < G::EPN; i += 512) epl[i] = a.eph[i];   // RingS::EPN <= RingH::EPN, same content
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   if (g) h3_barrier();
   if constexpr (SPLIT) {
-    if (solo_pass == 0) h3s_pass<CI, NF, NP, 0, 0, true>(a, c, epl, xh, xl, g, q, qok, lane, kq);
-    else if (solo_pass == 1) h3s_pass<CI, NF, NP, 0, 1, true>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+    if (solo_pass == 0) h3s_pass<KIN, MOUT, NF, MODE, NP, 0, 0, true>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+    else if (solo_pass == 1) h3s_pass<KIN, MOUT, NF, MODE, NP, 0, 1, true>(a, c, epl, xh, xl, g, q, qok, lane, kq);
     else if constexpr (NP > 2) {
-      if (solo_pass == 2) h3s_pass<CI, NF, NP, 0, 2, true>(a, c, epl, xh, xl, g, q, qok, lane, kq);
-      else h3s_pass<CI, NF, NP, 0, 3, true>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+      if (solo_pass == 2) h3s_pass<KIN, MOUT, NF, MODE, NP, 0, 2, true>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+      else h3s_pass<KIN, MOUT, NF, MODE, NP, 0, 3, true>(a, c, epl, xh, xl, g, q, qok, lane, kq);
     }
   } else {
-    h3s_passes<CI, NF, NP, 0, 0>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+    h3s_passes<KIN, MOUT, NF, MODE, NP, 0, 0>(a, c, epl, xh, xl, g, q, qok, lane, kq);
   }
   if (!g) h3_barrier();
 }
