@@ -834,6 +834,7 @@ NetArgs net_args(glowk_handle* h, const Level& lv, const StepDev& sd, const floa
 
 // per-step save buffers of the input-gradient path, forward order index sidx = level*K + (K-1-k)
 int ensure_save(glowk_handle* h, int N) {
+  if (!h->bufC) HIPCHK(hipMalloc(&h->bufC, (size_t)h->wsN * (size_t)h->cfg.H * h->cfg.W * h->cfg.C * 4));   // (ensure_ws drops it when it grows)
   if (N <= h->saveN) return 0;
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipDeviceSynchronize());

@@ -1,0 +1,71 @@
+"""Randomised cross-check on the GPU (not part of the test suite): for random shapes and batch sizes -- i.e. random mixes of
+launch forms (2/4 passes, split or not, 16x16x32 or 32x32x16 tiling, one lane or four lanes per pixel) -- the fp16x3 kernels
+against the exact-fp32 kernels: log_prob, latent, inverse round trip, input gradient; plus batch independence (a tile's result
+does not depend on what else is in the batch)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from audiosourcesep_amd import _lib
+from audiosourcesep_amd.config import GlowConfig
+from audiosourcesep_amd.synthetic import calibrated_engine, synthetic_mel_tiles
+
+rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "0")))
+budget = float(os.environ.get("FUZZ_SECONDS", "240"))
+t_end = time.time() + budget
+case = 0
+worst = {"lp": 0.0, "g": 0.0, "inv": 0.0, "batch": 0.0}
+while time.time() < t_end:
+    L = int(rng.choice([2, 3, 3, 4]))
+    unit = 2 ** L
+    H, W = unit * int(rng.integers(1, 5)), unit * int(rng.integers(1, 5))
+    F = int(rng.choice([128, 128, 512]))
+    K = int(rng.integers(1, 4))
+    if os.environ.get("FUZZ_ONLY"):   # e.g. FUZZ_ONLY=64,64,4,3,512: hammer one shape (random weights, batch sizes, call order)
+        H, W, L, K, F = [int(v) for v in os.environ["FUZZ_ONLY"].split(",")]
+    cfg = GlowConfig(H=H, W=W, C=1, L=L, K=K, F=F)
+    eseed = int(rng.integers(1, 10 ** 6))
+    eng, params = calibrated_engine(cfg, device=0, init_tiles=16, seed=eseed)
+    for _ in range(3):
+        n = int(rng.choice([1, 2, 3, 7, 30, 64, 129, 300, 700])) if F == 128 else int(rng.choice([1, 3, 30, 65, 200]))
+        xseed = int(rng.integers(1, 10 ** 6))
+        x = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=xseed)).cuda()
+        eng.set_precision(_lib.PREC_F32)
+        lp32, g32 = eng.log_prob_grad(x)
+        z32, _ = eng.forward(x)
+        eng.set_precision(_lib.PREC_F16X3)
+        lp16, g16 = eng.log_prob_grad(x)
+        lp16b = eng.log_prob(x)
+        z16, _ = eng.forward(x)
+        xr = eng.inverse(z16)
+        e_lp = float(((lp16 - lp32).abs() / lp32.abs()).max())
+        e_lpb = float(((lp16b - lp32).abs() / lp32.abs()).max())
+        dg = (g16 - g32).abs() / g32.abs().max()
+        e_g = float(dg.max())
+        frac_g = float((dg > 1e-3).float().mean())      # isolated outliers = ReLU decisions that flipped between the arithmetics
+        e_inv = float((xr - x).abs().max())
+        j = int(rng.integers(0, n))
+        e_b = float(((eng.log_prob(x[j:j + 1]) - lp16b[j:j + 1]).abs() / lp16b[j:j + 1].abs()).max())
+        worst["lp"] = max(worst["lp"], e_lp, e_lpb); worst["g"] = max(worst["g"], e_g); worst["inv"] = max(worst["inv"], e_inv); worst["batch"] = max(worst["batch"], e_b)
+        ok = e_lp < 5e-6 and e_lpb < 5e-6 and (e_g < 2e-3 or (frac_g < 5e-4 and e_g < 2e-2)) and e_inv < 5e-2 and e_b < 5e-6 and bool(torch.isfinite(g16).all())
+        case += 1
+        print("%s case %d: H%d W%d L%d K%d F%d N%d  lp %.1e/%.1e grad %.1e (>1e-3: %.1e of the entries) inv %.1e batch %.1e" % ("ok  " if ok else "FAIL", case, H, W, L, K, F, n, e_lp, e_lpb, e_g, frac_g, e_inv, e_b), flush=True)
+        if not ok:
+            print("   replay: H=%d W=%d L=%d K=%d F=%d engine seed %d, N=%d tiles seed %d" % (H, W, L, K, F, eseed, n, xseed), flush=True)
+        if not ok:   # who is right?  both arithmetics against the fp64 autograd of the oracle.  A ReLU whose pre-activation is within
+            # rounding of zero may be decided differently by ANY arithmetic; one such flip moves a few dozen gradient entries by
+            # ~1e-3 of the maximum while log_prob does not notice -- tolerated; anything systematic is not.
+            from oracle import glowref_torch as RT
+            lp_ref, g_ref = RT.log_prob_and_grad(x.cpu().numpy().astype(np.float64), params, cfg.as_dict())
+            sc = np.abs(g_ref).max()
+            verdict = True
+            for name, gg in (("fp32", g32), ("f16x3", g16)):
+                d = np.abs(gg.cpu().numpy() - g_ref) / sc
+                tiles = sorted(set(np.argwhere(d > 1e-3)[:, 0].tolist()))
+                print("   %-5s vs fp64 autograd: max %.2e, entries > 1e-3: %d of %d, in tiles %s" % (name, d.max(), int((d > 1e-3).sum()), d.size, tiles[:6]), flush=True)
+                if d.max() > 2e-2 or len(tiles) > 3:
+                    verdict = False
+            lp_ok = e_lp < 5e-6 and e_lpb < 5e-6 and e_inv < 5e-2 and e_b < 5e-6 and bool(torch.isfinite(g16).all())
+            if not (verdict and lp_ok):
+                sys.exit(1)
+            print("   -> isolated ReLU flips, tolerated", flush=True)
+print("fuzz: %d cases, worst %s" % (case, worst))
