@@ -26,7 +26,12 @@ def sharded_log_prob(log_prob_fn, x_local, group=None):
     lp = log_prob_fn(x_local) if x_local.shape[0] else torch.zeros(0, dtype=torch.float32, device=x_local.device)
     total = lp.sum(dtype=torch.float64).reshape(1)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+        if total.is_cuda and dist.get_backend(group) == "gloo":   # rehearsal of the multi-process path without RCCL
+            t = total.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            total = t.to(total.device)
+        else:
+            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
     return lp, total[0]
 
 

@@ -121,7 +121,7 @@ def secondary_workload(args, cfg, eng, params, rank, world, local_rank, dist):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if dist.get_backend() == "gloo" else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
@@ -158,13 +158,21 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    # GLOWK_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend -- exercises the multi-process control flow (sharding,
+    # barriers, max-over-ranks timing, rank-0 JSON) on a one-GPU box; the numbers it prints mean nothing
+    rehearsal = os.environ.get("GLOWK_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     cfg = {"A": CONFIG_A, "B": CONFIG_B, "YAML": CONFIG_YAML}[args.config]
     from audiosourcesep_amd import _lib
@@ -205,7 +213,7 @@ def main():
         el = time.perf_counter() - t0
         pr = eng.profile_end()
         if dist is not None:
-            t = torch.tensor([el], device="cuda", dtype=torch.float64)
+            t = torch.tensor([el], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, pr
