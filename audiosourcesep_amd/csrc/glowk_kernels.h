@@ -1149,6 +1149,7 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
   if (!g) h3_barrier();
 }
 
+#ifndef GLOWK_NET_ONLY   // (the per-shape translation units of the coupling-network kernels stop here)
 // ------------------------------------------------------------------------------------------------
 // light kernels: one 256-thread workgroup per sample (deterministic per-sample reductions, no atomics)
 // ------------------------------------------------------------------------------------------------
@@ -1718,3 +1719,4 @@ __global__ __launch_bounds__(256) void k_bwd_in(const float* __restrict__ gu, co
     }
   }
 }
+#endif  // GLOWK_NET_ONLY

@@ -1,0 +1,117 @@
+// Launch policy of the coupling-network kernels (which kernel family, how many passes, split or not), as templates over the
+// level shape.  The heavy kernels are instantiated ONLY through launch_net_t<CI, NF>; each (CI, NF) pair is explicitly
+// instantiated in its own translation unit (glowk_net_inst.hip, compiled once per pair), so the ~100 kernel instances build
+// in parallel; glowk.hip sees extern template declarations.
+#pragma once
+#include "glowk_kernels.h"
+
+#include <string>
+
+namespace glowk_detail {
+
+int num_cus();                          // compute units of the current device (queried once); glowk.hip
+bool h3_shape16();                      // GLOWK_H3_SHAPE=32 keeps the forward pass on the 32x32x16 kernel (A/B timing); glowk.hip
+void launch_fail(const std::string&);   // sets glowk_last_error(); glowk.hip
+
+// k_net_h3 / k_net_h3s launch forms.  NP = passes over the hidden width (2, or 4 where the shape needs the registers);
+// when NP workgroups per 256 pixels still fit the CUs in one round the passes become workgroups of their own (SPLIT):
+// 1/NP of the latency per launch.  Returns the number of partial P buffers the launch writes (= NP), 0 if no instance fits.
+// dry: decide only (the consumers of P need the same answer).
+template <int KIN, int MOUT, int NF, int MODE>
+int launch_h3(const NetArgs& a, hipStream_t s, bool dry) {
+  constexpr bool F2 = RingH<KIN, MOUT, NF, MODE, 2>::FITS, F4 = RingH<KIN, MOUT, NF, MODE, 4>::FITS;
+  const int wgs = (a.Q + 255) / 256, cus = num_cus();
+  if constexpr (F4) {
+    if (a.max_np >= 4 && (4 * wgs <= cus || !F2)) {
+      const bool split = 4 * wgs <= cus;
+      if (!dry) {
+        if (split) hipLaunchKernelGGL((k_net_h3<KIN, MOUT, NF, MODE, 4, true>), dim3(wgs, 4), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((k_net_h3<KIN, MOUT, NF, MODE, 4, false>), dim3(wgs), dim3(512), 0, s, a);
+      }
+      return 4;
+    }
+  }
+  if constexpr (F2) {
+    if (!dry) {
+      if (2 * wgs <= cus) hipLaunchKernelGGL((k_net_h3<KIN, MOUT, NF, MODE, 2, true>), dim3(wgs, 2), dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((k_net_h3<KIN, MOUT, NF, MODE, 2, false>), dim3(wgs), dim3(512), 0, s, a);
+    }
+    return 2;
+  }
+  return 0;
+}
+
+template <int KIN, int MOUT, int NF, int MODE>
+int launch_h3s(const NetArgs& a, hipStream_t s, bool dry) {
+  constexpr bool F2 = RingS<KIN, MOUT, NF, MODE, 2>::FITS, F4 = RingS<KIN, MOUT, NF, MODE, 4>::FITS;
+  const int wgs = (a.Q + 255) / 256, cus = num_cus();
+  if constexpr (F4) {
+    if (a.max_np >= 4 && (4 * wgs <= cus || !F2)) {
+      const bool split = 4 * wgs <= cus;
+      if (!dry) {
+        if (split) hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE, 4, true>), dim3(wgs, 4), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE, 4, false>), dim3(wgs), dim3(512), 0, s, a);
+      }
+      return 4;
+    }
+  }
+  if constexpr (F2) {
+    if (!dry) {
+      if (2 * wgs <= cus) hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE, 2, true>), dim3(wgs, 2), dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE, 2, false>), dim3(wgs), dim3(512), 0, s, a);
+    }
+    return 2;
+  }
+  return 0;
+}
+
+// a level's saving forward pass and its backward pass run in ONE kernel family (their ReLU-mask layouts differ): the
+// 16x16x32 family if both have an instance that works whatever the batch size (NP = 4 if NP = 2 does not fit needs room
+// for four partial buffers, which the save buffers may not have)
+// ... and only where the grid fills the chip (measured: +3.3 % at 1024 tiles, -2.5 % at 30, where the launches are split
+// into passes and latency-bound).  Both launches of a level see the same pixel count, so they decide alike.
+inline bool big_grid(const NetArgs& a) { return 2 * ((a.Q + 255) / 256) > num_cus(); }
+
+template <int CI, int NF>
+constexpr bool fam16_ok() {
+  return RingS<CI, 18 * CI, NF, NET_FWD_SAVE, 2>::FITS && (RingS<2 * CI, 9 * CI, NF, NET_BWD, 2>::FITS || RingS<2 * CI, 9 * CI, NF, NET_BWD, 4>::FITS);
+}
+
+// returns the number of partial P buffers written (>= 1), or -1 on error
+template <int CI, int NF>
+int launch_net_t(const NetArgs& a, int mode, hipStream_t s, bool dry) {
+  const int ntiles = (a.Q + 127) / 128;
+  int np = 0;
+  switch (mode) {
+    case NET_FWD:      if (!dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a); break;
+    case NET_FWD_SAVE: if (!dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE>), dim3(ntiles), dim3(256), 0, s, a); break;
+    case NET_BWD:      if (!dry) hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD>), dim3(ntiles), dim3(256), 0, s, a); break;
+    case 3:   // f16x3 arithmetic: forward / forward with saves / backward; shapes without an instance run the exact fp32 kernel
+      if (a.RSp && h3_shape16()) np = launch_h3s<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
+      if (!np && a.RHp) np = launch_h3<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
+      if (!np && !dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a);
+      break;
+    case 4:
+      if constexpr (fam16_ok<CI, NF>()) {
+        if (a.fam16 && h3_shape16() && big_grid(a)) np = launch_h3s<CI, 18 * CI, NF, NET_FWD_SAVE>(a, s, dry);
+      }
+      if (!np && a.RHp) np = launch_h3<CI, 18 * CI, NF, NET_FWD_SAVE>(a, s, dry);
+      if (!np && !dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE>), dim3(ntiles), dim3(256), 0, s, a);
+      break;
+    case 5:
+      if constexpr (fam16_ok<CI, NF>()) {
+        if (a.fam16 && h3_shape16() && big_grid(a)) np = launch_h3s<2 * CI, 9 * CI, NF, NET_BWD>(a, s, dry);
+      }
+      if (!np && a.RHp) np = launch_h3<2 * CI, 9 * CI, NF, NET_BWD>(a, s, dry);
+      if (!np && !dry) hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD>), dim3(ntiles), dim3(256), 0, s, a);
+      break;
+    default: launch_fail("bad k_net mode"); return -1;
+  }
+  if (!dry) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { launch_fail(std::string("k_net: ") + hipGetErrorString(e)); return -1; }
+  }
+  return np ? np : 1;
+}
+
+}  // namespace glowk_detail
