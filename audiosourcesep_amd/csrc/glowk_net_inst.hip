@@ -2,6 +2,10 @@
 // kernel instance of that shape (fp32 and fp16x3, both tilings, 2 and 4 passes, split or not, three modes).
 // Compiled by __graft_entry__.build() with -DGLOWK_INST_CI=<ci> -DGLOWK_INST_NF=<nf>.
 #define GLOWK_NET_ONLY
+#ifndef GLOWK_INST_CI   // (a bare "hipcc -c" of this file still compiles: the level-1 shape of the benchmark config)
+#define GLOWK_INST_CI 2
+#define GLOWK_INST_NF 16
+#endif
 #include "glowk_launch.h"
 
 namespace glowk_detail {
