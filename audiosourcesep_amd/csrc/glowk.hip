@@ -815,7 +815,8 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
         na.mask2 = na.mask1 + blocks * NF * 64;
       }
       int np = 1;   // the f16x3 kernels leave P as np partial sums (one per pass over the hidden width)
-      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, h->precision == GLOWK_PREC_F16X3 ? (save ? 4 : 3) : (save ? NET_FWD_SAVE : NET_FWD), &np)) return rc;
+      const bool f16_fwd = h->precision == GLOWK_PREC_F16X3;
+      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, f16_fwd ? (save ? 4 : 3) : (save ? NET_FWD_SAVE : NET_FWD), &np)) return rc;
       if (save) h->save_parts[sidx] = np;
       CoupleArgs ca;
       ca.vin = cur; ca.P = na.P; ca.np = np; ca.pstride = na.pstride; ca.b3 = sd.b3; ca.logdet = h->bufLd; ca.log_s_out = nullptr; ca.t_out = nullptr;

@@ -164,8 +164,11 @@ __device__ __forceinline__ void net_step(const NetArgs& a, int fi, bool first, c
     }
     if (MODE == NET_FWD_SAVE) a.mask1[(wblk * NF + fi) * 64 + lane] = (unsigned short)bits;
   }
-  if (!first || G::K1_IN_BUF) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {
+    // ALSO at the first step: block 0's small-conv operands were staged behind slot 1's main part, and the DMA below rewrites
+    // that slot -- without this barrier a wave still in conv1(0) could read block 2's operands (seen as run-to-run
+    // differences of the K = 72 backward kernel in 1 % of the calls: its 36 MFMAs leave the widest window)
+    if (!first || G::K1_IN_BUF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing is in flight at the first step)
     __syncthreads();   // chunk fi landed in every wave's view; slot P^1 (and the separate operand buffer) is no longer read
   }
   stage_range<0, G::PIECES>(nsrc, ring_slot<P ^ 1>(s0, s1), wave, voff);

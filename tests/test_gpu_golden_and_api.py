@@ -220,3 +220,20 @@ def test_input_gradient_f16x3_full_width():
     lp32, g32 = eng.log_prob_grad(xl)
     np.testing.assert_allclose(lp16.cpu().numpy(), lp32.cpu().numpy(), rtol=2e-6)
     np.testing.assert_allclose(g16.cpu().numpy(), g32.cpu().numpy(), atol=1e-3 * float(g32.abs().max()), rtol=5e-3)
+
+
+def test_gradient_path_is_bitwise_repeatable():
+    """Regression for a missing barrier at the first step of k_net_f32 (block 0's small-conv operands could be overwritten by
+    the first weight DMA while a slow wave was still reading them): 1 % of the exact-fp32 gradient calls differed from run to
+    run in a few tiles.  400 repeats of one call, both arithmetics, every result bitwise equal to the first."""
+    from audiosourcesep_amd import _lib
+    from audiosourcesep_amd.synthetic import calibrated_engine
+    cfg = GlowConfig(H=64, W=64, C=1, L=2, K=3, F=512)
+    eng, _ = calibrated_engine(cfg, device=0, init_tiles=16, seed=5)
+    x = dev(synthetic_mel_tiles(200, cfg, seed=300))
+    for prec in (_lib.PREC_F32, _lib.PREC_F16X3):
+        eng.set_precision(prec)
+        lp0, g0 = eng.log_prob_grad(x)
+        for _ in range(400 if prec == _lib.PREC_F32 else 100):
+            lp, g = eng.log_prob_grad(x)
+            assert torch.equal(lp, lp0) and torch.equal(g, g0)
