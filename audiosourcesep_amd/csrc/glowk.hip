@@ -388,7 +388,7 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
           }
     }
     const int S1 = pow2_scale(K1f.data(), K1f.size()), S2 = pow2_scale(K2f.data(), K2f.size()), S3 = pow2_scale(K3f.data(), K3f.size());
-    const float act = 32.0f;                        // GLOWK_ACT_SCALE
+    const float act = GLOWK_ACT_SCALE;
     scales3[0] = std::ldexp(1.0f, -S1); scales3[1] = std::ldexp(1.0f, -S2); scales3[2] = std::ldexp(1.0f, -S3) / act;
     {
       float* eh = dst + L.epH;          // [conv2 accumulator init (F) | pb (32 * NMT)]
@@ -494,7 +494,7 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
     for (int f2 = 0; f2 < F; ++f2)
       for (int f1 = 0; f1 < F; ++f1) W2b[(size_t)f2 * F + f1] = K2[(size_t)f1 * F + f2] * ep[F + f1];      // [k = f2][out = f1]
     const int S1 = pow2_scale(W3b.data(), W3b.size()), S2 = pow2_scale(W2b.data(), W2b.size()), S3 = pow2_scale(K1, (size_t)9 * CI * F);
-    scales3[3] = std::ldexp(1.0f, -S1); scales3[4] = std::ldexp(1.0f, -S2); scales3[5] = std::ldexp(1.0f, -S3) / 32.0f;
+    scales3[3] = std::ldexp(1.0f, -S1); scales3[4] = std::ldexp(1.0f, -S2); scales3[5] = std::ldexp(1.0f, -S3) / GLOWK_ACT_SCALE;
     const size_t k1blk = (size_t)KSB * 2 * 256, chunkf = (size_t)NFH * 1024;
     float* img = dst + L.RHBp;
     if (L.slotHB)

@@ -102,11 +102,14 @@ def secondary_workload(args, cfg, eng, params, rank, world, local_rank, dist):
         m1, m2 = GlowFlow(eng), GlowFlow(eng2)
         x2 = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=4321 + rank)).cuda()
         mixed = basis.mixing_db(x, x2)
-        state = {"x1": torch.rand_like(x) * 120 - 100, "x2": torch.rand_like(x) * 120 - 100}
+        # state: mel-like tiles (other seeds), not the reference's uniform draw -- the synthetic priors are far out of their
+        # domain on uniform noise (log_prob ~ -1e33), and timing a loop that carries inf/NaN would not be a measurement
+        state = {"x1": torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=777 + rank)).cuda(),
+                 "x2": torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=888 + rank)).cuda()}
         sigmas = basis.get_sigmas(1.0, 0.01, 10)
 
-        def step():
-            state["x1"], state["x2"] = basis.basis_inner_loop(mixed, state["x1"], state["x2"], m1, m2, 9, sigmas, T=1)
+        def step():   # every step starts from the same state: with these untrained priors the chain itself diverges within ~8 steps
+            state["y1"], state["y2"] = basis.basis_inner_loop(mixed, state["x1"], state["x2"], m1, m2, 9, sigmas, T=1)
         unit, metric, per_step = "tile-steps/s", "BASIS Langevin tile-steps/sec (2 Glow priors)", n
     for _ in range(args.warmup):
         step()
@@ -120,6 +123,8 @@ def secondary_workload(args, cfg, eng, params, rank, world, local_rank, dist):
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if args.workload == "basis":
+        assert torch.isfinite(state["y1"]).all() and torch.isfinite(state["y2"]).all(), "BASIS update left the finite range"
     if dist is not None:
         t = torch.tensor([elapsed], device="cpu" if dist.get_backend() == "gloo" else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -75,7 +75,7 @@ enum glowk_precision {
   GLOWK_PREC_F32 = 0,     /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (default) */
   GLOWK_PREC_F16X3 = 1    /* error-compensated split: x = hi + lo in fp16, 3 fp16 MFMAs per product, fp32 accumulate:
                              fp32-class results (~5e-8 relative on log_prob) at ~3x the speed; assumes hidden activations
-                             below 2047 in magnitude (any normalised flow) */
+                             below 16 376 in magnitude (any normalised flow) */
 };
 
 int glowk_version(void);
