@@ -170,9 +170,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # GLOWK_BENCH_FORCE_DIST=1: take the RCCL path (init, barriers, all-reduces) even with one rank -- a one-GPU check that
+    # the process-group calls this file makes work on the box's RCCL build
+    if world > 1 or os.environ.get("GLOWK_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -282,12 +285,14 @@ def main():
         value = passes / elapsed
         value_o = n * world * steps_o / elapsed_o
         net_ms_total = sum(m for m, _ in prof)
-        dtype_name = {"f32": "f32", "f16x3": "f16x3 (fp16 hi/lo split, 3 MFMAs per product, fp32 accumulate; fp32-class accuracy)"}
+        dtype_name = {"f32": "f32", "f16x3": "f16x3"}
+        dtype_note = {"f32": "fp32 operands on v_mfma_f32_32x32x2_f32, fp32 accumulate",
+                      "f16x3": "fp32 operands split into fp16 hi + lo, 3 fp16 MFMAs per product, fp32 accumulate"}
         out = {
             "metric": baseline_metric() if args.config == "B" else "Glow fwd+logdet passes/sec (config %s)" % args.config,
             "value": value, "unit": "passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": dtype_name[args.precision],
+            "vs_baseline": None, "dtype": dtype_name[args.precision], "dtype_note": dtype_note[args.precision],
             "data": "synthetic",
             "config": {"workload": "Glow log_prob, %dx%dx%d mel tiles, L=%d K=%d n_filters=%d, %d tiles/GPU/step"
                                    % (cfg.H, cfg.W, cfg.C, cfg.L, cfg.K, cfg.F, n),
