@@ -64,6 +64,7 @@ SYMBOLS = {
     "glowk_get_precision": (_i, [_vp]),
     "glowk_workspace_bytes": (ctypes.c_size_t, [_vp, _i]),
     "glowk_reserve": (_i, [_vp, _i]),
+    "glowk_max_tiles": (_i, [_vp]),
     "glowk_forward": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "glowk_inverse": (_i, [_vp, _vp, _i, _vp, _vp]),
     "glowk_log_prob": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),

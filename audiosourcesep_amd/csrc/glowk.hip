@@ -729,10 +729,25 @@ int ensure_ws(glowk_handle* h, int N) {
   return 0;
 }
 
+// pixel and element indices of a call are 32-bit in the light kernels: one call takes at most 2^28 elements (1 GiB of tiles,
+// 22 GB of workspace); larger batches are the caller's loop (the Python mirror chunks by glowk_max_tiles)
+int max_tiles(const glowk_handle* h) {
+  const long long E = (long long)h->cfg.H * h->cfg.W * h->cfg.C;
+  const long long m = (1LL << 28) / E;
+  return m < 1 ? 1 : (int)m;
+}
+
+int check_batch(const glowk_handle* h, int N) {
+  if (N <= 0) return fail("batch size must be positive");
+  if (N > max_tiles(h)) return fail("batch of " + std::to_string(N) + " tiles exceeds glowk_max_tiles() = " + std::to_string(max_tiles(h)) +
+                                    " (32-bit indices within one call): split the batch");
+  return 0;
+}
+
 int check_ready(glowk_handle* h, int N) {
   if (!h) return fail("null handle");
   if (!h->finalized) return fail("glowk_finalize_weights has not been called");
-  if (N <= 0) return fail("batch size must be positive");
+  if (int rc = check_batch(h, N)) return rc;
   return ensure_ws(h, N);
 }
 
@@ -1263,9 +1278,11 @@ size_t glowk_workspace_bytes(const glowk_handle* h, int N) {
   return (size_t)N * E * 4 * 21 + (size_t)N * 8;
 }
 
+int glowk_max_tiles(const glowk_handle* h) { return h ? max_tiles(h) : 0; }
+
 int glowk_reserve(glowk_handle* h, int N) {
   if (!h) return fail("null handle");
-  if (N <= 0) return fail("batch size must be positive");
+  if (int rc = check_batch(h, N)) return rc;
   return ensure_ws(h, N);
 }
 
@@ -1362,6 +1379,7 @@ int glowk_profile_end(glowk_handle* h, glowk_profile* out) {
 int glowk_squeeze(const float* x_dev, int N, int H, int W, int C, float* y_dev, void* stream) {
   if (!x_dev || !y_dev) return fail("null tensor");
   if (N <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2) return fail("squeeze needs even H and W");  // flow_tfp_bijectors.py:165-166
+  if ((long long)N * H * W * C > (1LL << 28)) return fail("squeeze: more than 2^28 elements in one call; split the batch");
   PreArgs p = {0, 1, 0, 0};
   const int c = 4 * C;
   CDISPATCH(c, hipLaunchKernelGGL((k_in<CC>), dim3(N), dim3(256), 0, (hipStream_t)stream, x_dev, H, W, p, 0, (const float*)nullptr,
@@ -1373,6 +1391,7 @@ int glowk_squeeze(const float* x_dev, int N, int H, int W, int C, float* y_dev, 
 int glowk_unsqueeze(const float* y_dev, int N, int hh, int ww, int c4, float* x_dev, void* stream) {
   if (!x_dev || !y_dev) return fail("null tensor");
   if (N <= 0 || hh <= 0 || ww <= 0 || c4 % 4) return fail("unsqueeze needs a channel count divisible by 4");
+  if ((long long)N * hh * ww * c4 > (1LL << 28)) return fail("unsqueeze: more than 2^28 elements in one call; split the batch");
   PreArgs p = {0, 1, 0, 0};
   CDISPATCH(c4, hipLaunchKernelGGL((k_out<CC>), dim3(N), dim3(256), 0, (hipStream_t)stream, y_dev, hh, ww, p, 0, x_dev));
   LAUNCHCHK("k_out(unsqueeze)");
@@ -1381,7 +1400,7 @@ int glowk_unsqueeze(const float* y_dev, int N, int hh, int ww, int c4, float* x_
 
 int glowk_preprocess_forward(glowk_handle* h, const float* x_dev, int N, float* y_dev, float* logdet_dev, void* stream) {
   if (!h || !x_dev || !y_dev) return fail("null argument");
-  if (N <= 0) return fail("batch size must be positive");
+  if (int rc = check_batch(h, N)) return rc;
   const int E = h->cfg.H * h->cfg.W * h->cfg.C;
   double ldc = -(double)E * std::log((double)h->cfg.maxval - (double)h->cfg.minval);
   if (h->cfg.use_logit) ldc += (double)E * std::log(1.0 - 2.0 * (double)h->cfg.alpha);
@@ -1392,7 +1411,7 @@ int glowk_preprocess_forward(glowk_handle* h, const float* x_dev, int N, float* 
 
 int glowk_preprocess_inverse(glowk_handle* h, const float* y_dev, int N, float* x_dev, void* stream) {
   if (!h || !x_dev || !y_dev) return fail("null argument");
-  if (N <= 0) return fail("batch size must be positive");
+  if (int rc = check_batch(h, N)) return rc;
   const int E = h->cfg.H * h->cfg.W * h->cfg.C;
   hipLaunchKernelGGL(k_pre_only, dim3(N), dim3(256), 0, (hipStream_t)stream, y_dev, E, pre_args(h->cfg), 1, x_dev, (float*)nullptr, 0.0);
   LAUNCHCHK("k_pre_only");

@@ -34,6 +34,7 @@ class GlowEngine:
         _lib.check(self.lib.glowk_create(ctypes.byref(c), self.device.index, ctypes.byref(h)))
         self.h = h
         self._finalized = False
+        self._max_tiles_cap = None   # tests lower it to exercise the chunk loop on small batches
 
     def close(self):
         if getattr(self, "h", None):
@@ -100,7 +101,17 @@ class GlowEngine:
         return int(self.lib.glowk_get_precision(self.h))
 
     def reserve(self, n):
-        _lib.check(self.lib.glowk_reserve(self.h, int(n)))
+        _lib.check(self.lib.glowk_reserve(self.h, min(int(n), self.max_tiles)))
+
+    @property
+    def max_tiles(self):
+        """Largest batch one C-ABI call takes (glowk_max_tiles); the methods below loop over chunks of it."""
+        m = int(self.lib.glowk_max_tiles(self.h))
+        return min(m, self._max_tiles_cap) if self._max_tiles_cap else m
+
+    def _chunks(self, n):
+        m = self.max_tiles
+        return [(i, min(i + m, n)) for i in range(0, n, m)]
 
     def workspace_bytes(self, n):
         return int(self.lib.glowk_workspace_bytes(self.h, int(n)))
@@ -140,7 +151,9 @@ class GlowEngine:
         ld = self._new(n) if with_logdet else None
         if n == 0:   # an empty batch is an empty result (TF semantics), not a launch
             return (z, ld) if with_logdet else z
-        _lib.check(self.lib.glowk_forward(self.h, _ptr(x), n, _ptr(z), _ptr(ld), _stream_ptr()))
+        for a, b in self._chunks(n):   # tiles are independent: a batch beyond max_tiles is a loop over chunks
+            _lib.check(self.lib.glowk_forward(self.h, _ptr(x[a:b]), b - a, _ptr(z[a:b]), _ptr(ld[a:b] if with_logdet else None),
+                                              _stream_ptr()))
         return (z, ld) if with_logdet else z
 
     def inverse(self, z):
@@ -149,7 +162,8 @@ class GlowEngine:
         x = self._new(n, *self.data_shape)
         if n == 0:
             return x
-        _lib.check(self.lib.glowk_inverse(self.h, _ptr(z), n, _ptr(x), _stream_ptr()))
+        for a, b in self._chunks(n):
+            _lib.check(self.lib.glowk_inverse(self.h, _ptr(z[a:b]), b - a, _ptr(x[a:b]), _stream_ptr()))
         return x
 
     def log_prob(self, x, return_latent=False, out=None):
@@ -159,7 +173,9 @@ class GlowEngine:
         z = self._new(n, *self.cfg.latent_shape()) if return_latent else None
         if n == 0:
             return (lp, z) if return_latent else lp
-        _lib.check(self.lib.glowk_log_prob(self.h, _ptr(x), n, _ptr(lp), _ptr(z), _stream_ptr()))
+        for a, b in self._chunks(n):
+            _lib.check(self.lib.glowk_log_prob(self.h, _ptr(x[a:b]), b - a, _ptr(lp[a:b]), _ptr(z[a:b] if return_latent else None),
+                                               _stream_ptr()))
         return (lp, z) if return_latent else lp
 
     def log_prob_grad(self, x):
@@ -168,7 +184,8 @@ class GlowEngine:
         lp, dx = self._new(n), torch.empty_like(x)
         if n == 0:
             return lp, dx
-        _lib.check(self.lib.glowk_log_prob_grad(self.h, _ptr(x), n, _ptr(lp), _ptr(dx), _stream_ptr()))
+        for a, b in self._chunks(n):
+            _lib.check(self.lib.glowk_log_prob_grad(self.h, _ptr(x[a:b]), b - a, _ptr(lp[a:b]), _ptr(dx[a:b]), _stream_ptr()))
         return lp, dx
 
     def sample_from_eps(self, eps):
@@ -177,13 +194,15 @@ class GlowEngine:
         x = self._new(n, *self.data_shape)
         if n == 0:
             return x
-        _lib.check(self.lib.glowk_sample(self.h, _ptr(eps), n, _ptr(x), _stream_ptr()))
+        for a, b in self._chunks(n):
+            _lib.check(self.lib.glowk_sample(self.h, _ptr(eps[a:b]), b - a, _ptr(x[a:b]), _stream_ptr()))
         return x
 
     def prior_log_prob(self, z):
         z = self._in(z, self.cfg.latent_shape())
         lp = self._new(z.shape[0])
-        _lib.check(self.lib.glowk_prior_log_prob(self.h, _ptr(z), z.shape[0], _ptr(lp), _stream_ptr()))
+        for a, b in self._chunks(z.shape[0]):
+            _lib.check(self.lib.glowk_prior_log_prob(self.h, _ptr(z[a:b]), b - a, _ptr(lp[a:b]), _stream_ptr()))
         return lp
 
     # ---- sub-bijectors ----------------------------------------------------------------------------

@@ -114,6 +114,10 @@ int glowk_get_precision(const glowk_handle* h);
  * compute call allocates (required before hipGraph capture) */
 size_t glowk_workspace_bytes(const glowk_handle* h, int N);
 int glowk_reserve(glowk_handle* h, int N);
+/* the largest batch ONE call accepts (2^28 elements / (H*W*C): indices within a call are 32-bit); every batch entry point
+ * rejects a larger N with GLOWK_ERR.  Tiles are independent, so a caller with more tiles loops over chunks
+ * (audiosourcesep_amd/engine.py does). */
+int glowk_max_tiles(const glowk_handle* h);
 
 /* --- the hot path ------------------------------------------------------------------------------- */
 /* Chain([glow, prepro]).forward(x) and its forward_log_det_jacobian (flow_builder.py:127;

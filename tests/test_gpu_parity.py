@@ -298,3 +298,34 @@ def test_empty_and_single_tile_batches(gpu):
         l1, g1 = eng.log_prob_grad(x[2:3])
         l5, g5 = eng.log_prob_grad(x)
         np.testing.assert_allclose(g1.cpu().numpy(), g5[2:3].cpu().numpy(), atol=2e-4 * float(g5.abs().max()), rtol=2e-3)
+
+
+def test_batches_beyond_max_tiles_are_chunked(gpu):
+    """One C-ABI call takes at most glowk_max_tiles() tiles (32-bit indices within a call) and says so; the Python mirror loops
+    over chunks, and since tiles are independent the chunked result is the unchunked one (to rounding)."""
+    import ctypes
+    from audiosourcesep_amd import _lib
+    cfg = GlowConfig(H=16, W=16, C=1, L=2, K=2, F=128)
+    eng, _ = calibrated_engine(cfg, device=0, init_tiles=8)
+    assert eng.max_tiles == (1 << 28) // (16 * 16)
+    x = torch.from_numpy(synthetic_mel_tiles(7, cfg, seed=5)).cuda()
+    lp = torch.empty(7, device="cuda")
+    rc = eng.lib.glowk_log_prob(eng.h, ctypes.c_void_p(x.data_ptr()), eng.max_tiles + 1, ctypes.c_void_p(lp.data_ptr()), None, None)
+    assert rc != 0 and b"glowk_max_tiles" in eng.lib.glowk_last_error()
+    with pytest.raises(_lib.GlowkError):
+        _lib.check(eng.lib.glowk_reserve(eng.h, eng.max_tiles + 1))
+    whole = (eng.forward(x), eng.log_prob(x, return_latent=True), eng.log_prob_grad(x))
+    eps = torch.randn(7, *cfg.latent_shape(), device="cuda")
+    whole_s, whole_p = eng.sample_from_eps(eps), eng.prior_log_prob(eps)
+    whole_i = eng.inverse(whole[0][0])
+    eng._max_tiles_cap = 3   # 7 tiles -> chunks of 3, 3, 1
+    parts = (eng.forward(x), eng.log_prob(x, return_latent=True), eng.log_prob_grad(x))
+    def close(a, b):   # (the launch forms depend on the batch size, so the partial sums may be ordered differently)
+        a, b = a.double().cpu().numpy(), b.double().cpu().numpy()
+        np.testing.assert_allclose(b, a, rtol=2e-6, atol=2e-4 * float(np.abs(a).max()))
+    for w, p in zip(whole, parts):
+        for a, b in zip(w, p):
+            close(a, b)
+    close(whole_s, eng.sample_from_eps(eps))
+    assert torch.equal(whole_p, eng.prior_log_prob(eps))
+    close(whole_i, eng.inverse(whole[0][0]))
