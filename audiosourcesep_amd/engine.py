@@ -109,9 +109,17 @@ class GlowEngine:
         m = int(self.lib.glowk_max_tiles(self.h))
         return min(m, self._max_tiles_cap) if self._max_tiles_cap else m
 
-    def _chunks(self, n):
-        m = self.max_tiles
+    def _chunks(self, n, m=None):
+        m = m or self.max_tiles
         return [(i, min(i + m, n)) for i in range(0, n, m)]
+
+    @property
+    def grad_max_tiles(self):
+        """Chunk of log_prob_grad: the pass keeps every step's ReLU masks and activations until the backward sweep
+        (~5.5 MB per 64x64 tile at K=32, F=512), so its chunks are 2^24 elements (4096 such tiles, ~22 GB) -- far past
+        the batch size at which the kernels saturate."""
+        c = self.cfg
+        return max(1, min(self.max_tiles, (1 << 24) // (c.H * c.W * c.C)))
 
     def workspace_bytes(self, n):
         return int(self.lib.glowk_workspace_bytes(self.h, int(n)))
@@ -184,7 +192,7 @@ class GlowEngine:
         lp, dx = self._new(n), torch.empty_like(x)
         if n == 0:
             return lp, dx
-        for a, b in self._chunks(n):
+        for a, b in self._chunks(n, self.grad_max_tiles):
             _lib.check(self.lib.glowk_log_prob_grad(self.h, _ptr(x[a:b]), b - a, _ptr(lp[a:b]), _ptr(dx[a:b]), _stream_ptr()))
         return lp, dx
 
