@@ -25,7 +25,7 @@ def sharded_log_prob(log_prob_fn, x_local, group=None):
     The sum is accumulated in fp64 so that its value does not depend on how tiles were sharded to ~1e-12."""
     lp = log_prob_fn(x_local) if x_local.shape[0] else torch.zeros(0, dtype=torch.float32, device=x_local.device)
     total = lp.sum(dtype=torch.float64).reshape(1)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():   # (a one-rank group still makes the call: same code path at every N)
         if total.is_cuda and dist.get_backend(group) == "gloo":   # rehearsal of the multi-process path without RCCL
             t = total.cpu()
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
@@ -33,6 +33,16 @@ def sharded_log_prob(log_prob_fn, x_local, group=None):
         else:
             dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
     return lp, total[0]
+
+
+def distributed_test_step(log_prob_fn, x_local, global_batch_size, group=None):
+    """The evaluation step of the trainer (train_glow.py:33-35, 48-50, 64-68): every replica computes
+    ``sum(-log_prob(X_local)) / global_batch_size`` (tf.nn.compute_average_loss) and the per-replica losses are summed --
+    i.e. the mean negative log-likelihood of the global batch, identical on every rank (fp64)."""
+    if global_batch_size <= 0:
+        raise ValueError("global_batch_size must be positive")
+    _, total = sharded_log_prob(log_prob_fn, x_local, group=group)
+    return -total / float(global_batch_size)
 
 
 def gather_log_prob(lp_local, n_total, group=None):

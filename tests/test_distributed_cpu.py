@@ -10,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from audiosourcesep_amd.config import GlowConfig
-from audiosourcesep_amd.distributed import shard_bounds, sharded_log_prob, gather_log_prob
+from audiosourcesep_amd.distributed import shard_bounds, sharded_log_prob, gather_log_prob, distributed_test_step
 from audiosourcesep_amd.synthetic import synthetic_params, synthetic_mel_tiles
 
 CFG = GlowConfig(H=8, W=8, C=1, L=2, K=2, F=128)
@@ -40,7 +40,8 @@ def _worker(rank, world, port, out_dir):
     a, b = shard_bounds(N_TILES, world, rank)
     lp, total = sharded_log_prob(_oracle_log_prob, x[a:b])
     full = gather_log_prob(lp, N_TILES)
-    np.save(os.path.join(out_dir, "r%d.npy" % rank), np.concatenate([[total.item()], full.numpy().astype(np.float64)]))
+    loss = distributed_test_step(_oracle_log_prob, x[a:b], N_TILES)
+    np.save(os.path.join(out_dir, "r%d.npy" % rank), np.concatenate([[total.item(), loss.item()], full.numpy().astype(np.float64)]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -65,4 +66,13 @@ def test_sharded_sum_equals_single_process(world, tmp_path):
     for r in range(world):
         got = np.load(tmp_path / ("r%d.npy" % r))
         np.testing.assert_allclose(got[0], ref.sum(), rtol=1e-6)
-        np.testing.assert_array_equal(got[1:], ref)                   # gathered back in batch order
+        np.testing.assert_allclose(got[1], -ref.mean(), rtol=1e-6)    # train_glow.py:33-35: the global batch's mean NLL
+        np.testing.assert_array_equal(got[2:], ref)                   # gathered back in batch order
+
+
+def test_test_step_without_process_group():
+    x = torch.from_numpy(synthetic_mel_tiles(3, CFG))
+    ref = _oracle_log_prob(x).numpy().astype(np.float64)
+    np.testing.assert_allclose(distributed_test_step(_oracle_log_prob, x, 3).item(), -ref.mean(), rtol=1e-6)
+    with pytest.raises(ValueError):
+        distributed_test_step(_oracle_log_prob, x, 0)
