@@ -84,13 +84,19 @@ struct Ring1 {
   // barrier per step (the buffer is requested and consumed between the same two ring barriers)
   static constexpr bool K1_IN_RING = (size_t)2 * (MAIN4 + K1PIECES_FULL * 64) * 16 + (size_t)6 * NF * 32 * 4 <= 160 * 1024;
   static constexpr int K1PIECES = K1_IN_RING ? K1PIECES_FULL : 0;
-  // (K = 288 at c = 32 fits neither: those operands are loaded from global memory per step, each load serialised behind
-  // the DMA in flight -- the 4-level graphs' last level only)
   static constexpr bool K1_IN_BUF = !K1_IN_RING && (size_t)2 * MAIN4 * 16 + (size_t)6 * NF * 32 * 4 + (size_t)K1PIECES_FULL * 1024 <= 160 * 1024;
-  static constexpr int K1BUF4 = K1_IN_BUF ? K1PIECES_FULL * 64 : 1;   // float4 of the separate buffer
+  // K = 288 at c = 32 (the 4-level graphs' last level, backward) fits neither: its operands pass through a buffer of HALF a
+  // block -- first half fetched during the previous block's main contraction, second half between the two halves of the
+  // small conv (an exposed 18-KiB DMA per step; loading them from global memory instead cost 4x: every load queues behind
+  // the chunk DMA and 144 live im2col registers leave no room to batch them)
+  static constexpr int K1HALF_KS = KS1 / 2;
+  static constexpr int K1HALF_PIECES = (K1HALF_KS * 256 + 1023) / 1024;
+  static constexpr bool K1_IN_HALF = !K1_IN_RING && !K1_IN_BUF && KS1 % 2 == 0 && (K1HALF_KS * 256) % 1024 == 0 &&
+                                     (size_t)2 * MAIN4 * 16 + (size_t)6 * NF * 32 * 4 + (size_t)K1HALF_PIECES * 1024 <= 160 * 1024;
+  static constexpr int K1BUF4 = K1_IN_BUF ? K1PIECES_FULL * 64 : K1_IN_HALF ? K1HALF_PIECES * 64 : 1;   // float4 of the separate buffer
   static constexpr int SLOT4 = MAIN4 + K1PIECES * 64;
   static constexpr int PIECES = NF * 4 + K1PIECES;
-  static constexpr size_t LDS_BYTES = (size_t)2 * SLOT4 * 16 + (size_t)6 * NF * 32 * 4 + (K1_IN_BUF ? (size_t)K1BUF4 * 16 : 0);
+  static constexpr size_t LDS_BYTES = (size_t)2 * SLOT4 * 16 + (size_t)6 * NF * 32 * 4 + ((K1_IN_BUF || K1_IN_HALF) ? (size_t)K1BUF4 * 16 : 0);
   static constexpr bool FITS = LDS_BYTES <= 160 * 1024;
 };
 
@@ -134,7 +140,22 @@ __device__ __forceinline__ void net_step(const NetArgs& a, int fi, bool first, c
   f32x16 h1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) h1[r] = 0.0f;
-  {
+  if constexpr (G::K1_IN_HALF) {
+    constexpr int KH = G::K1HALF_KS;
+    if (!first) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();   // chunk fi and the first half of this block's small-conv operands landed in every wave's view
+    }
+    const float* k1 = reinterpret_cast<const float*>(k1buf) + lane;
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks) h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[ks * 64], xcol[ks], h1, 0, 0, 0);
+    __syncthreads();     // every wave has read the first half
+    stage_range<0, G::K1HALF_PIECES>(reinterpret_cast<const float4*>(a.K1p + ((size_t)fi * KS1 + KH) * 64), k1buf, wave, voff);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();     // second half landed (nothing else is in flight here)
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks) h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[ks * 64], xcol[KH + ks], h1, 0, 0, 0);
+  } else {
     if (G::K1_IN_BUF && !first) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();   // chunk fi and this block's small-conv operands landed in every wave's view
@@ -174,6 +195,9 @@ __device__ __forceinline__ void net_step(const NetArgs& a, int fi, bool first, c
   stage_range<0, G::PIECES>(nsrc, ring_slot<P ^ 1>(s0, s1), wave, voff);
   if (G::K1_IN_BUF && fi + 1 < NF)
     stage_range<0, G::K1PIECES_FULL>(reinterpret_cast<const float4*>(a.K1p + (size_t)(fi + 1) * KS1 * 64), k1buf, wave, voff);
+  if constexpr (G::K1_IN_HALF) {
+    if (fi + 1 < NF) stage_range<0, G::K1HALF_PIECES>(reinterpret_cast<const float4*>(a.K1p + (size_t)(fi + 1) * KS1 * 64), k1buf, wave, voff);
+  }
   const float4* buf = ring_slot<P>(s0, s1);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -256,6 +280,7 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
   stage_range<0, G::PIECES>(ring, slot0, wave, voff);                                           // chunk 0 -> slot 0
   if (G::K1_IN_RING) stage_range<NF * 4, (G::K1PIECES > 0 ? G::K1PIECES : 1)>(ring + (size_t)(NF - 1) * SLOT4, slot1, wave, voff);   // small-conv operands of block 0
   else if (G::K1_IN_BUF) stage_range<0, G::K1PIECES_FULL>(reinterpret_cast<const float4*>(a.K1p), k1buf, wave, voff);
+  else if (G::K1_IN_HALF) stage_range<0, G::K1HALF_PIECES>(reinterpret_cast<const float4*>(a.K1p), k1buf, wave, voff);
 
   f32x16 acc2[NF];
 #pragma unroll

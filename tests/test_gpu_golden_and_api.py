@@ -237,3 +237,30 @@ def test_gradient_path_is_bitwise_repeatable():
         for _ in range(400 if prec == _lib.PREC_F32 else 100):
             lp, g = eng.log_prob_grad(x)
             assert torch.equal(lp, lp0) and torch.equal(g, g0)
+
+
+def test_input_gradient_four_levels_full_width():
+    """L = 4 at n_filters = 512: the last level's backward pass is the K = 288 small convolution whose operands pass through
+    a half-block LDS buffer (two DMA phases per step).  Gradient against the fp64 autograd of the oracle, and 100 repeats of
+    one call bitwise equal (the extra barriers of that path are what a race would get past)."""
+    from audiosourcesep_amd import _lib
+    from audiosourcesep_amd.synthetic import calibrated_engine
+    from oracle import glowref_torch as RT
+    cfg = GlowConfig(H=32, W=32, C=1, L=4, K=2, F=512)
+    eng, params = calibrated_engine(cfg, device=0, init_tiles=8)
+    x = synthetic_mel_tiles(3, cfg, seed=21)
+    lp_ref, g_ref = RT.log_prob_and_grad(x.astype(np.float64), params, cfg.as_dict())
+    scale = np.abs(g_ref).max()
+    for prec in (_lib.PREC_F32, _lib.PREC_F16X3):
+        eng.set_precision(prec)
+        lp, g = eng.log_prob_grad(dev(x))
+        np.testing.assert_allclose(lp.cpu().numpy(), lp_ref, rtol=1e-6)
+        assert float(np.abs(g.cpu().numpy() - g_ref).max() / scale) < 1e-3
+    xl = dev(synthetic_mel_tiles(150, cfg, seed=22))   # 600 level-3 pixels: five workgroups, the last one ragged
+    for prec in (_lib.PREC_F32, _lib.PREC_F16X3):
+        eng.set_precision(prec)
+        lp0, g0 = eng.log_prob_grad(xl)
+        assert torch.isfinite(g0).all()
+        for _ in range(100):
+            lp, g = eng.log_prob_grad(xl)
+            assert torch.equal(lp, lp0) and torch.equal(g, g0)
