@@ -45,7 +45,7 @@ STEP_TENSOR_IDS = {
     "nn/conv3/kernel": 19, "nn/conv3/bias": 20,
 }
 PRIOR_TENSOR_IDS = {"prior/loc": 100, "prior/log_scale": 101}
-PREC_F32, PREC_F16X3 = 0, 1
+PREC_F32, PREC_F16X3, PREC_F16X2 = 0, 1, 2
 
 _vp, _i, _fp = ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float)
 

@@ -653,6 +653,10 @@ namespace {
 using glowk_detail::num_cus;
 using glowk_detail::launch_net_t;
 
+// launch_net mode of the plain forward network for the handle's precision (glowk_launch.h: 0 exact fp32, 3 three-term split,
+// 6 two-term split)
+int fwd_mode(const glowk_handle* h) { return h->precision == GLOWK_PREC_F16X3 ? 3 : h->precision == GLOWK_PREC_F16X2 ? 6 : NET_FWD; }
+
 int launch_net_raw(int c, int F, const NetArgs& a, int mode, hipStream_t s, bool dry = false) {
 #define NETCASE(CI_, NF_) if (c == 2 * CI_ && F == 32 * NF_) return launch_net_t<CI_, NF_>(a, mode, s, dry);
   NETCASE(2, 16) NETCASE(4, 16) NETCASE(8, 16) NETCASE(16, 16)
@@ -830,8 +834,7 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
         na.mask2 = na.mask1 + blocks * NF * 64;
       }
       int np = 1;   // the f16x3 kernels leave P as np partial sums (one per pass over the hidden width)
-      const bool f16_fwd = h->precision == GLOWK_PREC_F16X3;
-      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, f16_fwd ? (save ? 4 : 3) : (save ? NET_FWD_SAVE : NET_FWD), &np)) return rc;
+      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, save ? (h->precision == GLOWK_PREC_F32 ? NET_FWD_SAVE : 4) : fwd_mode(h), &np)) return rc;
       if (save) h->save_parts[sidx] = np;
       CoupleArgs ca;
       ca.vin = cur; ca.P = na.P; ca.np = np; ca.pstride = na.pstride; ca.b3 = sd.b3; ca.logdet = h->bufLd; ca.log_s_out = nullptr; ca.t_out = nullptr;
@@ -908,7 +911,7 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       na.K1p = sd.K3bp; na.R0p = sd.RBp; na.P = Pg;
       na.mask1 = h->saveM + h->offM[sidx];
       na.mask2 = na.mask1 + blocks * NF * 64;
-      const bool h3b = h->precision == GLOWK_PREC_F16X3 && sd.RHBp;
+      const bool h3b = h->precision != GLOWK_PREC_F32 && sd.RHBp;
       if (h3b) { na.RHp = sd.RHBp; na.RSp = sd.RSBp; na.eph = nullptr; na.sc1 = sd.scb1; na.sc2 = sd.scb2; na.sc3 = sd.scb3; }
       if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, h3b ? 5 : NET_BWD, &npg)) return rc;
     }
@@ -952,7 +955,7 @@ int run_inverse(glowk_handle* h, const float* z, int N, float* x, hipStream_t s)
     for (int k = 0; k < K; ++k) {   // Chain.inverse: step 0 first
       const StepDev& sd = lv.dev[k];
       int np = 1;
-      if (int rc = launch_net(h, lvl, lv.c, cfg.F, net_args(h, lv, sd, cur, lv.c, lv.c / 2, N), s, h->precision == GLOWK_PREC_F16X3 ? 3 : NET_FWD, &np)) return rc;
+      if (int rc = launch_net(h, lvl, lv.c, cfg.F, net_args(h, lv, sd, cur, lv.c, lv.c / 2, N), s, fwd_mode(h), &np)) return rc;
       CoupleArgs ca;
       ca.vin = cur; ca.P = h->bufP; ca.np = np; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
       ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 1;
@@ -1265,7 +1268,7 @@ int glowk_actnorm_data_init(glowk_handle* h, const float* x_dev, int N, int runt
 
 int glowk_set_precision(glowk_handle* h, int precision) {
   if (!h) return fail("null handle");
-  if (precision != GLOWK_PREC_F32 && precision != GLOWK_PREC_F16X3) return fail("unknown precision mode");
+  if (precision != GLOWK_PREC_F32 && precision != GLOWK_PREC_F16X3 && precision != GLOWK_PREC_F16X2) return fail("unknown precision mode");
   h->precision = precision;
   return 0;
 }
@@ -1429,7 +1432,7 @@ int glowk_step_forward(glowk_handle* h, int level, int step, const float* u_dev,
   CDISPATCH(lv.c, hipLaunchKernelGGL((k_affine<CC>), dim3((Q + 255) / 256), dim3(256), 0, s, u_dev, Q, sd.Afwd, sd.bfwd, h->bufA));
   LAUNCHCHK("k_affine");
   int np = 1;
-  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, h->bufA, lv.c, lv.c / 2, N), s, h->precision == GLOWK_PREC_F16X3 ? 3 : NET_FWD, &np)) return rc;
+  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, h->bufA, lv.c, lv.c / 2, N), s, fwd_mode(h), &np)) return rc;
   if (logdet_dev) {
     // logdet accumulator starts at the step's constant h*w*(sum log_scale + sum log_S)
     PreArgs p = {0, 1, 0, 0};
@@ -1460,7 +1463,7 @@ int glowk_step_inverse(glowk_handle* h, int level, int step, const float* y_dev,
   const Level& lv = h->levels[level];
   const StepDev& sd = lv.dev[step];
   int np = 1;
-  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, y_dev, lv.c, lv.c / 2, N), s, h->precision == GLOWK_PREC_F16X3 ? 3 : NET_FWD, &np)) return rc;
+  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, y_dev, lv.c, lv.c / 2, N), s, fwd_mode(h), &np)) return rc;
   CoupleArgs ca;
   ca.vin = y_dev; ca.P = h->bufP; ca.np = np; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.A = sd.Ainv; ca.b = sd.binv;
   ca.out = u_dev; ca.out_stride = lv.c; ca.out_off = 0;
@@ -1477,7 +1480,7 @@ int glowk_coupling_net(glowk_handle* h, int level, int step, const float* xb_dev
   const Level& lv = h->levels[level];
   const StepDev& sd = lv.dev[step];
   int np = 1;
-  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, xb_dev, lv.c / 2, 0, N), s, h->precision == GLOWK_PREC_F16X3 ? 3 : NET_FWD, &np)) return rc;
+  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, xb_dev, lv.c / 2, 0, N), s, fwd_mode(h), &np)) return rc;
   CoupleArgs ca;
   ca.vin = nullptr; ca.P = h->bufP; ca.np = np; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
   ca.out = nullptr; ca.out_stride = 0; ca.out_off = 0;

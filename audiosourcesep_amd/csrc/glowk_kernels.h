@@ -116,7 +116,9 @@ __device__ __forceinline__ void stage_range(const float4* __restrict__ src, floa
 //   NET_FWD / NET_FWD_SAVE   conv1 (K = 9ci chain) -> bias+ReLU+BN1 -> conv2 (16 accumulator tiles) -> bias+ReLU+BN2 -> conv3 per-tap
 //   NET_BWD                  conv3^T (K = 9c chain) -> x g2 x mask2  -> conv2^T (16 accumulator tiles) -> x g1 x mask1 -> conv1^T per-tap
 // NET_FWD_SAVE also stores the two ReLU masks (16 bits per lane per hidden block) for NET_BWD.
-enum { NET_FWD = 0, NET_FWD_SAVE = 1, NET_BWD = 2 };
+enum { NET_FWD = 0, NET_FWD_SAVE = 1, NET_BWD = 2,
+       NET_FWD2 = 3 };   // k_net_h3s only: plain forward with TWO split terms per product (activations rounded to fp16 once,
+                         // weights still hi + lo): ~1e-5-class log_prob instead of fp32-class, 2/3 of the MFMAs
 
 // select word j of a small register array with a wave-uniform index (v_cndmask chain; no dynamic register indexing)
 template <int N>
@@ -870,9 +872,10 @@ struct RingS {
   static constexpr int tile_mt(int t) { return t < NFH * G0N ? t % G0N : G0N + (t - NFH * G0N) % G1D; }
 };
 
+template <bool TWO = false>
 __device__ __forceinline__ f32x4 mfma3s(const h8& ahi, const h8& alo, const h8& bhi, const h8& blo, f32x4 acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, acc, 0, 0, 0);
+  if (!TWO) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, acc, 0, 0, 0);
   return acc;
 }
@@ -892,7 +895,10 @@ __device__ __forceinline__ unsigned h3s_act(const f32x4& r0, const f32x4& r1, fl
       if (MODE == NET_FWD_SAVE) bits |= (acc > 0.0f ? 1u : 0u) << j;
     }
   }
-  split8(v, bh, bl);
+  if (MODE == NET_FWD2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { bh[j] = (_Float16)v[j]; bl[j] = (_Float16)0.0f; }
+  } else split8(v, bh, bl);
   return bits;
 }
 
@@ -920,7 +926,7 @@ __device__ __forceinline__ void h3s_X(const NetArgs& a, const H3Ctx& c, int fi, 
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
-          h1[rb][hf] = mfma3s(kf[(s * 2 + rb) * 2 + 0], kf[(s * 2 + rb) * 2 + 1], xh[s][hf], xl[s][hf], h1[rb][hf]);
+          h1[rb][hf] = mfma3s<MODE == NET_FWD2>(kf[(s * 2 + rb) * 2 + 0], kf[(s * 2 + rb) * 2 + 1], xh[s][hf], xl[s][hf], h1[rb][hf]);
   } else {
 #pragma unroll
     for (int s = 0; s < G::KS; ++s)
@@ -928,7 +934,7 @@ __device__ __forceinline__ void h3s_X(const NetArgs& a, const H3Ctx& c, int fi, 
       for (int rb = 0; rb < 2; ++rb) {
         const h8 ah = k1[((s * 2 + rb) * 2 + 0) * 64], al = k1[((s * 2 + rb) * 2 + 1) * 64];
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) h1[rb][hf] = mfma3s(ah, al, xh[s][hf], xl[s][hf], h1[rb][hf]);
+        for (int hf = 0; hf < 2; ++hf) h1[rb][hf] = mfma3s<MODE == NET_FWD2>(ah, al, xh[s][hf], xl[s][hf], h1[rb][hf]);
       }
   }
   unsigned bits = 0;
@@ -978,10 +984,12 @@ __device__ __forceinline__ void h3s_Y(const float4* slot, const h8 (&bh)[2], con
     acc2[o0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1], bh[1], acc2[o0][1], 0, 0, 0);
     acc2[o1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[3], bh[0], acc2[o1][0], 0, 0, 0);
     acc2[o1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[3], bh[1], acc2[o1][1], 0, 0, 0);
-    acc2[o0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bl[0], acc2[o0][0], 0, 0, 0);
-    acc2[o0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bl[1], acc2[o0][1], 0, 0, 0);
-    acc2[o1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2], bl[0], acc2[o1][0], 0, 0, 0);
-    acc2[o1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2], bl[1], acc2[o1][1], 0, 0, 0);
+    if (MODE != NET_FWD2) {
+      acc2[o0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bl[0], acc2[o0][0], 0, 0, 0);
+      acc2[o0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bl[1], acc2[o0][1], 0, 0, 0);
+      acc2[o1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2], bl[0], acc2[o1][0], 0, 0, 0);
+      acc2[o1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2], bl[1], acc2[o1][1], 0, 0, 0);
+    }
     acc2[o0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bh[0], acc2[o0][0], 0, 0, 0);
     acc2[o0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bh[1], acc2[o0][1], 0, 0, 0);
     acc2[o1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2], bh[0], acc2[o1][0], 0, 0, 0);
@@ -1032,8 +1040,8 @@ __device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const fl
         for (int r = 0; r < 4; ++r) { acc3[ml][0][r] = 0.0f; acc3[ml][1][r] = 0.0f; }
       }
       const h8 ah = buf[(tp * 2 + 0) * 64], al = buf[(tp * 2 + 1) * 64];
-      acc3[ml][0] = mfma3s(ah, al, bh[0], bl[0], acc3[ml][0]);
-      acc3[ml][1] = mfma3s(ah, al, bh[1], bl[1], acc3[ml][1]);
+      acc3[ml][0] = mfma3s<MODE == NET_FWD2>(ah, al, bh[0], bl[0], acc3[ml][0]);
+      acc3[ml][1] = mfma3s<MODE == NET_FWD2>(ah, al, bh[1], bl[1], acc3[ml][1]);
       if (fo == NFH - 1) {
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)

@@ -91,6 +91,12 @@ int launch_net_t(const NetArgs& a, int mode, hipStream_t s, bool dry) {
       if (!np && a.RHp) np = launch_h3<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
       if (!np && !dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a);
       break;
+    case 6:   // two-term forward (GLOWK_PREC_F16X2): 16x16x32 kernel only; without an instance, the three-term forms of case 3
+      if (a.RSp && h3_shape16()) np = launch_h3s<CI, 18 * CI, NF, NET_FWD2>(a, s, dry);
+      if (!np && a.RSp && h3_shape16()) np = launch_h3s<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
+      if (!np && a.RHp) np = launch_h3<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
+      if (!np && !dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a);
+      break;
     case 4:
       if constexpr (fam16_ok<CI, NF>()) {
         if (a.fam16 && h3_shape16() && big_grid(a)) np = launch_h3s<CI, 18 * CI, NF, NET_FWD_SAVE>(a, s, dry);

@@ -204,7 +204,7 @@ class GlowFlow:
 
     def set_precision(self, precision):
         """``"f32"`` (exact fp32 MFMA) or ``"f16x3"`` (error-compensated fp16 split) for every later call."""
-        modes = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3}
+        modes = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3, "f16x2": _lib.PREC_F16X2}
         if precision not in modes:
             raise ValueError("precision must be 'f32' or 'f16x3'")
         self.engine.set_precision(modes[precision])

@@ -150,7 +150,7 @@ def main():
     ap.add_argument("--config", default="B", choices=["A", "B", "YAML"])
     ap.add_argument("--workload", default="log_prob", choices=["log_prob", "log_prob_grad", "basis"],
                     help="log_prob = BASELINE.json's headline metric; the other two are secondary lines (SURVEY section 8f-1)")
-    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "f16x2"],
                     help="f16x3: error-compensated fp16 split on the fp16 MFMA (fp32-class accuracy, demonstrated in the line); "
                          "f32: exact fp32-input MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -188,7 +188,8 @@ def main():
     # synthetic weights + ActNorm data-dependent init on a minibatch of the benchmark's own batch size, so that
     # every k_net launch of the process has the same grid (rocprof's per-kernel average == the timed one)
     eng, params = calibrated_engine(cfg, device=local_rank, init_tiles=args.batch)
-    eng.set_precision(_lib.PREC_F32 if args.precision == "f32" else _lib.PREC_F16X3)
+    PREC = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3, "f16x2": _lib.PREC_F16X2}
+    eng.set_precision(PREC[args.precision])
     n = args.batch
     eng.reserve(n)
     if args.workload != "log_prob":
@@ -232,14 +233,21 @@ def main():
     assert torch.isfinite(total).all(), "non-finite log-likelihood"
     lp_main = lp.clone()
     # the other arithmetic on the same batch: exact fp32 beside the split path (or vice versa), same run
-    other = "f32" if args.precision == "f16x3" else "f16x3"
-    eng.set_precision(_lib.PREC_F32 if other == "f32" else _lib.PREC_F16X3)
+    other = "f32" if args.precision != "f32" else "f16x3"
+    eng.set_precision(PREC[other])
     step()
     elapsed_o, prof_o = timed(max(2, args.steps // 2))
     steps_o = max(2, args.steps // 2)
     lp_other = lp.clone()
-    eng.set_precision(_lib.PREC_F32 if args.precision == "f32" else _lib.PREC_F16X3)
     rel_diff = float(((lp_main - lp_other).abs() / lp_other.abs()).max().item())
+    # the throughput mode (two split terms per product: inside the 1e-4 bar, not fp32-class), same batch, same run
+    two = None
+    if args.precision == "f16x3":
+        eng.set_precision(PREC["f16x2"])
+        step()
+        elapsed_2, prof_2 = timed(steps_o)
+        two = (elapsed_2, prof_2, float(((lp - lp_other).abs() / lp_other.abs()).max().item()))
+    eng.set_precision(PREC[args.precision])
     # accuracy of the headline arithmetic against the fp64 CPU oracle on two tiles of the same batch (rank 0)
     acc_vs_oracle = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # (N > 1: the other ranks would idle at the barrier meanwhile)
@@ -261,6 +269,9 @@ def main():
             if precision == "f32":
                 kernel, peak = "k_net_f32<CI=%d,NF=%d> (level 0)" % (c0 // 2, cfg.F // 32), PEAK_F32_MFMA_TFLOPS
                 note = "fp32-input MFMA peak"
+            elif precision == "f16x2":
+                kernel, peak = "k_net_h3s<CI=%d,NF=%d,two-term> (level 0)" % (c0 // 2, cfg.F // 32), PEAK_F16_MFMA_TFLOPS / 2.0
+                note = "fp16 dense MFMA peak / 2 (two fp16 MFMAs per product)"
             else:
                 kernel, peak = "k_net_h3s<CI=%d,NF=%d> (level 0)" % (c0 // 2, cfg.F // 32), PEAK_F16_MFMA_TFLOPS / 3.0
                 note = "fp16 dense MFMA peak / 3 (three fp16 MFMAs per fp32-equivalent product)"
@@ -275,7 +286,7 @@ def main():
                     traffic = None
             # what a bare MFMA loop with this kernel's operand pattern sustains on this chip under its power management
             # (scripts/mfma_shape.hip, random data): 1 697 TFLOP/s for 16x16x32 f16 (/3), 150.8 TFLOP/s for 32x32x2 f32
-            sustained = SUSTAINED_F32_MFMA_TFLOPS if precision == "f32" else SUSTAINED_F16_MFMA_TFLOPS / 3.0
+            sustained = SUSTAINED_F32_MFMA_TFLOPS if precision == "f32" else SUSTAINED_F16_MFMA_TFLOPS / (2.0 if precision == "f16x2" else 3.0)
             return {"kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "peak_note": note, "unit": "TFLOP/s",
                     "frac": (achieved / peak) if achieved else None, "traffic": traffic, "avg_launch_ms": avg_ms,
                     "launches": launches0, "flop_per_launch": flop_launch, "sustained_mfma_rate_measured": sustained,
@@ -285,9 +296,10 @@ def main():
         value = passes / elapsed
         value_o = n * world * steps_o / elapsed_o
         net_ms_total = sum(m for m, _ in prof)
-        dtype_name = {"f32": "f32", "f16x3": "f16x3"}
+        dtype_name = {"f32": "f32", "f16x3": "f16x3", "f16x2": "f16x2"}
         dtype_note = {"f32": "fp32 operands on v_mfma_f32_32x32x2_f32, fp32 accumulate",
-                      "f16x3": "fp32 operands split into fp16 hi + lo, 3 fp16 MFMAs per product, fp32 accumulate"}
+                      "f16x3": "fp32 operands split into fp16 hi + lo, 3 fp16 MFMAs per product, fp32 accumulate",
+                      "f16x2": "weights split into fp16 hi + lo, activations rounded to fp16, 2 fp16 MFMAs per product, fp32 accumulate"}
         out = {
             "metric": baseline_metric() if args.config == "B" else "Glow fwd+logdet passes/sec (config %s)" % args.config,
             "value": value, "unit": "passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -309,6 +321,11 @@ def main():
                 "value": value_o, "unit": "passes/s", "steps": steps_o, "ms_per_step": elapsed_o / steps_o * 1e3,
                 "dtype": dtype_name[other], "roofline": roofline_obj(other, prof_o)},
         }
+        if two is not None:
+            out["two_term_split_fp16"] = {
+                "value": n * world * steps_o / two[0], "unit": "passes/s", "steps": steps_o, "ms_per_step": two[0] / steps_o * 1e3,
+                "dtype": "f16x2", "dtype_note": dtype_note["f16x2"], "max_rel_diff_log_prob_vs_f32_%d_tiles" % n: two[2],
+                "roofline": roofline_obj("f16x2", two[1])}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, params, args.cpu_budget)
         print(json.dumps(out), flush=True)

@@ -73,9 +73,13 @@ enum glowk_tensor_id {
  * (c = 32) run the exact kernels in either mode. */
 enum glowk_precision {
   GLOWK_PREC_F32 = 0,     /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (default) */
-  GLOWK_PREC_F16X3 = 1    /* error-compensated split: x = hi + lo in fp16, 3 fp16 MFMAs per product, fp32 accumulate:
+  GLOWK_PREC_F16X3 = 1,   /* error-compensated split: x = hi + lo in fp16, 3 fp16 MFMAs per product, fp32 accumulate:
                              fp32-class results (~5e-8 relative on log_prob) at ~3x the speed; assumes hidden activations
                              below 16 376 in magnitude (any normalised flow) */
+  GLOWK_PREC_F16X2 = 2    /* throughput mode of the plain forward direction (forward, log_prob, inverse, sample): weights
+                             hi + lo, activations rounded to fp16 once, 2 fp16 MFMAs per product -- log_prob ~1e-5 relative
+                             (inside the 1e-4 bar, no longer fp32-class); log_prob_grad runs the F16X3 kernels in this mode,
+                             and so do shapes without a two-term instance */
 };
 
 int glowk_version(void);

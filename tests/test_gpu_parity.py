@@ -329,3 +329,34 @@ def test_batches_beyond_max_tiles_are_chunked(gpu):
     close(whole_s, eng.sample_from_eps(eps))
     assert torch.equal(whole_p, eng.prior_log_prob(eps))
     close(whole_i, eng.inverse(whole[0][0]))
+
+
+# ---- GLOWK_PREC_F16X2: throughput mode, activations rounded to fp16 once, 2 MFMAs per product -------------------------
+@pytest.mark.parametrize("name", ["tiny_L3_rect", "L4", "config_A", "config_B"])
+def test_f16x2_throughput_mode_is_within_the_bar(gpu, name):
+    """The two-term mode trades the fp32-class accuracy of f16x3 for 2/3 of the MFMAs: log_prob must stay inside the
+    north-star bar (1e-4 relative; measured ~1.5e-5 worst over 1024 config-B tiles) against the fp64 oracle and against the
+    exact-fp32 kernels; log_prob_grad in this mode IS the f16x3 gradient path; switching back restores exact results."""
+    from audiosourcesep_amd import _lib
+    cfg = CONFIG_B if name == "config_B" else CASES[name]
+    eng, params = make_engine(gpu, cfg)
+    x = synthetic_mel_tiles(2, cfg)
+    lp_ref = R.log_prob(x.astype(np.float64), p64(params), cfg.as_dict())
+    xb = dev(synthetic_mel_tiles(48, cfg, seed=5))
+    lp32 = eng.log_prob(xb)
+    eng.set_precision(_lib.PREC_F16X3)
+    l3, g3 = eng.log_prob_grad(xb)
+    eng.set_precision(_lib.PREC_F16X2)
+    assert eng.get_precision() == _lib.PREC_F16X2
+    lp2 = eng.log_prob(dev(x)).cpu().numpy()
+    lp2b, z2 = eng.log_prob(xb, return_latent=True)
+    e_or = np.max(np.abs(lp2 - lp_ref) / np.abs(lp_ref))
+    e_32 = float(((lp2b - lp32).abs() / lp32.abs()).max())
+    print("f16x2 %s: max rel err vs fp64 oracle %.2e, vs fp32 kernels over 48 tiles %.2e" % (name, e_or, e_32))
+    assert e_or < 5e-5 and e_32 < 5e-5          # bar: 1e-4
+    xr = eng.inverse(z2)
+    assert float((xr - xb).abs().max()) < 0.5   # dB on a 120 dB range: fp16-rounded activations are not smooth in their input
+    l2, g2 = eng.log_prob_grad(xb)
+    assert torch.equal(l2, l3) and torch.equal(g2, g3)
+    eng.set_precision(_lib.PREC_F32)
+    assert torch.equal(eng.log_prob(xb), lp32)
