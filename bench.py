@@ -284,11 +284,21 @@ def main():
                     traffic = t * n if t is not None else None
                 except Exception:
                     traffic = None
+            # MFMA-pipe busy fraction of the same kernel from PMC counters (profiles/mfma_utilisation.json, scripts/pmc_mfma.py)
+            mfma_busy = None
+            upath = os.path.join(ROOT, "profiles", "mfma_utilisation.json")
+            if os.path.exists(upath) and args.config == "B":
+                try:
+                    kk = {"f32": "void k_net_f32<2, 36, 16, 0>(NetArgs)", "f16x3": "void k_net_h3s<2, 36, 16, 0, 2, false>(NetArgs)",
+                          "f16x2": "void k_net_h3s<2, 36, 16, 3, 2, false>(NetArgs)"}[precision]
+                    mfma_busy = json.load(open(upath))["kernels"][kk]["mfma_utilisation"]
+                except Exception:
+                    mfma_busy = None
             # what a bare MFMA loop with this kernel's operand pattern sustains on this chip under its power management
             # (scripts/mfma_shape.hip, random data): 1 697 TFLOP/s for 16x16x32 f16 (/3), 150.8 TFLOP/s for 32x32x2 f32
             sustained = SUSTAINED_F32_MFMA_TFLOPS if precision == "f32" else SUSTAINED_F16_MFMA_TFLOPS / (2.0 if precision == "f16x2" else 3.0)
             return {"kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "peak_note": note, "unit": "TFLOP/s",
-                    "frac": (achieved / peak) if achieved else None, "traffic": traffic, "avg_launch_ms": avg_ms,
+                    "frac": (achieved / peak) if achieved else None, "traffic": traffic, "mfma_busy_pmc": mfma_busy, "avg_launch_ms": avg_ms,
                     "launches": launches0, "flop_per_launch": flop_launch, "sustained_mfma_rate_measured": sustained,
                     "frac_of_sustained": (achieved / sustained) if achieved else None}
 
