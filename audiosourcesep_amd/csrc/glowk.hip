@@ -195,13 +195,16 @@ StepLayout step_layout(int c, int F) {
     const size_t ephn = pad4((size_t)F + 32 * NMT);
     const size_t lds = (size_t)3 * NFH * 4096 + (size_t)2 * KS * 2048 + ephn * 4;
     const bool fitsH = lds <= 160 * 1024 && NF % 4 == 0 && KS <= 5 && NMT <= 6;
+    const int KSS = (9 * CI + 1 + 31) / 32, NMS = (18 * CI + 15) / 16, NCH = (NFH * NMS + 2 * NFH - 1) / (2 * NFH);     // RingS<CI, NF>
+    const size_t ldss = (size_t)3 * NFH * 4096 + (size_t)2 * KSS * 4096 + pad4((size_t)F + 16 * NMS) * 4;
+    // the 16x16x32 kernel alone (RingS<CI, 18 CI, NF, fwd, 4>::FITS without a RingH instance): c = 32 at n_filters = 512 --
+    // 18 row blocks of P in three fused groups, K = 145 in five k-steps, four passes; forward direction only
+    const bool fitsSonly = !fitsH && NF % 4 == 0 && NF / 4 >= 2 && KSS <= 5 && NMS <= 18 && NMS % 6 == 0 && ldss <= 160 * 1024;
+    const bool fitsS = (fitsH && ldss <= 160 * 1024 && KSS <= 3 && NMS <= 12 && NCH >= 2) || fitsSonly;
     L.slotH = fitsH ? (size_t)NFH * 1024 : 0;
     L.RHp = o; o += fitsH ? (size_t)NF * KS * 512 + (size_t)2 * (NF + NMT) * NFH * 1024 : 0;
-    L.epH = o; o += fitsH ? ephn : 0;
-    {                                                                                                 // RingS<CI, NF>
-      const int KSS = (9 * CI + 1 + 31) / 32, NMS = (18 * CI + 15) / 16, NCH = (NFH * NMS + 2 * NFH - 1) / (2 * NFH);
-      const size_t ldss = (size_t)3 * NFH * 4096 + (size_t)2 * KSS * 4096 + pad4((size_t)F + 16 * NMS) * 4;
-      const bool fitsS = fitsH && ldss <= 160 * 1024 && KSS <= 3 && NMS <= 12 && NCH >= 2;
+    L.epH = o; o += (fitsH || fitsS) ? ephn : 0;
+    {
       L.slotS = fitsS ? (size_t)NFH * 1024 : 0;
       L.RSp = o; o += fitsS ? (size_t)NF * KSS * 1024 + (size_t)2 * (NF + NCH) * NFH * 1024 : 0;
       // RingS<c, 9 CI, NF, bwd>: K = 9c in k-steps of 32, 9 CI output rows in blocks of 16
@@ -348,7 +351,7 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
     _Float16* dsth = reinterpret_cast<_Float16*>(row_lane) + (size_t)hl * 64 * 8;
     dsth[j] = hl ? lo : hi;
   };
-  if (L.slotH) {
+  if (L.slotH || L.slotS) {
     const int KS = (9 * CI + 1 + 15) / 16;
     // Every per-channel constant of the epilogues is folded into the weights (host, fp64):
     //  * BatchNorm y = g*r + d with g = m * 2^e (|m| in [0.5,1)): the power of two scales the channel's own producer
@@ -400,6 +403,7 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
     const int NFH = NF / 2, G0N = NMT < 3 ? NMT : 3, G1N = NMT - G0N > 0 ? NMT - G0N : 1;
     const size_t k1blk = (size_t)KS * 2 * 256, chunkf = (size_t)NFH * 1024;
     float* img = dst + L.RHp;
+    if (L.slotH)
     for (int blk = 0; blk < NF; ++blk)
       for (int s2 = 0; s2 < KS; ++s2)
         for (int l = 0; l < 64; ++l)
@@ -410,6 +414,7 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
             put(row_lane, j, 0, w, S1);
             put(row_lane, j, 1, w, S1);
           }
+    if (L.slotH)
     for (int ps = 0; ps < 2; ++ps)
       for (int ch = 0; ch < NF + NMT; ++ch) {
         float* chunk = img + (size_t)NF * k1blk + ((size_t)ps * (NF + NMT) + ch) * chunkf;
@@ -439,7 +444,7 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
     //      accumulator-derived B fragment is channel 16 (j >> 2) + 4 kq + (j & 3) of the block ----
     if (L.slotS) {
       const int KSS = (9 * CI + 1 + 31) / 32, NMS = (18 * CI + 15) / 16, NRB = 2 * NFH, TPC = 2 * NFH, NT = NFH * NMS;
-      const int NCH = (NT + TPC - 1) / TPC, GS0 = NMS < 6 ? NMS : 6, GS1 = NMS - GS0 > 0 ? NMS - GS0 : 1;
+      const int NCH = (NT + TPC - 1) / TPC;
       const size_t k1blkS = (size_t)KSS * 4 * 256;
       float* imgS = dst + L.RSp;
       for (int blk = 0; blk < NF; ++blk)
@@ -468,8 +473,8 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
                   const int t = (ch - NF) * TPC + tp;
                   S = S3;
                   if (t < NT) {
-                    const int fo = t < NFH * GS0 ? t / GS0 : (t - NFH * GS0) / GS1;
-                    const int mt = t < NFH * GS0 ? t % GS0 : GS0 + (t - NFH * GS0) % GS1;
+                    const int gi = t / (NFH * 6), gn = NMS - 6 * gi < 6 ? NMS - 6 * gi : 6, tl = t - gi * NFH * 6;   // RingS::tile_fo / tile_mt
+                    const int fo = tl / gn, mt = 6 * gi + tl % gn;
                     const int m = mt * 16 + i, f = (ps * NFH + fo) * 32 + kloc;
                     if (m < 9 * CO) { const int tap = m / CO, co = m % CO; w = K3f[((size_t)tap * F + f) * CO + co]; }
                   }
@@ -1137,7 +1142,7 @@ int glowk_finalize_weights(glowk_handle* h) {
       d.K1p = base + SL.K1p; d.ep = base + SL.ep;
       d.R0p = reinterpret_cast<const float4*>(base + SL.R0p);
       d.RHp = SL.slotH ? reinterpret_cast<const float4*>(base + SL.RHp) : nullptr;
-      d.epH = SL.slotH ? base + SL.epH : nullptr;
+      d.epH = (SL.slotH || SL.slotS) ? base + SL.epH : nullptr;
       d.RSp = SL.slotS ? reinterpret_cast<const float4*>(base + SL.RSp) : nullptr;
       d.RSBp = SL.slotSB ? reinterpret_cast<const float4*>(base + SL.RSBp) : nullptr;
       d.RHBp = SL.slotHB ? reinterpret_cast<const float4*>(base + SL.RHBp) : nullptr;

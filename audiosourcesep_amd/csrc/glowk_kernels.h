@@ -844,14 +844,15 @@ struct RingS {
   static constexpr int TPC = MAINP / 2;                           // conv3 tiles (16 rows x 32 k, hi + lo) per chunk
   static constexpr int NT = NFH * NMT;                            // conv3 tiles per pass
   static constexpr int NCH = (NT + TPC - 1) / TPC;                // conv3 chunks per pass (the last one may be part empty)
-  static constexpr int G0N = NMT < 6 ? NMT : 6;                   // row blocks are processed in fused groups of <= 6
-  static constexpr int G1N = NMT - G0N;
-  static constexpr int G1D = G1N > 0 ? G1N : 1;
+  static constexpr int G0N = NMT < 6 ? NMT : 6;                   // row blocks are processed in fused groups of <= 6 (the last may be short)
+  static constexpr int NGRP = (NMT + 5) / 6;
+  static constexpr int GT = NFH * 6;                              // tiles of a full group
+  static constexpr int grp_n(int gi) { return NMT - 6 * gi < 6 ? NMT - 6 * gi : 6; }
   static constexpr int EPN = (NF * 32 + 16 * NMT + 3) & ~3;       // conv2 accumulator init (F) | per-row constants of P
   static constexpr int MASK2B = BWD ? 2 * NF * 512 * 2 : 0;       // backward: both ReLU masks of the workgroup's 8 column blocks
   static constexpr size_t LDS_BYTES = (size_t)3 * MAIN4 * 16 + (size_t)2 * K14 * 16 + (size_t)EPN * 4 + MASK2B;
-  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && NFH >= 2 && KS <= (NP == 2 ? 3 : 5) && G1N <= 6 &&
-                               (G1N == 0 || (NFH * G0N) % TPC == 0);
+  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && NFH >= 2 && KS <= (NP == 2 ? 3 : 5) && NGRP <= 3 &&
+                               (NGRP == 1 || GT % TPC == 0);   // (chunks do not straddle groups)
   // image (one for every NP, laid out for NP = 2): conv1 operands of all blocks, then per half of the hidden width the main
   // chunks (NF row blocks) and the conv3 tiles of NF/2 hidden blocks, 16 tiles per chunk; a pass of NP = 4 reads its half
   static constexpr int K1TOT4 = NF * K14;
@@ -865,11 +866,12 @@ struct RingS {
   }
   __device__ static const float4* out_chunk(const float4* img, int pass, int s) {   // conv3 chunk s of a pass (TPC tiles)
     const int sub = pass % SUBS, t4 = s * TPC;
-    const int t2 = t4 < NFH * G0N ? sub * NFH * G0N + t4 : IMGH * G0N + sub * NFH * G1N + (t4 - NFH * G0N);
+    const int gi = t4 / GT;                                        // image order: group by group, within a group sub-pass by sub-pass
+    const int t2 = IMGH * 6 * gi + sub * NFH * grp_n(gi) + (t4 - GT * gi);
     return img + K1TOT4 + (size_t)(pass / SUBS) * IMG_PASS4 + (size_t)NF * IMG_MAIN4 + (size_t)t2 * 128;
   }
-  static constexpr int tile_fo(int t) { return t < NFH * G0N ? t / G0N : (t - NFH * G0N) / G1D; }
-  static constexpr int tile_mt(int t) { return t < NFH * G0N ? t % G0N : G0N + (t - NFH * G0N) % G1D; }
+  static constexpr int tile_fo(int t) { return (t - GT * (t / GT)) / grp_n(t / GT); }
+  static constexpr int tile_mt(int t) { return 6 * (t / GT) + (t - GT * (t / GT)) % grp_n(t / GT); }
 };
 
 template <bool TWO = false>
@@ -1026,7 +1028,7 @@ __device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const fl
     const int t = S * TPC + tp;
     if (t < G::NT) {
       const int fo = G::tile_fo(t), mt = G::tile_mt(t);
-      const int ml = t >= NFH * G::G0N ? mt - G::G0N : mt;
+      const int ml = mt % 6;                             // this row block's accumulator within its group
       if (ml == 0) {
         unsigned mask = 0, bits = 0;
         if (MODE == NET_BWD) mask = c.mkl[((size_t)(threadIdx.x >> 6) * NF + PASS * NFH + fo) * 64 + lane];   // mask1: the ReLU after conv1

@@ -256,6 +256,19 @@ def test_input_gradient_four_levels_full_width():
         lp, g = eng.log_prob_grad(dev(x))
         np.testing.assert_allclose(lp.cpu().numpy(), lp_ref, rtol=1e-6)
         assert float(np.abs(g.cpu().numpy() - g_ref).max() / scale) < 1e-3
+    # plain forward: the last level (c = 32) on the 16x16x32 split kernel (four passes, three fused output groups), as
+    # workgroups of their own (small grids) and inside one workgroup (4 x workgroups > CUs: more than 4096 of these tiles)
+    eng.set_precision(_lib.PREC_F32)
+    xs = dev(x)
+    xb = dev(synthetic_mel_tiles(4200, cfg, seed=23))
+    lp32s, lp32b = eng.log_prob(xs), eng.log_prob(xb)
+    np.testing.assert_allclose(lp32s.cpu().numpy(), lp_ref, rtol=1e-6)
+    for prec, tol in ((_lib.PREC_F16X3, 2e-6), (_lib.PREC_F16X2, 5e-5)):
+        eng.set_precision(prec)
+        np.testing.assert_allclose(eng.log_prob(xs).cpu().numpy(), lp_ref, rtol=tol)
+        lpb, zb = eng.log_prob(xb, return_latent=True)
+        np.testing.assert_allclose(lpb.cpu().numpy(), lp32b.cpu().numpy(), rtol=tol)
+        assert float((eng.inverse(zb) - xb).abs().max()) < (5e-3 if prec == _lib.PREC_F16X3 else 0.5)
     xl = dev(synthetic_mel_tiles(150, cfg, seed=22))   # 600 level-3 pixels: five workgroups, the last one ragged
     for prec in (_lib.PREC_F32, _lib.PREC_F16X3):
         eng.set_precision(prec)
