@@ -70,7 +70,7 @@ enum glowk_tensor_id {
 
 /* Arithmetic of the coupling-network contractions (the >95 % of the FLOPs), for every compute entry point of the handle
  * (forward, inverse, log_prob, log_prob_grad, sample, the per-step calls).  Shapes without a split-kernel instance
- * (c = 32) run the exact kernels in either mode. */
+ * (the gradient path of the c = 32 level of 4-level models) run the exact kernels in every mode. */
 enum glowk_precision {
   GLOWK_PREC_F32 = 0,     /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (default) */
   GLOWK_PREC_F16X3 = 1,   /* error-compensated split: x = hi + lo in fp16, 3 fp16 MFMAs per product, fp32 accumulate:
