@@ -116,3 +116,23 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libglowk.so"))
     with pytest.raises(_lib.GlowkLibraryMissing):
         _lib.load()
+
+
+def test_batch_chunking_host_logic():
+    """GlowEngine splits a batch beyond glowk_max_tiles() into contiguous chunks (pure host logic, no GPU needed)."""
+    from audiosourcesep_amd.engine import GlowEngine
+    from audiosourcesep_amd.config import GlowConfig
+
+    class FakeLib:
+        def glowk_max_tiles(self, h):
+            return 10
+
+    e = GlowEngine.__new__(GlowEngine)
+    e.lib, e.h, e._max_tiles_cap, e.cfg = FakeLib(), None, None, GlowConfig(H=64, W=64, C=1, L=3, K=2, F=128)
+    assert e.max_tiles == 10 and e._chunks(0) == [] and e._chunks(10) == [(0, 10)]
+    assert e._chunks(25) == [(0, 10), (10, 20), (20, 25)]
+    e._max_tiles_cap = 3
+    assert e._chunks(7) == [(0, 3), (3, 6), (6, 7)]
+    assert e.grad_max_tiles == 3                      # never above max_tiles
+    e._max_tiles_cap = None
+    assert e.grad_max_tiles == 10
