@@ -1,4 +1,4 @@
-"""Determinism stress of log_prob / forward / inverse on config B (both arithmetics, three batch sizes): every repeat bitwise
+"""Determinism stress of log_prob / forward / inverse on config B (all three arithmetics, three batch sizes; ONLY=f16x2 restricts): every repeat bitwise
 equal to the first."""
 import os, sys
 sys.path.insert(0, os.getcwd())
@@ -9,7 +9,9 @@ from audiosourcesep_amd.synthetic import calibrated_engine, synthetic_mel_tiles
 eng, _ = calibrated_engine(CONFIG_B, device=0)
 for n in (1024, 64, 7):
     x = torch.from_numpy(synthetic_mel_tiles(n, CONFIG_B, seed=n)).cuda()
-    for name, prec, reps in (("fp32", _lib.PREC_F32, 60), ("f16x3", _lib.PREC_F16X3, 200)):
+    for name, prec, reps in (("fp32", _lib.PREC_F32, 60), ("f16x3", _lib.PREC_F16X3, 200), ("f16x2", _lib.PREC_F16X2, 200)):
+        if os.environ.get("ONLY") and name not in os.environ["ONLY"].split(","):
+            continue
         eng.set_precision(prec)
         lp0 = eng.log_prob(x); z0, ld0 = eng.forward(x); x0 = eng.inverse(z0)
         bad = 0
