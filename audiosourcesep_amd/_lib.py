@@ -18,6 +18,10 @@ class GlowkError(RuntimeError):
     pass
 
 
+class GlowkRangeError(GlowkError):
+    """GLOWK_ERR_RANGE: a call in a split arithmetic (f16x3 / f16x2) left the fp16 range; its outputs are not usable."""
+
+
 class GlowkConfigStruct(ctypes.Structure):
     """``glowk_config`` of include/glowk.h (field order and types must match)."""
     _fields_ = [
@@ -43,9 +47,12 @@ STEP_TENSOR_IDS = {
     "nn/conv2/kernel": 13, "nn/conv2/bias": 14,
     "nn/bn2/gamma": 15, "nn/bn2/beta": 16, "nn/bn2/mean": 17, "nn/bn2/var": 18,
     "nn/conv3/kernel": 19, "nn/conv3/bias": 20,
+    "inv1x1/P_inv": 21,
 }
 PRIOR_TENSOR_IDS = {"prior/loc": 100, "prior/log_scale": 101}
 PREC_F32, PREC_F16X3, PREC_F16X2 = 0, 1, 2
+OK, ERR, ERR_RANGE = 0, 1, 2                       # enum glowk_status
+RANGE_IGNORE, RANGE_ERROR, RANGE_FALLBACK = 0, 1, 2   # enum glowk_range_policy
 
 _vp, _i, _fp = ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float)
 
@@ -62,8 +69,11 @@ SYMBOLS = {
     "glowk_actnorm_data_init": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "glowk_set_precision": (_i, [_vp, _i]),
     "glowk_get_precision": (_i, [_vp]),
-    "glowk_workspace_bytes": (ctypes.c_size_t, [_vp, _i]),
-    "glowk_reserve": (_i, [_vp, _i]),
+    "glowk_set_range_policy": (_i, [_vp, _i]),
+    "glowk_get_range_policy": (_i, [_vp]),
+    "glowk_range_status": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_int64), _vp]),
+    "glowk_workspace_bytes": (ctypes.c_size_t, [_vp, _i, _i]),
+    "glowk_reserve": (_i, [_vp, _i, _i]),
     "glowk_max_tiles": (_i, [_vp]),
     "glowk_forward": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "glowk_inverse": (_i, [_vp, _vp, _i, _vp, _vp]),
@@ -109,4 +119,4 @@ def load():
 def check(rc):
     if rc != 0:
         msg = load().glowk_last_error()
-        raise GlowkError(msg.decode() if msg else "glowk error %d" % rc)
+        raise (GlowkRangeError if rc == ERR_RANGE else GlowkError)(msg.decode() if msg else "glowk error %d" % rc)

@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC glowk.hip -o libglowk.so   (see __graft_entry__.build)
 #include "../../include/glowk.h"
 #include "glowk_kernels.h"
+#include "glowk_light.h"
 #include "glowk_launch.h"
 
 #include <algorithm>
@@ -21,8 +22,22 @@ thread_local std::string g_err;
 
 int fail(const std::string& m) {
   g_err = m;
-  return 1;
+  return GLOWK_ERR;
 }
+
+// every entry point that touches the GPU runs on the handle's device and hands the caller's current device back
+struct DeviceGuard {
+  int prev = -1;
+  bool changed = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) changed = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (changed) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 #define HIPCHK(expr)                                                                           \
   do {                                                                                         \
@@ -47,6 +62,8 @@ struct StepDev {            // device pointers into the arena
   const float4* RHBp = nullptr;  // f16x3 image of the backward network (null: not supported: exact fp32 backward)
   float scb1 = 1.f, scb2 = 1.f, scb3 = 1.f;
   float sc1 = 1.f, sc2 = 1.f, sc3 = 1.f;
+  float xlim_f = 0.f, xlim_b = 0.f;   // range guard of the split kernels: largest |network input| (forward: v_b; backward: g_o) for which no
+                                      // hidden value can leave the fp16 range (L1 bounds of the weights; pack_step)
   const float* K3bp = nullptr;   // backward: conv3^T operands of the small-conv chain [NF][9c/2][64]
   const float4* RBp = nullptr;   // backward ring image: K2^T chunk fo | K3b operands of block fo+1 ; conv1^T chunks
   const float *Afwd = nullptr, *bfwd = nullptr, *Ainv = nullptr, *binv = nullptr, *b3 = nullptr;
@@ -67,6 +84,10 @@ struct glowk_handle {
   glowk_config cfg;
   int device = 0;
   int precision = GLOWK_PREC_F32;
+  int range_policy = GLOWK_RANGE_ERROR;
+  int64_t range_fallbacks = 0;
+  int* d_flag = nullptr;        // sticky range flag (device), written by k_couple / k_bwd_light
+  int* h_flag = nullptr;        // pinned host word it is read back into
   std::vector<Level> levels;
   int Hl = 0, Wl = 0, Cl = 0;
   std::vector<float> prior_loc, prior_log_scale;
@@ -85,6 +106,7 @@ struct glowk_handle {
   double* bufStat = nullptr;    // [STAT_BLOCKS][32] partial sums + [32] means
   // input-gradient path: per-step saves of the forward pass (v, P, ReLU masks) and gradient scratch
   int saveN = 0;
+  size_t cN = 0;                // tiles bufC holds
   float *saveV = nullptr, *saveP = nullptr, *bufGz = nullptr;   // saveP: save_np partials of every step's P, save_pstride apart
   size_t save_pstride = 0;
   int save_np = 1;
@@ -105,7 +127,7 @@ size_t step_tensor_size(const glowk_config& cfg, const Level& lv, int id) {
   switch (id) {
     case GLOWK_ACTNORM_LOG_SCALE: case GLOWK_ACTNORM_SHIFT: case GLOWK_INV1X1_SIGN_S: case GLOWK_INV1X1_LOG_S:
     case GLOWK_CONV3_BIAS: return c;
-    case GLOWK_INV1X1_P: case GLOWK_INV1X1_L: case GLOWK_INV1X1_U: return c * c;
+    case GLOWK_INV1X1_P: case GLOWK_INV1X1_L: case GLOWK_INV1X1_U: case GLOWK_INV1X1_P_INV: return c * c;
     case GLOWK_CONV1_KERNEL: return 9 * (c / 2) * F;
     case GLOWK_CONV2_KERNEL: return F * F;
     case GLOWK_CONV3_KERNEL: return 9 * F * c;
@@ -250,6 +272,14 @@ bool pack_affine(const glowk_config& cfg, const Level& lv, int k, float* dst, do
     *err = "singular 1x1 convolution factor";
     return false;
   }
+  {
+    // the reference's inverse multiplies by its stored variable P_inv (:313), not by inv(P): honour one that was loaded
+    const float* pin = T(GLOWK_INV1X1_P_INV);
+    bool set = false;
+    for (int i = 0; i < c * c; ++i) set |= pin[i] != 0.0f;
+    if (set)
+      for (int i = 0; i < c * c; ++i) Pi[i] = pin[i];
+  }
   const Mat Winv = matmul(Ui, matmul(Li, Pi, c), c);  // :309-315
   const float* ls = T(GLOWK_ACTNORM_LOG_SCALE);
   const float* sh = T(GLOWK_ACTNORM_SHIFT);
@@ -272,7 +302,7 @@ bool pack_affine(const glowk_config& cfg, const Level& lv, int k, float* dst, do
 }
 
 // pack one step into dst (host staging of the arena)
-bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, double* ld_const_out, float* scales3 /* [6]: fwd, bwd */, std::string* err) {
+bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, double* ld_const_out, float* scales3 /* [8]: fwd, bwd scales; fwd, bwd input limits */, std::string* err) {
   const int c = lv.c, F = cfg.F, CI = c / 2, CO = c, NF = F / 32, KS1 = (9 * CI) / 2, NMT = (9 * c + 31) / 32;
   const StepLayout L = step_layout(c, F);
   auto T = [&](int id) -> const float* { return lv.host[id][k].data(); };
@@ -336,6 +366,9 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
   }
   // ---- f16x3 image (k_net_h3): weights scaled by a power of two, split hi/lo in fp16, A operands in fragment order ----
   for (int i = 0; i < 6; ++i) scales3[i] = 1.0f;
+  scales3[6] = scales3[7] = 0.0f;
+  // values about to be split must stay below the fp16 maximum after the activation scale (a little margin for rounding)
+  const double RANGE_LIM = 60000.0 / (double)GLOWK_ACT_SCALE;
   auto pow2_scale = [](const float* w, size_t n) {
     float m = 0.0f;
     for (size_t i = 0; i < n; ++i) m = std::fmax(m, std::fabs(w[i]));
@@ -389,6 +422,33 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
             K3f[((size_t)tap * F + f) * CO + co] = (float)(w * m2[f]);
             pbf[(size_t)tap * CO + co] += w * (double)ep[5 * F + f];
           }
+    }
+    {
+      // ---- range guard, forward network (glowk_kernels.h: range8): with |input| <= X the value split after conv1 is at most
+      //      2^e1[f] (sum_k |K1[k][f]| X + |b1[f]|), the one split after conv2 at most
+      //      2^e2[f'] (sum_f |K2[f][f']| (|g1[f]| r1max[f] + |d1[f]|) + |b2[f']|): the largest X that keeps all of them in range
+      const float* ep = dst + L.ep;     // [b1 | g1 | d1 | b2 | g2 | d2]
+      std::vector<double> n1(F, 0.0);   // sum_k |K1[k][f]|
+      for (int kk = 0; kk < 9 * CI; ++kk)
+        for (int f = 0; f < F; ++f) n1[f] += std::fabs((double)K1[(size_t)kk * F + f]);
+      double xl = RANGE_LIM;
+      auto tighten = [&](double A, double B) {
+        const double room = RANGE_LIM - B;
+        if (room <= 0.0) xl = 0.0;
+        else if (A > 0.0) xl = std::min(xl, room / A);
+      };
+      for (int f = 0; f < F; ++f) tighten(std::ldexp(n1[f], e1[f]), std::ldexp(std::fabs((double)ep[f]), e1[f]));
+      std::vector<double> A2(F, 0.0), B2(F, 0.0);
+      for (int fi = 0; fi < F; ++fi) {
+        const double ga = std::fabs((double)ep[F + fi]), a = ga * n1[fi], b = ga * std::fabs((double)ep[fi]) + std::fabs((double)ep[2 * F + fi]);
+        for (int fo = 0; fo < F; ++fo) {
+          const double w = std::fabs((double)K2[(size_t)fi * F + fo]);
+          A2[fo] += w * a;
+          B2[fo] += w * b;
+        }
+      }
+      for (int fo = 0; fo < F; ++fo) tighten(std::ldexp(A2[fo], e2[fo]), std::ldexp(B2[fo] + std::fabs((double)ep[3 * F + fo]), e2[fo]));
+      scales3[6] = (float)(xl * (double)GLOWK_ACT_SCALE * (1.0 - 1e-6));   // the kernel compares its scaled gathers
     }
     const int S1 = pow2_scale(K1f.data(), K1f.size()), S2 = pow2_scale(K2f.data(), K2f.size()), S3 = pow2_scale(K3f.data(), K3f.size());
     const float act = GLOWK_ACT_SCALE;
@@ -498,6 +558,18 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
       for (int f = 0; f < F; ++f) { const int tap = kk / c, co = kk % c; W3b[(size_t)kk * F + f] = K3[((size_t)tap * F + f) * c + co] * ep[4 * F + f]; }
     for (int f2 = 0; f2 < F; ++f2)
       for (int f1 = 0; f1 < F; ++f1) W2b[(size_t)f2 * F + f1] = K2[(size_t)f1 * F + f2] * ep[F + f1];      // [k = f2][out = f1]
+    {
+      // ---- range guard, backward network: with |g_o| <= X,  |g_a2[f]| <= sum_k |W3b[k][f]| X  and
+      //      |g_a1[f1]| <= sum_f2 |W2b[f2][f1]| |g_a2[f2]|  (no constants: the backward network is linear) ----
+      std::vector<double> a1(F, 0.0), a2(F, 0.0);
+      for (int kk = 0; kk < 9 * c; ++kk)
+        for (int f = 0; f < F; ++f) a1[f] += std::fabs((double)W3b[(size_t)kk * F + f]);
+      for (int f2 = 0; f2 < F; ++f2)
+        for (int f1 = 0; f1 < F; ++f1) a2[f1] += std::fabs((double)W2b[(size_t)f2 * F + f1]) * a1[f2];
+      double amax = 1.0;
+      for (int f = 0; f < F; ++f) amax = std::max(amax, std::max(a1[f], a2[f]));
+      scales3[7] = (float)(RANGE_LIM / amax * (double)GLOWK_ACT_SCALE * (1.0 - 1e-6));
+    }
     const int S1 = pow2_scale(W3b.data(), W3b.size()), S2 = pow2_scale(W2b.data(), W2b.size()), S3 = pow2_scale(K1, (size_t)9 * CI * F);
     scales3[3] = std::ldexp(1.0f, -S1); scales3[4] = std::ldexp(1.0f, -S2); scales3[5] = std::ldexp(1.0f, -S3) / GLOWK_ACT_SCALE;
     const size_t k1blk = (size_t)KSB * 2 * 256, chunkf = (size_t)NFH * 1024;
@@ -650,6 +722,8 @@ void launch_fail(const std::string& m) { fail(m); }
 // instantiated in glowk_net_inst.hip, one translation unit per (CI, NF)
 #define GLOWK_EXTERN_NET(CI_, NF_) extern template int launch_net_t<CI_, NF_>(const NetArgs&, int, hipStream_t, bool);
 GLOWK_EXTERN_NET(2, 16) GLOWK_EXTERN_NET(4, 16) GLOWK_EXTERN_NET(8, 16) GLOWK_EXTERN_NET(16, 16)
+GLOWK_EXTERN_NET(2, 12) GLOWK_EXTERN_NET(4, 12) GLOWK_EXTERN_NET(8, 12) GLOWK_EXTERN_NET(16, 12)
+GLOWK_EXTERN_NET(2, 8) GLOWK_EXTERN_NET(4, 8) GLOWK_EXTERN_NET(8, 8) GLOWK_EXTERN_NET(16, 8)
 GLOWK_EXTERN_NET(2, 4) GLOWK_EXTERN_NET(4, 4) GLOWK_EXTERN_NET(8, 4) GLOWK_EXTERN_NET(16, 4)
 #undef GLOWK_EXTERN_NET
 }  // namespace glowk_detail
@@ -662,9 +736,15 @@ using glowk_detail::launch_net_t;
 // 6 two-term split)
 int fwd_mode(const glowk_handle* h) { return h->precision == GLOWK_PREC_F16X3 ? 3 : h->precision == GLOWK_PREC_F16X2 ? 6 : NET_FWD; }
 
+// the light kernels raise the sticky range flag only for calls in a split arithmetic (in exact fp32 a non-finite value is the
+// reference's own result, and the fp32 re-run of the FALLBACK policy must not re-arm it)
+int* flagp(const glowk_handle* h) { return h->precision == GLOWK_PREC_F32 ? nullptr : h->d_flag; }
+
 int launch_net_raw(int c, int F, const NetArgs& a, int mode, hipStream_t s, bool dry = false) {
 #define NETCASE(CI_, NF_) if (c == 2 * CI_ && F == 32 * NF_) return launch_net_t<CI_, NF_>(a, mode, s, dry);
   NETCASE(2, 16) NETCASE(4, 16) NETCASE(8, 16) NETCASE(16, 16)
+  NETCASE(2, 12) NETCASE(4, 12) NETCASE(8, 12) NETCASE(16, 12)
+  NETCASE(2, 8) NETCASE(4, 8) NETCASE(8, 8) NETCASE(16, 8)
   NETCASE(2, 4) NETCASE(4, 4) NETCASE(8, 4) NETCASE(16, 4)
 #undef NETCASE
   fail("unsupported (channels, n_filters) combination: c=" + std::to_string(c) + " F=" + std::to_string(F));
@@ -720,21 +800,90 @@ PreArgs pre_args(const glowk_config& cfg) {
   return p;
 }
 
+// ---- device memory of a handle: ONE description of every buffer, used by the allocators and by glowk_workspace_bytes ----
+struct WsSizes {      // forward / inverse workspace for N tiles (bytes)
+  size_t act, P, ld;  // bufA, bufB, bufZ (each) | bufP (4 partial per-tap buffers) | bufLd
+  size_t total() const { return 3 * act + P + ld; }
+};
+WsSizes ws_sizes(const glowk_handle* h, size_t N) {
+  const size_t E = (size_t)h->cfg.H * h->cfg.W * h->cfg.C;
+  return WsSizes{N * E * 4, 4 * 9 * N * E * 4, N * 8};
+}
+struct SaveSizes {    // input-gradient path for N tiles: per-step saves + scratch
+  size_t v, p, m;     // floats of saveV, floats of ONE partial of saveP, shorts of saveM
+  int np;             // partials of saveP
+  size_t gz, c;       // bytes of bufGz, bufC
+  size_t total() const { return v * 4 + (size_t)np * p * 4 + m * 2 + gz + c; }
+};
+NetArgs net_args(glowk_handle* h, const Level& lv, const StepDev& sd, const float* vin, int in_stride, int in_off, int N);
+SaveSizes save_sizes(const glowk_handle* h, size_t N, std::vector<size_t>* offV = nullptr, std::vector<size_t>* offP = nullptr,
+                     std::vector<size_t>* offM = nullptr) {
+  const int K = h->cfg.K, L = h->cfg.L, NF = h->cfg.F / 32;
+  SaveSizes S{0, 0, 0, 1, 0, 0};
+  if (offV) { offV->assign((size_t)L * K, 0); offP->assign((size_t)L * K, 0); offM->assign((size_t)L * K, 0); }
+  for (int lvl = 0; lvl < L; ++lvl) {
+    const Level& lv = h->levels[lvl];
+    const size_t Q = N * lv.h * lv.w;
+    const size_t blocks = ((Q + 255) / 256) * 8;
+    for (int j = 0; j < K; ++j) {
+      const size_t sidx = (size_t)lvl * K + j;
+      if (offV) { (*offV)[sidx] = S.v; (*offP)[sidx] = S.p; (*offM)[sidx] = S.m; }
+      S.v += Q * lv.c;
+      S.p += Q * lv.c * 9;
+      S.m += 2 * blocks * NF * 64;   // mask1 then mask2
+    }
+  }
+  // partial P buffers per step: as many as the saving forward launches of this batch size write in the handle's arithmetic
+  // (exact fp32: one; the split kernels: one per pass over the hidden width -- asked of the launch policy itself, dry)
+  if (h->precision != GLOWK_PREC_F32 && h->finalized) {
+    if (N <= 256) S.np = 4;        // small batches: room for the 4-pass launches whatever batch size below N comes later
+    glowk_handle* hm = const_cast<glowk_handle*>(h);
+    for (const Level& lv : h->levels) {
+      NetArgs probe = net_args(hm, lv, lv.dev[0], nullptr, lv.c, lv.c / 2, (int)N);
+      probe.max_np = 4;
+      S.np = std::max(S.np, launch_net_raw(lv.c, h->cfg.F, probe, 4, nullptr, true));
+    }
+  }
+  const size_t E = (size_t)h->cfg.H * h->cfg.W * h->cfg.C;
+  S.gz = N * E * 4;
+  S.c = N * E * 4;
+  return S;
+}
+
+int ensure_flag(glowk_handle* h) {
+  if (h->d_flag) return 0;
+  HIPCHK(hipMalloc(&h->d_flag, 16));
+  HIPCHK(hipMemset(h->d_flag, 0, 16));
+  HIPCHK(hipHostMalloc(&h->h_flag, 16));
+  h->h_flag[0] = 0;
+  return 0;
+}
+
 int ensure_ws(glowk_handle* h, int N) {
+  if (int rc = ensure_flag(h)) return rc;
   if (N <= h->wsN) return 0;
-  HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipDeviceSynchronize());
   if (h->bufA) { hipFree(h->bufA); hipFree(h->bufB); hipFree(h->bufP); hipFree(h->bufZ); hipFree(h->bufLd); }
-  if (h->bufC) hipFree(h->bufC);
-  h->bufA = h->bufB = h->bufP = h->bufZ = h->bufC = nullptr; h->bufLd = nullptr; h->wsN = 0;
-  const size_t E = (size_t)h->cfg.H * h->cfg.W * h->cfg.C;
-  HIPCHK(hipMalloc(&h->bufA, (size_t)N * E * 4));
-  HIPCHK(hipMalloc(&h->bufB, (size_t)N * E * 4));
-  h->pstride = (size_t)N * E * 9;
-  HIPCHK(hipMalloc(&h->bufP, 4 * h->pstride * 4));
-  HIPCHK(hipMalloc(&h->bufZ, (size_t)N * E * 4));
-  HIPCHK(hipMalloc(&h->bufLd, (size_t)N * 8));
+  h->bufA = h->bufB = h->bufP = h->bufZ = nullptr; h->bufLd = nullptr; h->wsN = 0;
+  const WsSizes W = ws_sizes(h, (size_t)N);
+  HIPCHK(hipMalloc(&h->bufA, W.act));
+  HIPCHK(hipMalloc(&h->bufB, W.act));
+  h->pstride = W.P / 16;          // floats per partial
+  HIPCHK(hipMalloc(&h->bufP, W.P));
+  HIPCHK(hipMalloc(&h->bufZ, W.act));
+  HIPCHK(hipMalloc(&h->bufLd, W.ld));
   h->wsN = N;
+  return 0;
+}
+
+// scratch tensor of the gradient path / the ActNorm initialisation (one level tensor)
+int ensure_c(glowk_handle* h, int N) {
+  if ((size_t)N <= h->cN) return 0;
+  HIPCHK(hipDeviceSynchronize());
+  if (h->bufC) hipFree(h->bufC);
+  h->bufC = nullptr; h->cN = 0;
+  HIPCHK(hipMalloc(&h->bufC, (size_t)N * h->cfg.H * h->cfg.W * h->cfg.C * 4));
+  h->cN = (size_t)N;
   return 0;
 }
 
@@ -766,46 +915,29 @@ NetArgs net_args(glowk_handle* h, const Level& lv, const StepDev& sd, const floa
   a.Q = N * lv.h * lv.w; a.h = lv.h; a.w = lv.w;
   a.K1p = sd.K1p; a.ep = sd.ep; a.R0p = sd.R0p; a.mask1 = nullptr; a.mask2 = nullptr; a.P = h->bufP;
   a.RHp = sd.RHp; a.RSp = sd.RSp; a.fam16 = (sd.RSp && sd.RSBp) ? 1 : 0; a.eph = sd.epH; a.pstride = h->pstride; a.max_np = 4; a.sc1 = sd.sc1; a.sc2 = sd.sc2; a.sc3 = sd.sc3;
+  a.flag = flagp(h); a.xlim = sd.xlim_f;
   return a;
 }
 
 // per-step save buffers of the input-gradient path, forward order index sidx = level*K + (K-1-k)
 int ensure_save(glowk_handle* h, int N) {
-  if (!h->bufC) HIPCHK(hipMalloc(&h->bufC, (size_t)h->wsN * (size_t)h->cfg.H * h->cfg.W * h->cfg.C * 4));   // (ensure_ws drops it when it grows)
-  if (N <= h->saveN) return 0;
-  HIPCHK(hipSetDevice(h->device));
+  if (int rc = ensure_c(h, N)) return rc;
+  const SaveSizes need = save_sizes(h, (size_t)N);
+  if (N <= h->saveN && need.np <= h->save_np) return 0;
+  const int Na = std::max(N, h->saveN);
   HIPCHK(hipDeviceSynchronize());
   if (h->saveV) { hipFree(h->saveV); hipFree(h->saveP); hipFree(h->saveM); hipFree(h->bufGz); }
   h->saveV = h->saveP = h->bufGz = nullptr; h->saveM = nullptr; h->saveN = 0;
-  const int K = h->cfg.K, L = h->cfg.L, NF = h->cfg.F / 32;
-  size_t v = 0, p = 0, m = 0;
-  h->offV.assign((size_t)L * K, 0); h->offP.assign((size_t)L * K, 0); h->offM.assign((size_t)L * K, 0);
-  for (int lvl = 0; lvl < L; ++lvl) {
-    const Level& lv = h->levels[lvl];
-    const size_t Q = (size_t)N * lv.h * lv.w;
-    const size_t blocks = ((Q + 255) / 256) * 8;
-    for (int j = 0; j < K; ++j) {
-      const size_t sidx = (size_t)lvl * K + j;
-      h->offV[sidx] = v; v += Q * lv.c;
-      h->offP[sidx] = p; p += Q * lv.c * 9;
-      h->offM[sidx] = m; m += 2 * blocks * NF * 64;   // mask1 then mask2
-    }
-  }
-  const size_t E = (size_t)h->cfg.H * h->cfg.W * h->cfg.C;
-  HIPCHK(hipMalloc(&h->saveV, v * 4));
-  // partial P buffers per step: as many as the forward-with-saves launches of this batch size can write
-  h->save_np = N <= 256 ? 4 : 1;   // (small batches: room for the 4-pass launches whatever the probe says)
-  for (const Level& lv : h->levels) {
-    NetArgs probe = net_args(h, lv, lv.dev[0], nullptr, lv.c, lv.c / 2, N);
-    h->save_np = std::max(h->save_np, launch_net_raw(lv.c, h->cfg.F, probe, 4, nullptr, true));
-  }
-  h->save_pstride = p;
+  SaveSizes S = save_sizes(h, (size_t)Na, &h->offV, &h->offP, &h->offM);
+  S.np = std::max(S.np, need.np);
+  HIPCHK(hipMalloc(&h->saveV, S.v * 4));
+  h->save_np = S.np;
+  h->save_pstride = S.p;
   h->save_parts.assign((size_t)h->cfg.L * h->cfg.K, 1);
-  HIPCHK(hipMalloc(&h->saveP, (size_t)h->save_np * p * 4));
-  HIPCHK(hipMalloc(&h->saveM, m * 2));
-  HIPCHK(hipMalloc(&h->bufGz, (size_t)N * E * 4));
-  if (!h->bufC) HIPCHK(hipMalloc(&h->bufC, (size_t)h->wsN * E * 4));
-  h->saveN = N;
+  HIPCHK(hipMalloc(&h->saveP, (size_t)S.np * S.p * 4));
+  HIPCHK(hipMalloc(&h->saveM, S.m * 2));
+  HIPCHK(hipMalloc(&h->bufGz, S.gz));
+  h->saveN = Na;
   return 0;
 }
 
@@ -843,7 +975,7 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
       if (save) h->save_parts[sidx] = np;
       CoupleArgs ca;
       ca.vin = cur; ca.P = na.P; ca.np = np; ca.pstride = na.pstride; ca.b3 = sd.b3; ca.logdet = h->bufLd; ca.log_s_out = nullptr; ca.t_out = nullptr;
-      ca.Q = (int)Q; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0;
+      ca.Q = (int)Q; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0; ca.flag = flagp(h);
       float* next = save && k > 0 ? h->saveV + h->offV[sidx + 1] : oth;
       if (k > 0) {
         ca.A = lv.dev[k - 1].Afwd; ca.b = lv.dev[k - 1].bfwd;
@@ -896,7 +1028,7 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       const StepDev& sd = lv.dev[k];
       const size_t sidx = (size_t)lvl * K + (K - 1 - k);
       BwdArgs ba;
-      ba.Q = Q; ba.h = lv.h; ba.w = lv.w;
+      ba.Q = Q; ba.h = lv.h; ba.w = lv.w; ba.flag = flagp(h);
       ba.v = h->saveV + h->offV[sidx]; ba.P = h->saveP + h->offP[sidx]; ba.np = h->save_parts[sidx]; ba.pstride = h->save_pstride; ba.b3 = sd.b3;
       ba.g_o = g_o; ba.ghalf_out = gh_b; ba.gu_out = nullptr;
       if (k == 0) {
@@ -917,13 +1049,13 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       na.mask1 = h->saveM + h->offM[sidx];
       na.mask2 = na.mask1 + blocks * NF * 64;
       const bool h3b = h->precision != GLOWK_PREC_F32 && sd.RHBp;
-      if (h3b) { na.RHp = sd.RHBp; na.RSp = sd.RSBp; na.eph = nullptr; na.sc1 = sd.scb1; na.sc2 = sd.scb2; na.sc3 = sd.scb3; }
+      if (h3b) { na.RHp = sd.RHBp; na.RSp = sd.RSBp; na.eph = nullptr; na.sc1 = sd.scb1; na.sc2 = sd.scb2; na.sc3 = sd.scb3; na.xlim = sd.xlim_b; }
       if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, h3b ? 5 : NET_BWD, &npg)) return rc;
     }
     // first forward step of the block (k = K-1): merge, then through its ActNorm + 1x1 -> g_u of the squeezed block input
     {
       BwdArgs ba;
-      ba.Q = Q; ba.h = lv.h; ba.w = lv.w;
+      ba.Q = Q; ba.h = lv.h; ba.w = lv.w; ba.flag = flagp(h);
       ba.ghalf_in = gh_a; ba.Pg = Pg; ba.npg = npg; ba.pgstride = h->pstride; ba.gv_direct = nullptr; ba.gvd_stride = 0; ba.gvd_off = 0;
       ba.A = lv.dev[K - 1].Afwd;
       ba.v = nullptr; ba.P = nullptr; ba.np = 1; ba.pstride = 0; ba.b3 = nullptr; ba.g_o = nullptr; ba.ghalf_out = nullptr; ba.gu_out = g_o;   // reuse g_o as g_u
@@ -963,7 +1095,7 @@ int run_inverse(glowk_handle* h, const float* z, int N, float* x, hipStream_t s)
       if (int rc = launch_net(h, lvl, lv.c, cfg.F, net_args(h, lv, sd, cur, lv.c, lv.c / 2, N), s, fwd_mode(h), &np)) return rc;
       CoupleArgs ca;
       ca.vin = cur; ca.P = h->bufP; ca.np = np; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
-      ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 1;
+      ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 1; ca.flag = flagp(h);
       ca.A = sd.Ainv; ca.b = sd.binv; ca.out = oth; ca.out_stride = lv.c; ca.out_off = 0;
       if (int rc = launch_couple(lv.c, ca, N, s)) return rc;
       std::swap(cur, oth);
@@ -973,6 +1105,39 @@ int run_inverse(glowk_handle* h, const float* z, int N, float* x, hipStream_t s)
   CDISPATCH(l0.c, hipLaunchKernelGGL((k_out<CC>), dim3(N), dim3(256), 0, s, cur, l0.h, l0.w, pre_args(cfg), 1, x));
   LAUNCHCHK("k_out");
   return 0;
+}
+
+// device that owns a device pointer (the handle-free entry points launch there); the current device if HIP cannot tell
+int ptr_device(const void* p) {
+  hipPointerAttribute_t a;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  if (hipPointerGetAttributes(&a, p) == hipSuccess && a.device >= 0) return a.device;
+  (void)hipGetLastError();
+  return cur;
+}
+
+// The range guard around one compute call (include/glowk.h: glowk_range_policy).  `run` issues the call's launches.
+template <class Run>
+int guarded(glowk_handle* h, hipStream_t s, Run&& run) {
+  if (int rc = run()) return rc;
+  if (h->precision == GLOWK_PREC_F32 || h->range_policy == GLOWK_RANGE_IGNORE) return 0;
+  HIPCHK(hipMemcpyAsync(h->h_flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (!h->h_flag[0]) return 0;
+  h->h_flag[0] = 0;
+  HIPCHK(hipMemsetAsync(h->d_flag, 0, sizeof(int), s));
+  if (h->range_policy == GLOWK_RANGE_ERROR) {
+    g_err = "a hidden activation left the fp16 range of the split arithmetic (|a| >= 16 376) or the input is not finite: "
+            "the outputs of this call are not usable -- use GLOWK_PREC_F32 or GLOWK_RANGE_FALLBACK";
+    return GLOWK_ERR_RANGE;
+  }
+  const int prec = h->precision;   // FALLBACK: the same call on the exact kernels, in-process
+  h->precision = GLOWK_PREC_F32;
+  ++h->range_fallbacks;
+  const int rc = run();
+  h->precision = prec;
+  return rc;
 }
 
 }  // namespace
@@ -989,7 +1154,7 @@ int glowk_create(const glowk_config* cfg, int device, glowk_handle** out) {
   const int s = 1 << cfg->L;
   if (cfg->H <= 0 || cfg->W <= 0 || cfg->C <= 0 || cfg->H % s || cfg->W % s) return fail("H and W must be positive multiples of 2^L");
   if (cfg->K <= 0) return fail("K must be positive");
-  if (cfg->F % 128 || cfg->F <= 0 || cfg->F > 512) return fail("n_filters must be a multiple of 128, at most 512");
+  if (cfg->F != 128 && cfg->F != 256 && cfg->F != 384 && cfg->F != 512) return fail("n_filters must be 128, 256, 384 or 512 (the instantiated coupling-network widths)");
   glowk_handle* h = new glowk_handle();
   h->cfg = *cfg;
   h->device = device;
@@ -1022,8 +1187,10 @@ int glowk_create(const glowk_config* cfg, int device, glowk_handle** out) {
 
 int glowk_destroy(glowk_handle* h) {
   if (!h) return 0;
-  hipSetDevice(h->device);
+  DeviceGuard dg(h->device);
   if (h->arena) hipFree(h->arena);
+  if (h->d_flag) hipFree(h->d_flag);
+  if (h->h_flag) hipHostFree(h->h_flag);
   if (h->bufA) { hipFree(h->bufA); hipFree(h->bufB); hipFree(h->bufP); hipFree(h->bufZ); hipFree(h->bufLd); }
   if (h->bufC) hipFree(h->bufC);
   if (h->bufStat) hipFree(h->bufStat);
@@ -1064,6 +1231,17 @@ int glowk_get_tensor(const glowk_handle* h, int level, int step, int tensor_id, 
   if (!v) return fail("no such tensor");
   if (v->size() != n) return fail("tensor size mismatch");
   std::memcpy(host, v->data(), n * sizeof(float));
+  if (tensor_id == GLOWK_INV1X1_P_INV) {   // never loaded: what the reference initialises it to, inv(P)
+    bool set = false;
+    for (size_t i = 0; i < n; ++i) set |= host[i] != 0.0f;
+    if (!set) {
+      const int c = h->levels[level].c;
+      const std::vector<float>& P = h->levels[level].host[GLOWK_INV1X1_P][step];
+      Mat Pm(P.begin(), P.end()), Pi;
+      if (invert(Pm, c, Pi))
+        for (size_t i = 0; i < n; ++i) host[i] = (float)Pi[i];
+    }
+  }
   return 0;
 }
 
@@ -1073,7 +1251,6 @@ int glowk_finalize_weights(glowk_handle* h) {
   for (const Level& lv : h->levels)
     if (lv.c != 4 && lv.c != 8 && lv.c != 16 && lv.c != 32)
       return fail("unsupported channel count " + std::to_string(lv.c) + " (this build: 4, 8, 16, 32)");
-  if (cfg.F != 128 && cfg.F != 512) return fail("this build instantiates n_filters 128 and 512 only");
   size_t total = 0;
   for (const Level& lv : h->levels) total += step_layout(lv.c, cfg.F).total * cfg.K;
   const size_t E = h->prior_loc.size();
@@ -1083,14 +1260,14 @@ int glowk_finalize_weights(glowk_handle* h) {
   h->ld_step.assign((size_t)cfg.L * cfg.K, 0.0);
   h->ld_const = 0.0;
   // every step packs into its own block of the staging arena: steps are packed by a few host threads
-  struct Job { size_t l; int k; size_t off; double ldc; float sc[6]; std::string err; bool ok; };
+  struct Job { size_t l; int k; size_t off; double ldc; float sc[8]; std::string err; bool ok; };
   std::vector<Job> jobs;
   std::vector<size_t> offs;
   {
     size_t o = 0;
     for (size_t l = 0; l < h->levels.size(); ++l)
       for (int k = 0; k < cfg.K; ++k) {
-        jobs.push_back(Job{l, k, o, 0.0, {1, 1, 1, 1, 1, 1}, std::string(), false});
+        jobs.push_back(Job{l, k, o, 0.0, {1, 1, 1, 1, 1, 1, 0, 0}, std::string(), false});
         offs.push_back(o);
         o += step_layout(h->levels[l].c, cfg.F).total;
       }
@@ -1118,6 +1295,7 @@ int glowk_finalize_weights(glowk_handle* h) {
     h->ld_step[jb.l * cfg.K + jb.k] = jb.ldc;
     d.sc1 = jb.sc[0]; d.sc2 = jb.sc[1]; d.sc3 = jb.sc[2];
     d.scb1 = jb.sc[3]; d.scb2 = jb.sc[4]; d.scb3 = jb.sc[5];
+    d.xlim_f = jb.sc[6]; d.xlim_b = jb.sc[7];
     h->ld_const += jb.ldc;
   }
   std::memcpy(stage.data() + prior_off, h->prior_loc.data(), E * 4);
@@ -1127,7 +1305,7 @@ int glowk_finalize_weights(glowk_handle* h) {
   h->ld_pre_const = -npx * std::log((double)cfg.maxval - (double)cfg.minval);
   if (cfg.use_logit) h->ld_pre_const += npx * std::log(1.0 - 2.0 * (double)cfg.alpha);
 
-  HIPCHK(hipSetDevice(h->device));
+  DeviceGuard dg(h->device);
   HIPCHK(hipDeviceSynchronize());
   if (h->arena) { hipFree(h->arena); h->arena = nullptr; }
   HIPCHK(hipMalloc(&h->arena, total * 4));
@@ -1173,7 +1351,7 @@ int run_step_inplace(glowk_handle* h, int lvl, int k, float* cur, float* tmp, in
   ca.vin = tmp; ca.P = h->bufP; ca.np = 1; ca.pstride = 0; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
   ca.out = cur; ca.out_stride = lv.c; ca.out_off = 0;
   ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
-  ca.Q = Q; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0;
+  ca.Q = Q; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0; ca.flag = nullptr;
   return launch_couple(lv.c, ca, Nl, s);
 }
 
@@ -1193,13 +1371,15 @@ int refresh_step_affine(glowk_handle* h, int lvl, int k, hipStream_t s) {
 }  // namespace
 
 int glowk_actnorm_data_init(glowk_handle* h, const float* x_dev, int N, int runtime_order, int raw_minibatch_quirk, void* stream) {
+  if (!h) return fail("null handle");
+  DeviceGuard dg(h->device);
   if (int rc = check_ready(h, N)) return rc;
   if (!x_dev) return fail("null tensor");
   hipStream_t s = (hipStream_t)stream;
   const glowk_config& cfg = h->cfg;
   const int K = cfg.K, L = cfg.L;
   const size_t E = (size_t)cfg.H * cfg.W * cfg.C;
-  if (!h->bufC) HIPCHK(hipMalloc(&h->bufC, (size_t)h->wsN * E * 4));
+  if (int rc = ensure_c(h, N)) return rc;
   if (!h->bufStat) HIPCHK(hipMalloc(&h->bufStat, (size_t)(STAT_BLOCKS + 1) * 32 * 8));
   // y = SpecPreprocessing.forward(minibatch) (flow_builder.py:121), kept in bufZ
   hipLaunchKernelGGL(k_pre_only, dim3(N), dim3(256), 0, s, x_dev, (int)E, pre_args(cfg), 0, h->bufZ, (float*)nullptr, 0.0);
@@ -1280,77 +1460,134 @@ int glowk_set_precision(glowk_handle* h, int precision) {
 
 int glowk_get_precision(const glowk_handle* h) { return h ? h->precision : -1; }
 
-size_t glowk_workspace_bytes(const glowk_handle* h, int N) {
-  if (!h || N <= 0) return 0;
-  const size_t E = (size_t)h->cfg.H * h->cfg.W * h->cfg.C;
-  return (size_t)N * E * 4 * 21 + (size_t)N * 8;
-}
-
-int glowk_max_tiles(const glowk_handle* h) { return h ? max_tiles(h) : 0; }
-
-int glowk_reserve(glowk_handle* h, int N) {
+int glowk_set_range_policy(glowk_handle* h, int policy) {
   if (!h) return fail("null handle");
-  if (int rc = check_batch(h, N)) return rc;
-  return ensure_ws(h, N);
+  if (policy != GLOWK_RANGE_IGNORE && policy != GLOWK_RANGE_ERROR && policy != GLOWK_RANGE_FALLBACK) return fail("unknown range policy");
+  h->range_policy = policy;
+  return 0;
 }
 
-int glowk_forward(glowk_handle* h, const float* x_dev, int N, float* z_dev, float* logdet_dev, void* stream) {
-  if (int rc = check_ready(h, N)) return rc;
-  if (!x_dev || !z_dev) return fail("null tensor");
-  hipStream_t s = (hipStream_t)stream;
-  if (int rc = run_forward(h, x_dev, N, z_dev, s)) return rc;
-  if (logdet_dev) {
-    hipLaunchKernelGGL(k_prior, dim3(N), dim3(256), 0, s, (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr,
-                       (const double*)h->bufLd, (float*)nullptr, logdet_dev);
-    LAUNCHCHK("k_prior(logdet)");
+int glowk_get_range_policy(const glowk_handle* h) { return h ? h->range_policy : -1; }
+
+int glowk_range_status(glowk_handle* h, int* tripped, int64_t* fallbacks, void* stream) {
+  if (!h) return fail("null handle");
+  DeviceGuard dg(h->device);
+  if (fallbacks) *fallbacks = h->range_fallbacks;
+  if (tripped) {
+    *tripped = 0;
+    if (h->d_flag) {
+      hipStream_t s = (hipStream_t)stream;
+      HIPCHK(hipMemcpyAsync(h->h_flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      if (h->h_flag[0]) {
+        *tripped = 1;
+        h->h_flag[0] = 0;
+        HIPCHK(hipMemsetAsync(h->d_flag, 0, sizeof(int), s));
+      }
+    }
   }
   return 0;
 }
 
-int glowk_inverse(glowk_handle* h, const float* z_dev, int N, float* x_dev, void* stream) {
+size_t glowk_workspace_bytes(const glowk_handle* h, int N, int with_grad) {
+  if (!h || N <= 0) return 0;
+  size_t b = ws_sizes(h, (size_t)N).total() + 16 /* range flag */;
+  if (with_grad) b += save_sizes(h, (size_t)N).total();
+  return b;
+}
+
+int glowk_max_tiles(const glowk_handle* h) { return h ? max_tiles(h) : 0; }
+
+int glowk_reserve(glowk_handle* h, int N, int with_grad) {
+  if (!h) return fail("null handle");
+  DeviceGuard dg(h->device);
+  if (int rc = check_batch(h, N)) return rc;
+  if (int rc = ensure_ws(h, N)) return rc;
+  if (with_grad) {
+    if (!h->finalized) return fail("glowk_finalize_weights must run before reserving the gradient path (its size depends on the launch policy)");
+    return ensure_save(h, N);
+  }
+  return 0;
+}
+
+int glowk_forward(glowk_handle* h, const float* x_dev, int N, float* z_dev, float* logdet_dev, void* stream) {
+  if (!h) return fail("null handle");
+  DeviceGuard dg(h->device);
   if (int rc = check_ready(h, N)) return rc;
   if (!x_dev || !z_dev) return fail("null tensor");
-  return run_inverse(h, z_dev, N, x_dev, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  return guarded(h, s, [&]() -> int {
+    if (int rc = run_forward(h, x_dev, N, z_dev, s)) return rc;
+    if (logdet_dev) {
+      hipLaunchKernelGGL(k_prior, dim3(N), dim3(256), 0, s, (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr,
+                         (const double*)h->bufLd, (float*)nullptr, logdet_dev);
+      LAUNCHCHK("k_prior(logdet)");
+    }
+    return 0;
+  });
+}
+
+int glowk_inverse(glowk_handle* h, const float* z_dev, int N, float* x_dev, void* stream) {
+  if (!h) return fail("null handle");
+  DeviceGuard dg(h->device);
+  if (int rc = check_ready(h, N)) return rc;
+  if (!x_dev || !z_dev) return fail("null tensor");
+  hipStream_t s = (hipStream_t)stream;
+  return guarded(h, s, [&]() -> int { return run_inverse(h, z_dev, N, x_dev, s); });
 }
 
 int glowk_log_prob(glowk_handle* h, const float* x_dev, int N, float* logp_dev, float* z_dev, void* stream) {
+  if (!h) return fail("null handle");
+  DeviceGuard dg(h->device);
   if (int rc = check_ready(h, N)) return rc;
   if (!x_dev || !logp_dev) return fail("null tensor");
   hipStream_t s = (hipStream_t)stream;
   float* z = z_dev ? z_dev : h->bufZ;
-  if (int rc = run_forward(h, x_dev, N, z, s)) return rc;
-  hipLaunchKernelGGL(k_prior, dim3(N), dim3(256), 0, s, (const float*)z, h->Hl * h->Wl * h->Cl, h->d_loc, h->d_log_scale,
-                     (const double*)h->bufLd, logp_dev, (float*)nullptr);
-  LAUNCHCHK("k_prior");
-  return 0;
+  return guarded(h, s, [&]() -> int {
+    if (int rc = run_forward(h, x_dev, N, z, s)) return rc;
+    hipLaunchKernelGGL(k_prior, dim3(N), dim3(256), 0, s, (const float*)z, h->Hl * h->Wl * h->Cl, h->d_loc, h->d_log_scale,
+                       (const double*)h->bufLd, logp_dev, (float*)nullptr);
+    LAUNCHCHK("k_prior");
+    return 0;
+  });
 }
 
 int glowk_log_prob_grad(glowk_handle* h, const float* x_dev, int N, float* logp_dev, float* dx_dev, void* stream) {
+  if (!h) return fail("null handle");
+  DeviceGuard dg(h->device);
   if (int rc = check_ready(h, N)) return rc;
   if (!x_dev || !logp_dev || !dx_dev) return fail("null tensor");
   if (int rc = ensure_save(h, N)) return rc;
   hipStream_t s = (hipStream_t)stream;
   float* z = h->bufGz;   // the latent lives in bufGz until the prior gradient overwrites it in place
-  if (int rc = run_forward(h, x_dev, N, z, s, true)) return rc;
-  hipLaunchKernelGGL(k_prior, dim3(N), dim3(256), 0, s, (const float*)z, h->Hl * h->Wl * h->Cl, h->d_loc, h->d_log_scale,
-                     (const double*)h->bufLd, logp_dev, (float*)nullptr);
-  LAUNCHCHK("k_prior");
-  return run_backward(h, x_dev, z, N, dx_dev, s);
+  return guarded(h, s, [&]() -> int {
+    if (int rc = run_forward(h, x_dev, N, z, s, true)) return rc;
+    hipLaunchKernelGGL(k_prior, dim3(N), dim3(256), 0, s, (const float*)z, h->Hl * h->Wl * h->Cl, h->d_loc, h->d_log_scale,
+                       (const double*)h->bufLd, logp_dev, (float*)nullptr);
+    LAUNCHCHK("k_prior");
+    return run_backward(h, x_dev, z, N, dx_dev, s);
+  });
 }
 
 int glowk_sample(glowk_handle* h, const float* eps_dev, int N, float* x_dev, void* stream) {
+  if (!h) return fail("null handle");
+  DeviceGuard dg(h->device);
   if (int rc = check_ready(h, N)) return rc;
   if (!eps_dev || !x_dev) return fail("null tensor");
   hipStream_t s = (hipStream_t)stream;
   const int E = h->Hl * h->Wl * h->Cl;
   const size_t total = (size_t)N * E;
-  hipLaunchKernelGGL(k_prior_sample, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, eps_dev, total, E, h->d_loc, h->d_log_scale,
-                     h->bufZ);
-  LAUNCHCHK("k_prior_sample");
-  return run_inverse(h, h->bufZ, N, x_dev, s);
+  return guarded(h, s, [&]() -> int {
+    hipLaunchKernelGGL(k_prior_sample, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, eps_dev, total, E, h->d_loc, h->d_log_scale,
+                       h->bufZ);
+    LAUNCHCHK("k_prior_sample");
+    return run_inverse(h, h->bufZ, N, x_dev, s);
+  });
 }
 
 int glowk_prior_log_prob(glowk_handle* h, const float* z_dev, int N, float* logp_dev, void* stream) {
+  if (!h) return fail("null handle");
+  DeviceGuard dg(h->device);
   if (int rc = check_ready(h, N)) return rc;
   if (!z_dev || !logp_dev) return fail("null tensor");
   hipLaunchKernelGGL(k_prior, dim3(N), dim3(256), 0, (hipStream_t)stream, z_dev, h->Hl * h->Wl * h->Cl, h->d_loc, h->d_log_scale,
@@ -1371,7 +1608,7 @@ int glowk_profile_end(glowk_handle* h, glowk_profile* out) {
   if (!h || !out) return fail("null argument");
   std::memset(out, 0, sizeof(*out));
   h->profiling = false;
-  HIPCHK(hipSetDevice(h->device));
+  DeviceGuard dg(h->device);
   HIPCHK(hipDeviceSynchronize());
   for (size_t i = 0; i < h->ev_level.size(); ++i) {
     float ms = 0.0f;
@@ -1388,6 +1625,7 @@ int glowk_squeeze(const float* x_dev, int N, int H, int W, int C, float* y_dev, 
   if (!x_dev || !y_dev) return fail("null tensor");
   if (N <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2) return fail("squeeze needs even H and W");  // flow_tfp_bijectors.py:165-166
   if ((long long)N * H * W * C > (1LL << 28)) return fail("squeeze: more than 2^28 elements in one call; split the batch");
+  DeviceGuard dg(ptr_device(x_dev));
   PreArgs p = {0, 1, 0, 0};
   const int c = 4 * C;
   CDISPATCH(c, hipLaunchKernelGGL((k_in<CC>), dim3(N), dim3(256), 0, (hipStream_t)stream, x_dev, H, W, p, 0, (const float*)nullptr,
@@ -1400,6 +1638,7 @@ int glowk_unsqueeze(const float* y_dev, int N, int hh, int ww, int c4, float* x_
   if (!x_dev || !y_dev) return fail("null tensor");
   if (N <= 0 || hh <= 0 || ww <= 0 || c4 % 4) return fail("unsqueeze needs a channel count divisible by 4");
   if ((long long)N * hh * ww * c4 > (1LL << 28)) return fail("unsqueeze: more than 2^28 elements in one call; split the batch");
+  DeviceGuard dg(ptr_device(y_dev));
   PreArgs p = {0, 1, 0, 0};
   CDISPATCH(c4, hipLaunchKernelGGL((k_out<CC>), dim3(N), dim3(256), 0, (hipStream_t)stream, y_dev, hh, ww, p, 0, x_dev));
   LAUNCHCHK("k_out(unsqueeze)");
@@ -1408,6 +1647,7 @@ int glowk_unsqueeze(const float* y_dev, int N, int hh, int ww, int c4, float* x_
 
 int glowk_preprocess_forward(glowk_handle* h, const float* x_dev, int N, float* y_dev, float* logdet_dev, void* stream) {
   if (!h || !x_dev || !y_dev) return fail("null argument");
+  DeviceGuard dg(h->device);
   if (int rc = check_batch(h, N)) return rc;
   const int E = h->cfg.H * h->cfg.W * h->cfg.C;
   double ldc = -(double)E * std::log((double)h->cfg.maxval - (double)h->cfg.minval);
@@ -1419,6 +1659,7 @@ int glowk_preprocess_forward(glowk_handle* h, const float* x_dev, int N, float* 
 
 int glowk_preprocess_inverse(glowk_handle* h, const float* y_dev, int N, float* x_dev, void* stream) {
   if (!h || !x_dev || !y_dev) return fail("null argument");
+  DeviceGuard dg(h->device);
   if (int rc = check_batch(h, N)) return rc;
   const int E = h->cfg.H * h->cfg.W * h->cfg.C;
   hipLaunchKernelGGL(k_pre_only, dim3(N), dim3(256), 0, (hipStream_t)stream, y_dev, E, pre_args(h->cfg), 1, x_dev, (float*)nullptr, 0.0);
@@ -1427,6 +1668,8 @@ int glowk_preprocess_inverse(glowk_handle* h, const float* y_dev, int N, float* 
 }
 
 int glowk_step_forward(glowk_handle* h, int level, int step, const float* u_dev, int N, float* y_dev, float* logdet_dev, void* stream) {
+  if (!h) return fail("null handle");
+  DeviceGuard dg(h->device);
   if (int rc = check_ready(h, N)) return rc;
   if (level < 0 || level >= h->cfg.L || step < 0 || step >= h->cfg.K) return fail("no such step");
   if (!u_dev || !y_dev) return fail("null tensor");
@@ -1434,64 +1677,72 @@ int glowk_step_forward(glowk_handle* h, int level, int step, const float* u_dev,
   const Level& lv = h->levels[level];
   const StepDev& sd = lv.dev[step];
   const int Q = N * lv.h * lv.w;
-  CDISPATCH(lv.c, hipLaunchKernelGGL((k_affine<CC>), dim3((Q + 255) / 256), dim3(256), 0, s, u_dev, Q, sd.Afwd, sd.bfwd, h->bufA));
-  LAUNCHCHK("k_affine");
-  int np = 1;
-  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, h->bufA, lv.c, lv.c / 2, N), s, fwd_mode(h), &np)) return rc;
-  if (logdet_dev) {
-    // logdet accumulator starts at the step's constant h*w*(sum log_scale + sum log_S)
-    PreArgs p = {0, 1, 0, 0};
-    (void)p;
-    std::vector<double> init(N, h->ld_step[(size_t)level * h->cfg.K + step]);
-    HIPCHK(hipMemcpyAsync(h->bufLd, init.data(), (size_t)N * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));
-  }
-  CoupleArgs ca;
-  ca.vin = h->bufA; ca.P = h->bufP; ca.np = np; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
-  ca.out = y_dev; ca.out_stride = lv.c; ca.out_off = 0;
-  ca.logdet = logdet_dev ? h->bufLd : nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
-  ca.Q = Q; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0;
-  if (int rc = launch_couple(lv.c, ca, N, s)) return rc;
-  if (logdet_dev) {
-    hipLaunchKernelGGL(k_prior, dim3(N), dim3(256), 0, s, (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr,
-                       (const double*)h->bufLd, (float*)nullptr, logdet_dev);
-    LAUNCHCHK("k_prior(logdet)");
-  }
-  return 0;
+  return guarded(h, s, [&]() -> int {
+    CDISPATCH(lv.c, hipLaunchKernelGGL((k_affine<CC>), dim3((Q + 255) / 256), dim3(256), 0, s, u_dev, Q, sd.Afwd, sd.bfwd, h->bufA));
+    LAUNCHCHK("k_affine");
+    int np = 1;
+    if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, h->bufA, lv.c, lv.c / 2, N), s, fwd_mode(h), &np)) return rc;
+    if (logdet_dev) {
+      // logdet accumulator starts at the step's constant h*w*(sum log_scale + sum log_S)
+      std::vector<double> init(N, h->ld_step[(size_t)level * h->cfg.K + step]);
+      HIPCHK(hipMemcpyAsync(h->bufLd, init.data(), (size_t)N * 8, hipMemcpyHostToDevice, s));
+      HIPCHK(hipStreamSynchronize(s));
+    }
+    CoupleArgs ca;
+    ca.vin = h->bufA; ca.P = h->bufP; ca.np = np; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
+    ca.out = y_dev; ca.out_stride = lv.c; ca.out_off = 0;
+    ca.logdet = logdet_dev ? h->bufLd : nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
+    ca.Q = Q; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0; ca.flag = flagp(h);
+    if (int rc = launch_couple(lv.c, ca, N, s)) return rc;
+    if (logdet_dev) {
+      hipLaunchKernelGGL(k_prior, dim3(N), dim3(256), 0, s, (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr,
+                         (const double*)h->bufLd, (float*)nullptr, logdet_dev);
+      LAUNCHCHK("k_prior(logdet)");
+    }
+    return 0;
+  });
 }
 
 int glowk_step_inverse(glowk_handle* h, int level, int step, const float* y_dev, int N, float* u_dev, void* stream) {
+  if (!h) return fail("null handle");
+  DeviceGuard dg(h->device);
   if (int rc = check_ready(h, N)) return rc;
   if (level < 0 || level >= h->cfg.L || step < 0 || step >= h->cfg.K) return fail("no such step");
   if (!u_dev || !y_dev) return fail("null tensor");
   hipStream_t s = (hipStream_t)stream;
   const Level& lv = h->levels[level];
   const StepDev& sd = lv.dev[step];
-  int np = 1;
-  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, y_dev, lv.c, lv.c / 2, N), s, fwd_mode(h), &np)) return rc;
-  CoupleArgs ca;
-  ca.vin = y_dev; ca.P = h->bufP; ca.np = np; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.A = sd.Ainv; ca.b = sd.binv;
-  ca.out = u_dev; ca.out_stride = lv.c; ca.out_off = 0;
-  ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
-  ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 1;
-  return launch_couple(lv.c, ca, N, s);
+  return guarded(h, s, [&]() -> int {
+    int np = 1;
+    if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, y_dev, lv.c, lv.c / 2, N), s, fwd_mode(h), &np)) return rc;
+    CoupleArgs ca;
+    ca.vin = y_dev; ca.P = h->bufP; ca.np = np; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.A = sd.Ainv; ca.b = sd.binv;
+    ca.out = u_dev; ca.out_stride = lv.c; ca.out_off = 0;
+    ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
+    ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 1; ca.flag = flagp(h);
+    return launch_couple(lv.c, ca, N, s);
+  });
 }
 
 int glowk_coupling_net(glowk_handle* h, int level, int step, const float* xb_dev, int N, float* log_s_dev, float* t_dev, void* stream) {
+  if (!h) return fail("null handle");
+  DeviceGuard dg(h->device);
   if (int rc = check_ready(h, N)) return rc;
   if (level < 0 || level >= h->cfg.L || step < 0 || step >= h->cfg.K) return fail("no such step");
   if (!xb_dev || !log_s_dev || !t_dev) return fail("null tensor");
   hipStream_t s = (hipStream_t)stream;
   const Level& lv = h->levels[level];
   const StepDev& sd = lv.dev[step];
-  int np = 1;
-  if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, xb_dev, lv.c / 2, 0, N), s, fwd_mode(h), &np)) return rc;
-  CoupleArgs ca;
-  ca.vin = nullptr; ca.P = h->bufP; ca.np = np; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
-  ca.out = nullptr; ca.out_stride = 0; ca.out_off = 0;
-  ca.logdet = nullptr; ca.log_s_out = log_s_dev; ca.t_out = t_dev;
-  ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0;
-  return launch_couple(lv.c, ca, N, s);
+  return guarded(h, s, [&]() -> int {
+    int np = 1;
+    if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, xb_dev, lv.c / 2, 0, N), s, fwd_mode(h), &np)) return rc;
+    CoupleArgs ca;
+    ca.vin = nullptr; ca.P = h->bufP; ca.np = np; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
+    ca.out = nullptr; ca.out_stride = 0; ca.out_off = 0;
+    ca.logdet = nullptr; ca.log_s_out = log_s_dev; ca.t_out = t_dev;
+    ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0; ca.flag = flagp(h);
+    return launch_couple(lv.c, ca, N, s);
+  });
 }
 
 }  // extern "C"

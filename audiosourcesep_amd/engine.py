@@ -5,6 +5,8 @@ PyTorch-ROCm is used for storage and streams only: tensors are ``torch.cuda`` fl
 ``libglowk.so``.  No CPU fallback: construction raises if the library is missing or no GPU is present.
 """
 import ctypes
+import os
+import warnings
 
 import numpy as np
 import torch
@@ -13,8 +15,9 @@ from . import _lib
 from .config import GlowConfig
 
 
-def _stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream_ptr(device):
+    """The HIP stream torch currently uses on ``device`` (not on whatever device happens to be current)."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def _ptr(t):
@@ -35,6 +38,13 @@ class GlowEngine:
         self.h = h
         self._finalized = False
         self._max_tiles_cap = None   # tests lower it to exercise the chunk loop on small batches
+        self._fallbacks_seen = 0
+        # the Python mirror never hands back silently wrong numbers and never fails on a checkpoint the split arithmetic cannot
+        # hold: a call that leaves the fp16 range is re-run on the exact fp32 kernels inside the engine (one warning per engine)
+        self.set_range_policy("fallback")
+
+    def _stream(self):
+        return _stream_ptr(self.device)
 
     def close(self):
         if getattr(self, "h", None):
@@ -82,7 +92,7 @@ class GlowEngine:
         """ActNorm data-dependent init on the GPU (flow_tfp_bijectors.py:222-234 driven as flow_glow.py:40-49)."""
         x = self._in(minibatch, self.data_shape)
         _lib.check(self.lib.glowk_actnorm_data_init(self.h, _ptr(x), x.shape[0], int(runtime_order), int(raw_minibatch_quirk),
-                                                    _stream_ptr()))
+                                                    self._stream()))
 
     def actnorm_params(self):
         """{name: ndarray} of every step's ActNorm tensors as the engine currently holds them."""
@@ -95,13 +105,39 @@ class GlowEngine:
         return out
 
     def set_precision(self, mode):
+        """_lib.PREC_F32 (exact), PREC_F16X3 or PREC_F16X2.  The split modes need |hidden activation| < 16 376; what happens
+        beyond that is the range policy's business (default here: re-run the call on the fp32 kernels)."""
         _lib.check(self.lib.glowk_set_precision(self.h, int(mode)))
 
     def get_precision(self):
         return int(self.lib.glowk_get_precision(self.h))
 
-    def reserve(self, n):
-        _lib.check(self.lib.glowk_reserve(self.h, min(int(n), self.max_tiles)))
+    def set_range_policy(self, policy):
+        """"fallback" (default of this class), "error" (raise GlowkRangeError; the C ABI's default) or "ignore" (no
+        synchronisation: poll ``range_status``)."""
+        modes = {"ignore": _lib.RANGE_IGNORE, "error": _lib.RANGE_ERROR, "fallback": _lib.RANGE_FALLBACK}
+        _lib.check(self.lib.glowk_set_range_policy(self.h, modes[policy] if isinstance(policy, str) else int(policy)))
+
+    def range_status(self, sync=True):
+        """-> (tripped, fallbacks): whether the sticky range flag was set since the last look (clears it; waits for the stream)
+        and how many calls were re-run on the fp32 kernels.  ``sync=False`` only reads the counter."""
+        tripped, n = ctypes.c_int(0), ctypes.c_int64(0)
+        _lib.check(self.lib.glowk_range_status(self.h, ctypes.byref(tripped) if sync else None, ctypes.byref(n), self._stream()))
+        return bool(tripped.value), int(n.value)
+
+    def _after_call(self):
+        if self.get_precision() == _lib.PREC_F32:
+            return
+        n = self.range_status(sync=False)[1]
+        if n > self._fallbacks_seen:
+            if self._fallbacks_seen == 0:
+                warnings.warn("glowk: a hidden activation left the fp16 range of the split arithmetic; the call was re-run on the "
+                              "exact fp32 kernels (slower). Consider set_precision(PREC_F32) for this checkpoint.", RuntimeWarning,
+                              stacklevel=3)
+            self._fallbacks_seen = n
+
+    def reserve(self, n, with_grad=False):
+        _lib.check(self.lib.glowk_reserve(self.h, min(int(n), self.grad_max_tiles if with_grad else self.max_tiles), int(with_grad)))
 
     @property
     def max_tiles(self):
@@ -115,14 +151,35 @@ class GlowEngine:
 
     @property
     def grad_max_tiles(self):
-        """Chunk of log_prob_grad: the pass keeps every step's ReLU masks and activations until the backward sweep
-        (~5.5 MB per 64x64 tile at K=32, F=512), so its chunks are 2^24 elements (4096 such tiles, ~22 GB) -- far past
-        the batch size at which the kernels saturate."""
-        c = self.cfg
-        return max(1, min(self.max_tiles, (1 << 24) // (c.H * c.W * c.C)))
+        """Chunk of log_prob_grad.  The pass keeps every step's coupling input, per-tap conv3 outputs (one buffer per pass of
+        the split kernels) and ReLU masks until the backward sweep -- for 64x64, K=32, F=512: ~15 MB per tile in exact fp32,
+        ~23 MB with two partial buffers.  The chunk is the largest batch whose workspace + saves (``glowk_workspace_bytes``,
+        the allocators' own arithmetic) fit a byte budget: min(60 % of the free HBM, GLOWK_GRAD_BUDGET_GB or 64 GiB); kernels
+        saturate long before that."""
+        if not self._finalized:
+            self.finalize()
+        key = (self.get_precision(), self._max_tiles_cap)
+        if getattr(self, "_grad_chunk", (None, 0))[0] == key:
+            return self._grad_chunk[1]
+        budget = min(0.6 * self._free_bytes(), float(os.environ.get("GLOWK_GRAD_BUDGET_GB", "64")) * 2 ** 30)
+        lo, hi = 1, self.max_tiles
+        if self.workspace_bytes(hi, True) > budget:
+            while lo < hi:      # largest n with bytes(n) <= budget (bytes is monotone in n)
+                mid = (lo + hi + 1) // 2
+                if self.workspace_bytes(mid, True) <= budget:
+                    lo = mid
+                else:
+                    hi = mid - 1
+        else:
+            lo = hi
+        self._grad_chunk = (key, lo)
+        return lo
 
-    def workspace_bytes(self, n):
-        return int(self.lib.glowk_workspace_bytes(self.h, int(n)))
+    def _free_bytes(self):
+        return torch.cuda.mem_get_info(self.device)[0]
+
+    def workspace_bytes(self, n, with_grad=False):
+        return int(self.lib.glowk_workspace_bytes(self.h, int(n), int(with_grad)))
 
     def profile_begin(self):
         _lib.check(self.lib.glowk_profile_begin(self.h))
@@ -152,6 +209,10 @@ class GlowEngine:
         return (self.cfg.H, self.cfg.W, self.cfg.C)
 
     # ---- hot path ---------------------------------------------------------------------------------
+    def _compute(self, rc):
+        _lib.check(rc)
+        self._after_call()
+
     def forward(self, x, with_logdet=True):
         x = self._in(x, self.data_shape)
         n = x.shape[0]
@@ -160,8 +221,8 @@ class GlowEngine:
         if n == 0:   # an empty batch is an empty result (TF semantics), not a launch
             return (z, ld) if with_logdet else z
         for a, b in self._chunks(n):   # tiles are independent: a batch beyond max_tiles is a loop over chunks
-            _lib.check(self.lib.glowk_forward(self.h, _ptr(x[a:b]), b - a, _ptr(z[a:b]), _ptr(ld[a:b] if with_logdet else None),
-                                              _stream_ptr()))
+            self._compute(self.lib.glowk_forward(self.h, _ptr(x[a:b]), b - a, _ptr(z[a:b]), _ptr(ld[a:b] if with_logdet else None),
+                                              self._stream()))
         return (z, ld) if with_logdet else z
 
     def inverse(self, z):
@@ -171,7 +232,7 @@ class GlowEngine:
         if n == 0:
             return x
         for a, b in self._chunks(n):
-            _lib.check(self.lib.glowk_inverse(self.h, _ptr(z[a:b]), b - a, _ptr(x[a:b]), _stream_ptr()))
+            self._compute(self.lib.glowk_inverse(self.h, _ptr(z[a:b]), b - a, _ptr(x[a:b]), self._stream()))
         return x
 
     def log_prob(self, x, return_latent=False, out=None):
@@ -182,8 +243,8 @@ class GlowEngine:
         if n == 0:
             return (lp, z) if return_latent else lp
         for a, b in self._chunks(n):
-            _lib.check(self.lib.glowk_log_prob(self.h, _ptr(x[a:b]), b - a, _ptr(lp[a:b]), _ptr(z[a:b] if return_latent else None),
-                                               _stream_ptr()))
+            self._compute(self.lib.glowk_log_prob(self.h, _ptr(x[a:b]), b - a, _ptr(lp[a:b]), _ptr(z[a:b] if return_latent else None),
+                                               self._stream()))
         return (lp, z) if return_latent else lp
 
     def log_prob_grad(self, x):
@@ -193,7 +254,7 @@ class GlowEngine:
         if n == 0:
             return lp, dx
         for a, b in self._chunks(n, self.grad_max_tiles):
-            _lib.check(self.lib.glowk_log_prob_grad(self.h, _ptr(x[a:b]), b - a, _ptr(lp[a:b]), _ptr(dx[a:b]), _stream_ptr()))
+            self._compute(self.lib.glowk_log_prob_grad(self.h, _ptr(x[a:b]), b - a, _ptr(lp[a:b]), _ptr(dx[a:b]), self._stream()))
         return lp, dx
 
     def sample_from_eps(self, eps):
@@ -203,46 +264,46 @@ class GlowEngine:
         if n == 0:
             return x
         for a, b in self._chunks(n):
-            _lib.check(self.lib.glowk_sample(self.h, _ptr(eps[a:b]), b - a, _ptr(x[a:b]), _stream_ptr()))
+            self._compute(self.lib.glowk_sample(self.h, _ptr(eps[a:b]), b - a, _ptr(x[a:b]), self._stream()))
         return x
 
     def prior_log_prob(self, z):
         z = self._in(z, self.cfg.latent_shape())
         lp = self._new(z.shape[0])
         for a, b in self._chunks(z.shape[0]):
-            _lib.check(self.lib.glowk_prior_log_prob(self.h, _ptr(z[a:b]), b - a, _ptr(lp[a:b]), _stream_ptr()))
+            _lib.check(self.lib.glowk_prior_log_prob(self.h, _ptr(z[a:b]), b - a, _ptr(lp[a:b]), self._stream()))
         return lp
 
     # ---- sub-bijectors ----------------------------------------------------------------------------
     def preprocess_forward(self, x):
         x = self._in(x, self.data_shape)
         y, ld = torch.empty_like(x), self._new(x.shape[0])
-        _lib.check(self.lib.glowk_preprocess_forward(self.h, _ptr(x), x.shape[0], _ptr(y), _ptr(ld), _stream_ptr()))
+        _lib.check(self.lib.glowk_preprocess_forward(self.h, _ptr(x), x.shape[0], _ptr(y), _ptr(ld), self._stream()))
         return y, ld
 
     def preprocess_inverse(self, y):
         y = self._in(y, self.data_shape)
         x = torch.empty_like(y)
-        _lib.check(self.lib.glowk_preprocess_inverse(self.h, _ptr(y), y.shape[0], _ptr(x), _stream_ptr()))
+        _lib.check(self.lib.glowk_preprocess_inverse(self.h, _ptr(y), y.shape[0], _ptr(x), self._stream()))
         return x
 
     def step_forward(self, level, step, u):
         u = self._in(u, self.cfg.level_shapes()[level])
         y, ld = torch.empty_like(u), self._new(u.shape[0])
-        _lib.check(self.lib.glowk_step_forward(self.h, level, step, _ptr(u), u.shape[0], _ptr(y), _ptr(ld), _stream_ptr()))
+        self._compute(self.lib.glowk_step_forward(self.h, level, step, _ptr(u), u.shape[0], _ptr(y), _ptr(ld), self._stream()))
         return y, ld
 
     def step_inverse(self, level, step, y):
         y = self._in(y, self.cfg.level_shapes()[level])
         u = torch.empty_like(y)
-        _lib.check(self.lib.glowk_step_inverse(self.h, level, step, _ptr(y), y.shape[0], _ptr(u), _stream_ptr()))
+        self._compute(self.lib.glowk_step_inverse(self.h, level, step, _ptr(y), y.shape[0], _ptr(u), self._stream()))
         return u
 
     def coupling_net(self, level, step, xb):
         h, w, c = self.cfg.level_shapes()[level]
         xb = self._in(xb, (h, w, c // 2))
         log_s, t = torch.empty_like(xb), torch.empty_like(xb)
-        _lib.check(self.lib.glowk_coupling_net(self.h, level, step, _ptr(xb), xb.shape[0], _ptr(log_s), _ptr(t), _stream_ptr()))
+        self._compute(self.lib.glowk_coupling_net(self.h, level, step, _ptr(xb), xb.shape[0], _ptr(log_s), _ptr(t), self._stream()))
         return log_s, t
 
 
@@ -252,7 +313,7 @@ def squeeze(x):
     x = x.contiguous()
     n, H, W, C = x.shape
     y = torch.empty((n, H // 2, W // 2, 4 * C), device=x.device, dtype=torch.float32)
-    _lib.check(lib.glowk_squeeze(_ptr(x), n, H, W, C, _ptr(y), _stream_ptr()))
+    _lib.check(lib.glowk_squeeze(_ptr(x), n, H, W, C, _ptr(y), _stream_ptr(x.device)))
     return y
 
 
@@ -262,5 +323,5 @@ def unsqueeze(y):
     y = y.contiguous()
     n, h, w, c4 = y.shape
     x = torch.empty((n, 2 * h, 2 * w, c4 // 4), device=y.device, dtype=torch.float32)
-    _lib.check(lib.glowk_unsqueeze(_ptr(y), n, h, w, c4, _ptr(x), _stream_ptr()))
+    _lib.check(lib.glowk_unsqueeze(_ptr(y), n, h, w, c4, _ptr(x), _stream_ptr(y.device)))
     return x

@@ -32,16 +32,17 @@ def initial_variables(cfg: GlowConfig, rng):
     for lvl, (h, w, c) in enumerate(cfg.level_shapes()):
         for k in range(cfg.K):
             pre = "b%d/s%d/" % (lvl, k)
-            np_w = np.linalg.qr(rng.standard_normal((c, c)))[0]
-            np_p, np_l, np_u = scipy.linalg.lu(np_w)
-            np_s = np.diag(np_u)
+            q = np.linalg.qr(rng.standard_normal((c, c)))[0]        # flow_tfp_bijectors.py:271-278
+            perm, lower, upper = scipy.linalg.lu(q)
+            diag = np.diag(upper)
             p[pre + "actnorm/log_scale"] = np.zeros(c, np.float32)
             p[pre + "actnorm/shift"] = np.zeros(c, np.float32)
-            p[pre + "inv1x1/P"] = np_p.astype(np.float32)
-            p[pre + "inv1x1/sign_S"] = np.sign(np_s).astype(np.float32)
-            p[pre + "inv1x1/log_S"] = np.log(np.abs(np_s)).astype(np.float32)
-            p[pre + "inv1x1/L"] = np_l.astype(np.float32)
-            p[pre + "inv1x1/U"] = np.triu(np_u, k=1).astype(np.float32)
+            p[pre + "inv1x1/P"] = perm.astype(np.float32)
+            p[pre + "inv1x1/P_inv"] = np.linalg.inv(perm).astype(np.float32)      # :282-284
+            p[pre + "inv1x1/sign_S"] = np.sign(diag).astype(np.float32)
+            p[pre + "inv1x1/log_S"] = np.log(np.abs(diag)).astype(np.float32)
+            p[pre + "inv1x1/L"] = lower.astype(np.float32)
+            p[pre + "inv1x1/U"] = np.triu(upper, k=1).astype(np.float32)
             p[pre + "nn/conv1/kernel"] = _glorot_uniform(rng, (3, 3, c // 2, F))
             p[pre + "nn/conv1/bias"] = np.zeros(F, np.float32)
             p[pre + "nn/conv2/kernel"] = _glorot_uniform(rng, (1, 1, F, F))

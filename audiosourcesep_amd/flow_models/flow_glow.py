@@ -39,7 +39,7 @@ def _step_variable_shapes(c, F):
     ci = c // 2
     return [
         ("actnorm/log_scale", (c,), True), ("actnorm/shift", (c,), True),
-        ("inv1x1/P", (c, c), False), ("inv1x1/sign_S", (c,), False),
+        ("inv1x1/P", (c, c), False), ("inv1x1/P_inv", (c, c), False), ("inv1x1/sign_S", (c,), False),   # flow_tfp_bijectors.py:281-286
         ("inv1x1/L", (c, c), True), ("inv1x1/log_S", (c,), True), ("inv1x1/U", (c, c), True),
         ("nn/conv1/kernel", (3, 3, ci, F), True), ("nn/conv1/bias", (F,), True),
         ("nn/bn1/gamma", (F,), True), ("nn/bn1/beta", (F,), True), ("nn/bn1/mean", (F,), False), ("nn/bn1/var", (F,), False),
@@ -222,7 +222,17 @@ class GlowFlow:
     def state_dict(self):
         return {v.name: v.numpy() for v in self._variables}
 
-    def load_state_dict(self, state):
+    def load_state_dict(self, state, strict=True):
+        """``strict``: every variable must be present and no unknown key may be (like ``tf.train.Checkpoint.restore(...)
+        .assert_consumed()``); the frozen ``inv1x1/P_inv`` alone may be absent -- the engine then uses inv(P), the value the
+        reference initialises it to (flow_tfp_bijectors.py:282-284)."""
+        names = {v.name for v in self._variables}
+        if strict:
+            missing = sorted(n for n in names if n not in state and not n.endswith("inv1x1/P_inv"))
+            unexpected = sorted(k for k in state if k not in names)
+            if missing or unexpected:
+                raise KeyError("load_state_dict: missing %s; unexpected %s" % (missing[:5] + (["..."] if len(missing) > 5 else []),
+                                                                           unexpected[:5] + (["..."] if len(unexpected) > 5 else [])))
         for v in self._variables:
             if v.name in state:
                 v.assign(np.asarray(state[v.name]).reshape(v.shape))

@@ -20,6 +20,9 @@ Extra objects on the line
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -61,27 +64,73 @@ def host_threads():
     return max(1, min(16, n))
 
 
-def cpu_baseline(cfg, params, budget_s=20.0):
-    """Oracle port on the host cores: torch-CPU fp32, one network evaluation per step (deduplicated graph).
-    Bounded sample: one tile is timed first, then as many tiles as fit the time budget (1..16)."""
+def cpu_info():
+    model, phys = "?", set()
+    try:
+        pid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "?":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                phys.add((pid, line.split(":", 1)[1].strip()))
+    except OSError:
+        pass
+    return {"model": model, "physical_cores_visible": len(phys) or None, "logical_cpus_visible": os.cpu_count(),
+            "affinity": len(os.sched_getaffinity(0))}
+
+
+def cpu_baseline(cfg, params, budget_s=24.0):
+    """Oracle port on the host cores: torch-CPU fp32 restatement of the reference graph (oracle/glowref_torch.py; not
+    TensorFlow).  Bounded sample of the same workload: median of three passes each
+    of (a) the deduplicated graph (one network evaluation per step) at the host share of threads -- the headline `value`,
+    (b) the faithful graph (two evaluations per step, as TFP's forward + forward_log_det_jacobian do), (c) one thread."""
     from oracle import glowref_torch as RT
     threads = host_threads()
-    torch.set_num_threads(threads)
     p = RT.to_torch(params, torch.float32)
-    x = torch.from_numpy(synthetic_mel_tiles(128, cfg, seed=4321))
+    x = torch.from_numpy(synthetic_mel_tiles(32, cfg, seed=4321))
+    d = cfg.as_dict()
+
+    def timed(tiles, evals, reps=3):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            RT.log_prob(x[:tiles], p, d, evals_per_step=evals)
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), sum(ts)
+
+    out, spent = {}, 0.0
     with torch.no_grad():
+        torch.set_num_threads(threads)
         t0 = time.perf_counter()
-        RT.log_prob(x[:1], p, cfg.as_dict())          # also warms up primitive creation
+        RT.log_prob(x[:1], p, d)                      # also warms up primitive creation
         t1 = time.perf_counter() - t0
-        tiles = int(max(1, min(128, budget_s / max(t1, 1e-3))))
+        share = budget_s / 3.0 / 3.0                  # three variants x three passes
+        tiles = int(max(1, min(32, share / max(t1, 1e-3))))
+        med, tot = timed(tiles, 1)
+        spent += tot
+        out = {"value": tiles / med, "unit": "passes/s", "cores": threads, "kind": "port",
+               "sample": "median of 3 passes over %d tiles of the same config (%.1f s of CPU work in all three variants), torch-CPU "
+                         "fp32 restatement of the reference graph (oracle/glowref_torch.py; NOT TensorFlow), deduplicated graph "
+                         "(one network evaluation per step)" % (tiles, 0.0)}
+        tf = max(1, tiles // 2)
+        med, tot = timed(tf, 2)
+        spent += tot
+        out["faithful"] = {"value": tf / med, "unit": "passes/s", "cores": threads, "tiles": tf,
+                           "note": "coupling network evaluated twice per step, as TFP's forward + forward_log_det_jacobian do"}
+        torch.set_num_threads(1)
         t0 = time.perf_counter()
-        RT.log_prob(x[:tiles], p, cfg.as_dict())
-        dt = time.perf_counter() - t0
-    return {
-        "value": tiles / dt, "unit": "passes/s", "cores": threads, "kind": "port",
-        "sample": "%d tiles x 1 pass of the same config, torch-CPU fp32 restatement of the reference graph "
-                  "(oracle/glowref_torch.py; not TensorFlow), %.1f s after a %.1f s one-tile warm-up" % (tiles, dt, t1),
-    }
+        RT.log_prob(x[:1], p, d)
+        t1 = time.perf_counter() - t0
+        t1n = int(max(1, min(4, share / max(t1, 1e-3))))
+        med, tot = timed(t1n, 1)
+        spent += tot
+        out["threads_1"] = {"value": t1n / med, "unit": "passes/s", "cores": 1, "tiles": t1n, "note": "deduplicated graph, one thread"}
+        torch.set_num_threads(threads)
+    out["sample"] = out["sample"].replace("(0.0 s", "(%.1f s" % spent)
+    out["host"] = cpu_info()
+    return out
 
 
 def secondary_workload(args, cfg, eng, params, rank, world, local_rank, dist):
@@ -141,6 +190,35 @@ def secondary_workload(args, cfg, eng, params, rank, world, local_rank, dist):
         dist.destroy_process_group()
 
 
+def self_launch(args):
+    """``python bench.py --gpus N`` outside torch.distributed.run: start the N ranks ourselves -- BEFORE anything in this
+    process touches the GPU (nothing has: importing torch does not) -- relay their output and exit code.  One process per
+    GPU, rendezvous on 127.0.0.1 (train_glow.py:48-60 is the reference's MirroredStrategy counterpart)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def file_commit(rel):
+    """Commit that last touched a committed profile file (None outside a git checkout, e.g. on the GPU box's snapshot)."""
+    try:
+        return subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", rel], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,15 +232,18 @@ def main():
                     help="f16x3: error-compensated fp16 split on the fp16 MFMA (fp32-class accuracy, demonstrated in the line); "
                          "f32: exact fp32-input MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline sample")
+    ap.add_argument("--no-other-shapes", action="store_true", help="skip the config-A line inside the N=1 default run")
+    ap.add_argument("--cpu-budget", type=float, default=24.0, help="seconds of CPU work for the cpu_baseline sample")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(self_launch(args))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%s: launch with --nproc-per-node %d" % (args.gpus, os.environ["WORLD_SIZE"], args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     # GLOWK_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend -- exercises the multi-process control flow (sharding,
     # barriers, max-over-ranks timing, rank-0 JSON) on a one-GPU box; the numbers it prints mean nothing
     rehearsal = os.environ.get("GLOWK_BENCH_REHEARSAL") == "1"
@@ -185,136 +266,138 @@ def main():
     cfg = {"A": CONFIG_A, "B": CONFIG_B, "YAML": CONFIG_YAML}[args.config]
     from audiosourcesep_amd import _lib
     from audiosourcesep_amd.synthetic import calibrated_engine
-    # synthetic weights + ActNorm data-dependent init on a minibatch of the benchmark's own batch size, so that
-    # every k_net launch of the process has the same grid (rocprof's per-kernel average == the timed one)
-    eng, params = calibrated_engine(cfg, device=local_rank, init_tiles=args.batch)
+    from audiosourcesep_amd.distributed import sharded_log_prob
     PREC = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3, "f16x2": _lib.PREC_F16X2}
-    eng.set_precision(PREC[args.precision])
     n = args.batch
-    eng.reserve(n)
+
     if args.workload != "log_prob":
+        eng, params = calibrated_engine(cfg, device=local_rank, init_tiles=n)
+        eng.set_precision(PREC[args.precision])
+        eng.reserve(n, with_grad=True)
         secondary_workload(args, cfg, eng, params, rank, world, local_rank, dist)
         return
-    x = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=1234 + rank)).cuda()   # resident in HBM before timing
-    lp = torch.empty(n, device="cuda", dtype=torch.float32)
-    total = torch.zeros(1, device="cuda", dtype=torch.float64)
 
-    from audiosourcesep_amd.distributed import sharded_log_prob
+    def measure(cfg, precision, steps, warmup, with_others):
+        """One engine, one resident batch; K timed steps of the hot path in `precision`, then (with_others) the other two
+        arithmetics on the same batch.  Every call runs under the C ABI's default range policy (GLOWK_RANGE_ERROR): a hidden
+        activation outside the fp16 range of the split kernels would abort the benchmark instead of timing NaNs."""
+        # synthetic weights + ActNorm data-dependent init on a minibatch of the benchmark's own batch size, so that
+        # every k_net launch of the process has the same grid (rocprof's per-kernel average == the timed one)
+        eng, params = calibrated_engine(cfg, device=local_rank, init_tiles=n)
+        eng.set_range_policy("error")
+        eng.set_precision(PREC[precision])
+        eng.reserve(n)
+        x = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=1234 + rank)).cuda()   # resident in HBM before timing
+        lp = torch.empty(n, device="cuda", dtype=torch.float32)
+        total = torch.zeros(1, device="cuda", dtype=torch.float64)
 
-    def step():
-        # local shard on this GPU, then ONE all-reduce of the fp64 summed log-likelihood (RCCL over xGMI)
-        _, tot = sharded_log_prob(lambda xx: eng.log_prob(xx, out=lp), x)
-        total.copy_(tot)
+        def step():
+            # local shard on this GPU, then ONE all-reduce of the fp64 summed log-likelihood (RCCL over xGMI)
+            _, tot = sharded_log_prob(lambda xx: eng.log_prob(xx, out=lp), x)
+            total.copy_(tot)
 
-    def timed(k_steps):
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        eng.profile_begin()
-        t0 = time.perf_counter()
-        for _ in range(k_steps):
+        def timed(k_steps):
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            eng.profile_begin()
+            t0 = time.perf_counter()
+            for _ in range(k_steps):
+                step()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            pr = eng.profile_end()
+            if dist is not None:
+                t = torch.tensor([el], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            return el, pr
+
+        for _ in range(warmup):
             step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        pr = eng.profile_end()
-        if dist is not None:
-            t = torch.tensor([el], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el, pr
+        res = {"eng": eng, "params": params, "x": x}
+        res["main"] = timed(steps)
+        assert torch.isfinite(total).all(), "non-finite log-likelihood"
+        assert eng.range_status() == (False, 0), "the range guard fired"
+        res["lp_main"] = lp.clone()
+        if with_others:
+            # the other arithmetic on the same batch: exact fp32 beside the split path (or vice versa), same run
+            other = "f32" if precision != "f32" else "f16x3"
+            steps_o = max(2, steps // 2)
+            eng.set_precision(PREC[other])
+            step()
+            res["other"] = (other, steps_o) + timed(steps_o)
+            lp_other = lp.clone()
+            res["rel_diff"] = float(((res["lp_main"] - lp_other).abs() / lp_other.abs()).max().item())
+            # the throughput mode (two split terms per product: inside the 1e-4 bar, not fp32-class), same batch, same run
+            if precision == "f16x3":
+                eng.set_precision(PREC["f16x2"])
+                step()
+                el2, pr2 = timed(steps_o)
+                res["two"] = (el2, pr2, float(((lp - lp_other).abs() / lp_other.abs()).max().item()))
+            eng.set_precision(PREC[precision])
+        return res
 
-    for _ in range(args.warmup):
-        step()
-    elapsed, prof = timed(args.steps)
-    assert torch.isfinite(total).all(), "non-finite log-likelihood"
-    lp_main = lp.clone()
-    # the other arithmetic on the same batch: exact fp32 beside the split path (or vice versa), same run
-    other = "f32" if args.precision != "f32" else "f16x3"
-    eng.set_precision(PREC[other])
-    step()
-    elapsed_o, prof_o = timed(max(2, args.steps // 2))
-    steps_o = max(2, args.steps // 2)
-    lp_other = lp.clone()
-    rel_diff = float(((lp_main - lp_other).abs() / lp_other.abs()).max().item())
-    # the throughput mode (two split terms per product: inside the 1e-4 bar, not fp32-class), same batch, same run
-    two = None
-    if args.precision == "f16x3":
-        eng.set_precision(PREC["f16x2"])
-        step()
-        elapsed_2, prof_2 = timed(steps_o)
-        two = (elapsed_2, prof_2, float(((lp - lp_other).abs() / lp_other.abs()).max().item()))
-    eng.set_precision(PREC[args.precision])
-    # accuracy of the headline arithmetic against the fp64 CPU oracle on two tiles of the same batch (rank 0)
-    acc_vs_oracle = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # (N > 1: the other ranks would idle at the barrier meanwhile)
-        from oracle import glowref as R
-        xs = x[:2].cpu().numpy().astype(np.float64)
-        ref = R.log_prob(xs, R.cast_params(params, np.float64), cfg.as_dict())
-        acc_vs_oracle = float(np.max(np.abs(lp_main[:2].cpu().numpy() - ref) / np.abs(ref)))
-
-    if rank == 0:
-        passes = n * world * args.steps
-        value = passes / elapsed
+    def roofline_obj(cfg, precision, pr):
         h0, w0, c0 = cfg.level_shapes()[0]
         flop_launch = net_flop_per_pixel(c0, cfg.F) * n * h0 * w0
+        ms0, launches0 = pr[0]
+        avg_ms = ms0 / max(launches0, 1)
+        achieved = flop_launch / (avg_ms * 1e-3) / 1e12 if launches0 else None
+        if precision == "f32":
+            kernel, peak = "k_net_f32<CI=%d,NF=%d> (level 0)" % (c0 // 2, cfg.F // 32), PEAK_F32_MFMA_TFLOPS
+            note = "fp32-input MFMA peak"
+        elif precision == "f16x2":
+            kernel, peak = "k_net_h3s<CI=%d,NF=%d,two-term> (level 0)" % (c0 // 2, cfg.F // 32), PEAK_F16_MFMA_TFLOPS / 2.0
+            note = "fp16 dense MFMA peak / 2 (two fp16 MFMAs per product)"
+        else:
+            kernel, peak = "k_net_h3s<CI=%d,NF=%d> (level 0)" % (c0 // 2, cfg.F // 32), PEAK_F16_MFMA_TFLOPS / 3.0
+            note = "fp16 dense MFMA peak / 3 (three fp16 MFMAs per fp32-equivalent product)"
+        # HBM bytes per launch and MFMA-pipe busy fraction come from separate rocprofv3 --pmc passes of this same command
+        # (scripts/pmc_traffic.py, scripts/pmc_mfma.py), committed under profiles/: NOT measured by this process -- the
+        # `counters_source` object says which file and commit they were read from
+        traffic = mfma_busy = None
+        src = {}
+        if cfg is CONFIG_B and n == 1024:
+            tpath, upath = "profiles/roofline_traffic.json", "profiles/mfma_utilisation.json"
+            try:
+                tj = json.load(open(os.path.join(ROOT, tpath)))
+                key = {"f32": "k_net_f32", "f16x3": "k_net_h3s", "f16x2": "k_net_h3s_two_term"}[precision]
+                traffic = tj["hbm_bytes_per_level0_launch"][key]
+                src["traffic"] = {"file": tpath, "commit": file_commit(tpath), "build": tj.get("build"), "measured_in_this_run": False}
+            except Exception:
+                traffic = None
+            try:
+                uj = json.load(open(os.path.join(ROOT, upath)))
+                mfma_busy = uj["level0"][{"f32": "k_net_f32", "f16x3": "k_net_h3s", "f16x2": "k_net_h3s_two_term"}[precision]]["mfma_utilisation"]
+                src["mfma_busy_pmc"] = {"file": upath, "commit": file_commit(upath), "build": uj.get("build"), "measured_in_this_run": False}
+            except Exception:
+                mfma_busy = None
+        # what a bare MFMA loop with this kernel's operand pattern sustains on this chip under its power management
+        # (scripts/mfma_shape.hip, random data): 1 697 TFLOP/s for 16x16x32 f16 (/3), 150.8 TFLOP/s for 32x32x2 f32
+        sustained = SUSTAINED_F32_MFMA_TFLOPS if precision == "f32" else SUSTAINED_F16_MFMA_TFLOPS / (2.0 if precision == "f16x2" else 3.0)
+        return {"kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "peak_note": note, "unit": "TFLOP/s",
+                "frac": (achieved / peak) if achieved else None, "traffic": traffic, "mfma_busy_pmc": mfma_busy, "counters_source": src,
+                "avg_launch_ms": avg_ms, "launches": launches0, "flop_per_launch": flop_launch, "sustained_mfma_rate_measured": sustained,
+                "frac_of_sustained": (achieved / sustained) if achieved else None}
 
-        def roofline_obj(precision, pr):
-            ms0, launches0 = pr[0]
-            avg_ms = ms0 / max(launches0, 1)
-            achieved = flop_launch / (avg_ms * 1e-3) / 1e12 if launches0 else None
-            if precision == "f32":
-                kernel, peak = "k_net_f32<CI=%d,NF=%d> (level 0)" % (c0 // 2, cfg.F // 32), PEAK_F32_MFMA_TFLOPS
-                note = "fp32-input MFMA peak"
-            elif precision == "f16x2":
-                kernel, peak = "k_net_h3s<CI=%d,NF=%d,two-term> (level 0)" % (c0 // 2, cfg.F // 32), PEAK_F16_MFMA_TFLOPS / 2.0
-                note = "fp16 dense MFMA peak / 2 (two fp16 MFMAs per product)"
-            else:
-                kernel, peak = "k_net_h3s<CI=%d,NF=%d> (level 0)" % (c0 // 2, cfg.F // 32), PEAK_F16_MFMA_TFLOPS / 3.0
-                note = "fp16 dense MFMA peak / 3 (three fp16 MFMAs per fp32-equivalent product)"
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    key = "k_net_level0_hbm_bytes_per_launch_per_tile" if precision == "f32" else "k_net_h3_level0_hbm_bytes_per_launch_per_tile"
-                    t = json.load(open(tpath)).get(key)
-                    traffic = t * n if t is not None else None
-                except Exception:
-                    traffic = None
-            # MFMA-pipe busy fraction of the same kernel from PMC counters (profiles/mfma_utilisation.json, scripts/pmc_mfma.py)
-            mfma_busy = None
-            upath = os.path.join(ROOT, "profiles", "mfma_utilisation.json")
-            if os.path.exists(upath) and args.config == "B":
-                try:
-                    kk = {"f32": "void k_net_f32<2, 36, 16, 0>(NetArgs)", "f16x3": "void k_net_h3s<2, 36, 16, 0, 2, false>(NetArgs)",
-                          "f16x2": "void k_net_h3s<2, 36, 16, 3, 2, false>(NetArgs)"}[precision]
-                    mfma_busy = json.load(open(upath))["kernels"][kk]["mfma_utilisation"]
-                except Exception:
-                    mfma_busy = None
-            # what a bare MFMA loop with this kernel's operand pattern sustains on this chip under its power management
-            # (scripts/mfma_shape.hip, random data): 1 697 TFLOP/s for 16x16x32 f16 (/3), 150.8 TFLOP/s for 32x32x2 f32
-            sustained = SUSTAINED_F32_MFMA_TFLOPS if precision == "f32" else SUSTAINED_F16_MFMA_TFLOPS / (2.0 if precision == "f16x2" else 3.0)
-            return {"kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "peak_note": note, "unit": "TFLOP/s",
-                    "frac": (achieved / peak) if achieved else None, "traffic": traffic, "mfma_busy_pmc": mfma_busy, "avg_launch_ms": avg_ms,
-                    "launches": launches0, "flop_per_launch": flop_launch, "sustained_mfma_rate_measured": sustained,
-                    "frac_of_sustained": (achieved / sustained) if achieved else None}
+    dtype_note = {"f32": "fp32 operands on v_mfma_f32_32x32x2_f32, fp32 accumulate",
+                  "f16x3": "fp32 operands split into fp16 hi + lo, 3 fp16 MFMAs per product, fp32 accumulate",
+                  "f16x2": "weights split into fp16 hi + lo, activations rounded to fp16, 2 fp16 MFMAs per product, fp32 accumulate"}
 
-        passes = n * world * args.steps
-        value = passes / elapsed
-        value_o = n * world * steps_o / elapsed_o
-        net_ms_total = sum(m for m, _ in prof)
-        dtype_name = {"f32": "f32", "f16x3": "f16x3", "f16x2": "f16x2"}
-        dtype_note = {"f32": "fp32 operands on v_mfma_f32_32x32x2_f32, fp32 accumulate",
-                      "f16x3": "fp32 operands split into fp16 hi + lo, 3 fp16 MFMAs per product, fp32 accumulate",
-                      "f16x2": "weights split into fp16 hi + lo, activations rounded to fp16, 2 fp16 MFMAs per product, fp32 accumulate"}
+    def line(cfg, precision, res, steps, warmup, full):
+        elapsed, prof = res["main"]
+        value = n * world * steps / elapsed
         out = {
-            "metric": baseline_metric() if args.config == "B" else "Glow fwd+logdet passes/sec (config %s)" % args.config,
-            "value": value, "unit": "passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": dtype_name[args.precision], "dtype_note": dtype_note[args.precision],
+            "metric": baseline_metric() if cfg is CONFIG_B else "Glow fwd+logdet passes/sec on %dx%dx%d mel tiles (K=%d,L=%d)" % (cfg.H, cfg.W, cfg.C, cfg.K, cfg.L),
+            "value": value, "unit": "passes/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": precision, "dtype_note": dtype_note[precision],
+            "range_guard": "GLOWK_RANGE_ERROR on every call (a hidden activation beyond the fp16 range aborts the run); not tripped",
             "data": "synthetic",
             "config": {"workload": "Glow log_prob, %dx%dx%d mel tiles, L=%d K=%d n_filters=%d, %d tiles/GPU/step"
                                    % (cfg.H, cfg.W, cfg.C, cfg.L, cfg.K, cfg.F, n),
@@ -322,22 +405,53 @@ def main():
             "gflop_per_pass": cfg.flop_per_tile() / 1e9,
             "whole_path_tflops_fp32_equivalent": value / world * cfg.flop_per_tile() / 1e12,
             "hbm_frac_activations": value / world * cfg.act_bytes_per_tile() / 1e9 / PEAK_HBM_GBS,
-            "k_net_share_of_step_time": net_ms_total * 1e-3 / elapsed,
-            "accuracy": {"max_rel_err_log_prob_vs_fp64_oracle_2_tiles": acc_vs_oracle,
-                         "max_rel_diff_log_prob_%s_vs_%s_%d_tiles" % (args.precision, other, n): rel_diff,
-                         "north_star_bar": 1e-4},
-            "roofline": roofline_obj(args.precision, prof),
-            ("exact_fp32" if other == "f32" else "split_fp16"): {
-                "value": value_o, "unit": "passes/s", "steps": steps_o, "ms_per_step": elapsed_o / steps_o * 1e3,
-                "dtype": dtype_name[other], "roofline": roofline_obj(other, prof_o)},
+            "k_net_share_of_step_time": sum(m for m, _ in prof) * 1e-3 / elapsed,
+            "roofline": roofline_obj(cfg, precision, prof),
         }
-        if two is not None:
+        if "other" in res:
+            other, steps_o, elapsed_o, prof_o = res["other"]
+            out["accuracy"] = {"max_rel_diff_log_prob_%s_vs_%s_%d_tiles" % (precision, other, n): res["rel_diff"], "north_star_bar": 1e-4}
+            out["exact_fp32" if other == "f32" else "split_fp16"] = {
+                "value": n * world * steps_o / elapsed_o, "unit": "passes/s", "steps": steps_o, "ms_per_step": elapsed_o / steps_o * 1e3,
+                "dtype": other, "roofline": roofline_obj(cfg, other, prof_o) if full else None}
+        if "two" in res:
+            el2, pr2, d2 = res["two"]
+            steps_o = res["other"][1]
             out["two_term_split_fp16"] = {
-                "value": n * world * steps_o / two[0], "unit": "passes/s", "steps": steps_o, "ms_per_step": two[0] / steps_o * 1e3,
-                "dtype": "f16x2", "dtype_note": dtype_note["f16x2"], "max_rel_diff_log_prob_vs_f32_%d_tiles" % n: two[2],
-                "roofline": roofline_obj("f16x2", two[1])}
+                "value": n * world * steps_o / el2, "unit": "passes/s", "steps": steps_o, "ms_per_step": el2 / steps_o * 1e3,
+                "dtype": "f16x2", "dtype_note": dtype_note["f16x2"], "max_rel_diff_log_prob_vs_f32_%d_tiles" % n: d2,
+                "roofline": roofline_obj(cfg, "f16x2", pr2) if full else None}
+        return out
+
+    res = measure(cfg, args.precision, args.steps, args.warmup, True)
+    out = line(cfg, args.precision, res, args.steps, args.warmup, True) if rank == 0 else None
+    # accuracy of the headline arithmetic against the fp64 CPU oracle on two tiles of the same batch (rank 0)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # (N > 1: the other ranks would idle at the barrier meanwhile)
+        from oracle import glowref as R
+        xs = res["x"][:2].cpu().numpy().astype(np.float64)
+        ref = R.log_prob(xs, R.cast_params(res["params"], np.float64), cfg.as_dict())
+        out["accuracy"]["max_rel_err_log_prob_vs_fp64_oracle_2_tiles"] = float(np.max(np.abs(res["lp_main"][:2].cpu().numpy() - ref) / np.abs(ref)))
+    params_main = res["params"]
+    res["eng"].close()
+    del res
+    torch.cuda.empty_cache()
+    # the other north-star shape (32x32x1, K=16, L=2: BASELINE.json configs[1]) in the same run, as a sub-object of the ONE line
+    if world == 1 and cfg is CONFIG_B and not args.no_other_shapes:
+        ra = measure(CONFIG_A, args.precision, args.steps, args.warmup, True)
+        la = line(CONFIG_A, args.precision, ra, args.steps, args.warmup, False)
+        out["config_A_32x32_K16_L2"] = {k: la[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "gflop_per_pass",
+                                                         "whole_path_tflops_fp32_equivalent", "accuracy", "exact_fp32", "two_term_split_fp16")
+                                        if k in la}
+        for k in ("exact_fp32", "two_term_split_fp16"):
+            if k in out["config_A_32x32_K16_L2"]:
+                out["config_A_32x32_K16_L2"][k].pop("roofline", None)
+        out["config_A_32x32_K16_L2"]["roofline"] = {k: la["roofline"][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "flop_per_launch")}
+        ra["eng"].close()
+        del ra
+    if rank == 0:
+        out["git_head"] = git_head()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, params, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(cfg, params_main, args.cpu_budget)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

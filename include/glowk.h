@@ -10,8 +10,10 @@
  *   - every tensor is NHWC, float32, contiguous; "dev" pointers are device (HBM) addresses owned by the
  *     caller (e.g. torch storages), "host" pointers are ordinary host memory;
  *   - every compute call is asynchronous on the hipStream_t passed as `stream` (void*, 0 = null stream);
- *   - return value: 0 = OK, non-zero = error; glowk_last_error() returns a thread-local message;
- *   - one handle per device; a handle is not thread safe; the engine owns packed weights + workspace.
+ *   - return value: 0 = OK, non-zero = error (enum glowk_status); glowk_last_error() returns a thread-local message;
+ *   - one handle per device; a handle is not thread safe; the engine owns packed weights + workspace;
+ *   - every entry point that touches the GPU selects the handle's device for the duration of the call and restores the
+ *     caller's current device before returning.
  *   - `level` counts blocks from 0 (glowBlock1 = 0); `step` is the creation index k of glowStep_k
  *     (flow_glow.py:44-49).  The forward pass applies steps K-1 ... 0 (tfb.Chain order, :51-52).
  */
@@ -25,12 +27,12 @@
 extern "C" {
 #endif
 
-#define GLOWK_VERSION 100
+#define GLOWK_VERSION 200
 
 /* Arguments of build_glow (flow_builder.py:60-61) + SpecPreprocessing kwargs (flow_tfp_bijectors.py:365). */
 typedef struct glowk_config {
   int32_t H, W, C;     /* data_shape */
-  int32_t L, K, F;     /* L in {2,3,4}; K steps per block; F = n_filters (multiple of 128, <= 512) */
+  int32_t L, K, F;     /* L in {2,3,4}; K steps per block; F = n_filters in {128, 256, 384, 512} (glowk_create rejects others) */
   int32_t learntop;    /* 1: learnable diagonal Gaussian prior (flow_builder.py:131-141), 0: N(0,1) (:142-144) */
   int32_t use_logit;   /* SpecPreprocessing(use_logit=...) */
   float minval, maxval, alpha;
@@ -62,7 +64,9 @@ enum glowk_tensor_id {
   GLOWK_BN2_VAR = 18,
   GLOWK_CONV3_KERNEL = 19,     /* [3,3,F,c]                        :68-70 */
   GLOWK_CONV3_BIAS = 20,       /* [c] */
-  GLOWK_NUM_STEP_TENSORS = 21,
+  GLOWK_INV1X1_P_INV = 21,     /* [c,c]        P_inv, the stored inverse of P that _inverse multiplies by  :282-284,313.  Left unset
+                                  (all zeros) the engine uses inv(P), which is what the reference initialises it to. */
+  GLOWK_NUM_STEP_TENSORS = 22,
   /* prior (level = -1, step = 0), flow_builder.py:131-139 */
   GLOWK_PRIOR_LOC = 100,       /* [H/2^L, W/2^L, C*4^L] */
   GLOWK_PRIOR_LOG_SCALE = 101  /* same shape: log of scale_diag (TransformedVariable(.., Exp())) */
@@ -81,6 +85,26 @@ enum glowk_precision {
                              (inside the 1e-4 bar, no longer fp32-class); log_prob_grad runs the F16X3 kernels in this mode,
                              and so do shapes without a two-term instance */
 };
+
+enum glowk_status {
+  GLOWK_OK = 0,
+  GLOWK_ERR = 1,         /* bad argument / unsupported shape / HIP error: see glowk_last_error() */
+  GLOWK_ERR_RANGE = 2    /* a split-precision call left the fp16 range (see glowk_range_policy); outputs are not usable */
+};
+
+/* Range guard of the split arithmetics (F16X3 / F16X2).  They need |hidden activation| * 4 < 65504; beyond that the fp16
+ * split produces inf - inf, every network output of the pixel turns non-finite, and the coupling / gradient kernels that
+ * consume those outputs raise a sticky per-handle flag on the device (no cost in the MFMA kernels).  What a compute call
+ * (forward, inverse, log_prob, log_prob_grad, sample, step_*, coupling_net) does with the flag:
+ *   GLOWK_RANGE_ERROR (default)  after its launches the call waits for the stream, reads the flag and, if set, clears it and
+ *                                returns GLOWK_ERR_RANGE -- the reference's callers assert on NaN the same way
+ *                                (run_basis_sep.py:183-191, train_glow.py:115-118);
+ *   GLOWK_RANGE_FALLBACK         same check, but the call is re-run inside the engine on the exact fp32 kernels and returns
+ *                                that result (0); glowk_range_status counts the re-runs;
+ *   GLOWK_RANGE_IGNORE           no wait, no read: calls stay fully asynchronous (hipGraph capture); the caller polls
+ *                                glowk_range_status.
+ * Calls in GLOWK_PREC_F32 never check: there a non-finite result is the reference's own result. */
+enum glowk_range_policy { GLOWK_RANGE_IGNORE = 0, GLOWK_RANGE_ERROR = 1, GLOWK_RANGE_FALLBACK = 2 };
 
 int glowk_version(void);
 const char* glowk_last_error(void);
@@ -114,10 +138,17 @@ int glowk_finalize_weights(glowk_handle* h);
 int glowk_actnorm_data_init(glowk_handle* h, const float* x_dev, int N, int runtime_order, int raw_minibatch_quirk, void* stream);
 int glowk_set_precision(glowk_handle* h, int precision);
 int glowk_get_precision(const glowk_handle* h);
-/* workspace the engine needs for batch N (bytes); glowk_reserve allocates it up front so that no
- * compute call allocates (required before hipGraph capture) */
-size_t glowk_workspace_bytes(const glowk_handle* h, int N);
-int glowk_reserve(glowk_handle* h, int N);
+int glowk_set_range_policy(glowk_handle* h, int policy);
+int glowk_get_range_policy(const glowk_handle* h);
+/* waits for `stream`, reports whether the sticky range flag is set (and clears it) and how many calls were re-run on the
+ * fp32 kernels so far; either output may be NULL */
+int glowk_range_status(glowk_handle* h, int* tripped, int64_t* fallbacks, void* stream);
+/* device memory (bytes) the engine allocates for batches up to N: the forward/inverse workspace, plus -- with_grad != 0 --
+ * the per-step saves and gradient scratch of glowk_log_prob_grad in the handle's current precision.  glowk_reserve allocates
+ * exactly that up front, so that no later compute call of that kind with that batch size (or a smaller one in the same
+ * launch regime) allocates or synchronises the device (required before hipGraph capture).  Buffers only ever grow. */
+size_t glowk_workspace_bytes(const glowk_handle* h, int N, int with_grad);
+int glowk_reserve(glowk_handle* h, int N, int with_grad);
 /* the largest batch ONE call accepts (2^28 elements / (H*W*C): indices within a call are 32-bit); every batch entry point
  * rejects a larger N with GLOWK_ERR.  Tiles are independent, so a caller with more tiles loops over chunks
  * (audiosourcesep_amd/engine.py does). */

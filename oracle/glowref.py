@@ -30,7 +30,7 @@ import numpy as np
 
 TENSORS_STEP = (
     "actnorm/log_scale", "actnorm/shift",
-    "inv1x1/P", "inv1x1/sign_S", "inv1x1/L", "inv1x1/log_S", "inv1x1/U",
+    "inv1x1/P", "inv1x1/sign_S", "inv1x1/L", "inv1x1/log_S", "inv1x1/U",   # (+ optional "inv1x1/P_inv", :282-284)
     "nn/conv1/kernel", "nn/conv1/bias",
     "nn/bn1/gamma", "nn/bn1/beta", "nn/bn1/mean", "nn/bn1/var",
     "nn/conv2/kernel", "nn/conv2/bias",
@@ -181,14 +181,14 @@ def inv1x1_weight(P, L, U, sign_S, log_S):
     return P @ (Lm @ Um)
 
 
-def inv1x1_weight_inv(P, L, U, sign_S, log_S):
-    """:309-315 -- W^-1 = U^-1 L^-1 P^-1 (P_inv is inv(P), :282-284)."""
+def inv1x1_weight_inv(P, L, U, sign_S, log_S, P_inv=None):
+    """:309-315 -- W^-1 = U^-1 L^-1 P_inv; P_inv is the stored variable, initialised to inv(P) (:282-284)."""
     c = P.shape[0]
     dt = P.dtype
     l_mask = np.tril(np.ones((c, c), dtype=dt), -1)
     Lm = L * l_mask + np.eye(c, dtype=dt)
     Um = U * l_mask.T + np.diag(sign_S * np.exp(log_S))
-    return np.linalg.inv(Um) @ (np.linalg.inv(Lm) @ np.linalg.inv(P))
+    return np.linalg.inv(Um) @ (np.linalg.inv(Lm) @ (np.linalg.inv(P) if P_inv is None else P_inv))
 
 
 def inv1x1_forward(x, W):
@@ -285,7 +285,7 @@ def step_inverse(y, p, pre, cfg, nn_override=None):
     """Chain.inverse: coupling^-1, then inv1x1^-1, then actnorm^-1."""
     v = coupling_inverse(y, _step_nn(p, pre, cfg, nn_override))
     Winv = inv1x1_weight_inv(p[pre + "inv1x1/P"], p[pre + "inv1x1/L"], p[pre + "inv1x1/U"],
-                             p[pre + "inv1x1/sign_S"], p[pre + "inv1x1/log_S"])
+                             p[pre + "inv1x1/sign_S"], p[pre + "inv1x1/log_S"], p.get(pre + "inv1x1/P_inv"))
     a = v @ Winv
     return actnorm_inverse(a, p[pre + "actnorm/log_scale"], p[pre + "actnorm/shift"])
 

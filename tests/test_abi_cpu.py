@@ -30,7 +30,8 @@ def test_every_declared_symbol_is_exported_and_bound(lib, repo_root):
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.glowk_version() == 100
+    text = open(os.path.join(repo_root, "include", "glowk.h")).read()
+    assert lib.glowk_version() == int(re.search(r"#define GLOWK_VERSION (\d+)", text).group(1))
 
 
 def test_config_struct_matches_header(repo_root):
@@ -94,7 +95,7 @@ def test_create_validates_like_build_glow(lib):
     assert lib.glowk_set_tensor(h, 0, 7, 4, a.ctypes.data_as(_lib._fp), 16) != 0   # no such step
     # compute before finalize is refused (and never silently falls back)
     assert lib.glowk_log_prob(h, None, 1, None, None, None) != 0
-    assert lib.glowk_workspace_bytes(h, 4) > 0
+    assert lib.glowk_workspace_bytes(h, 4, 0) > 0
     assert lib.glowk_destroy(h) == 0
 
 
@@ -127,8 +128,16 @@ def test_batch_chunking_host_logic():
         def glowk_max_tiles(self, h):
             return 10
 
+        def glowk_get_precision(self, h):
+            return 0
+
+        def glowk_workspace_bytes(self, h, n, with_grad):
+            return n * (3000 if with_grad else 1000)
+
     e = GlowEngine.__new__(GlowEngine)
     e.lib, e.h, e._max_tiles_cap, e.cfg = FakeLib(), None, None, GlowConfig(H=64, W=64, C=1, L=3, K=2, F=128)
+    e._finalized = True
+    e._free_bytes = lambda: 10 ** 12
     assert e.max_tiles == 10 and e._chunks(0) == [] and e._chunks(10) == [(0, 10)]
     assert e._chunks(25) == [(0, 10), (10, 20), (20, 25)]
     e._max_tiles_cap = 3
@@ -136,3 +145,10 @@ def test_batch_chunking_host_logic():
     assert e.grad_max_tiles == 3                      # never above max_tiles
     e._max_tiles_cap = None
     assert e.grad_max_tiles == 10
+    # the gradient chunk is the largest batch whose workspace + saves fit 60 % of the free memory
+    e._free_bytes = lambda: 20000          # budget 12 000 bytes at 3 000 per tile
+    e._grad_chunk = (None, 0)
+    assert e.grad_max_tiles == 4
+    e._free_bytes = lambda: 100            # not even one tile fits: chunks of one, the allocation itself will say so
+    e._grad_chunk = (None, 0)
+    assert e.grad_max_tiles == 1

@@ -69,7 +69,17 @@ def test_build_glow_matches_reference_construction(L):
     flow = flow_builder.build_glow(mb, shape, L=L, K=2, n_filters=128, learntop=True, l2_reg=None,
                                    mirrored_strategy=None, seed=11, **MEL)
     names = [v.name for v in flow.variables]
-    assert len(names) == L * 2 * 21 + 2 and len(flow.trainable_variables) == L * 2 * 15 + 2
+    assert len(names) == L * 2 * 22 + 2 and len(flow.trainable_variables) == L * 2 * 15 + 2   # 22 per step incl. P_inv (flow_tfp_bijectors.py:281-294)
+    # creation order inside one step (flow_glow.py:15-20 -> flow_tfp_bijectors.py:236-239, 281-294, flow_tfk_layers.py:56-70)
+    assert [n.split("/", 2)[2] for n in names[:8]] == ["actnorm/log_scale", "actnorm/shift", "inv1x1/P", "inv1x1/P_inv", "inv1x1/sign_S",
+                                                       "inv1x1/L", "inv1x1/log_S", "inv1x1/U"]
+    sd = flow.state_dict()
+    np.testing.assert_allclose(sd["b0/s1/inv1x1/P_inv"], np.linalg.inv(sd["b0/s1/inv1x1/P"]), atol=1e-6)
+    with pytest.raises(KeyError):
+        flow.load_state_dict({k: v for k, v in sd.items() if not k.endswith("conv2/bias")})      # strict by default
+    with pytest.raises(KeyError):
+        flow.load_state_dict(dict(sd, stray=np.zeros(1)))
+    flow.load_state_dict({k: v for k, v in sd.items() if not k.endswith("P_inv")})                # the derived tensor may be absent
     p = R.cast_params(flow.state_dict(), np.float64)
     # right after construction conv3 is zero => every coupling is the identity and log_prob is the prior of an
     # ActNorm/1x1 chain; data-dependent init must equal the oracle's (reference order + raw-minibatch quirk)
@@ -90,7 +100,13 @@ def test_build_glow_matches_reference_construction(L):
     lp = flow.log_prob(dev(x))
     np.testing.assert_allclose(lp.cpu().numpy(), R.log_prob(x.astype(np.float64), p, cfg.as_dict()), rtol=1e-5)
     # the precision switch (extension): same numbers to fp32 class in the fp16-split arithmetic, and back
-    np.testing.assert_allclose(flow.set_precision("f16x3").log_prob(dev(x)).cpu().numpy(), lp.cpu().numpy(), rtol=2e-6)
+    # (the 3-level flow initialised in the reference's order is not normalised at run time -- SURVEY F8a -- and its inputs
+    # exceed what the range guard can vouch for: the call is then re-run on the fp32 kernels, with a warning)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        lp16 = flow.set_precision("f16x3").log_prob(dev(x))
+    np.testing.assert_allclose(lp16.cpu().numpy(), lp.cpu().numpy(), rtol=2e-6)
     assert torch.equal(flow.set_precision("f32").log_prob(dev(x)), lp)
     with pytest.raises(ValueError):
         flow.set_precision("bf16")

@@ -313,7 +313,7 @@ def test_batches_beyond_max_tiles_are_chunked(gpu):
     rc = eng.lib.glowk_log_prob(eng.h, ctypes.c_void_p(x.data_ptr()), eng.max_tiles + 1, ctypes.c_void_p(lp.data_ptr()), None, None)
     assert rc != 0 and b"glowk_max_tiles" in eng.lib.glowk_last_error()
     with pytest.raises(_lib.GlowkError):
-        _lib.check(eng.lib.glowk_reserve(eng.h, eng.max_tiles + 1))
+        _lib.check(eng.lib.glowk_reserve(eng.h, eng.max_tiles + 1, 0))
     whole = (eng.forward(x), eng.log_prob(x, return_latent=True), eng.log_prob_grad(x))
     eps = torch.randn(7, *cfg.latent_shape(), device="cuda")
     whole_s, whole_p = eng.sample_from_eps(eps), eng.prior_log_prob(eps)
