@@ -152,3 +152,60 @@ def test_batch_chunking_host_logic():
     e._free_bytes = lambda: 100            # not even one tile fits: chunks of one, the allocation itself will say so
     e._grad_chunk = (None, 0)
     assert e.grad_max_tiles == 1
+
+
+def test_status_and_policy_enums_match_header(repo_root):
+    text = open(os.path.join(repo_root, "include", "glowk.h")).read()
+    enum = dict((k, int(v)) for k, v in re.findall(r"(GLOWK_[A-Z0-9_]+) = (\d+)", text))
+    assert (enum["GLOWK_OK"], enum["GLOWK_ERR"], enum["GLOWK_ERR_RANGE"]) == (_lib.OK, _lib.ERR, _lib.ERR_RANGE)
+    assert (enum["GLOWK_RANGE_IGNORE"], enum["GLOWK_RANGE_ERROR"], enum["GLOWK_RANGE_FALLBACK"]) == (_lib.RANGE_IGNORE, _lib.RANGE_ERROR, _lib.RANGE_FALLBACK)
+    assert (enum["GLOWK_PREC_F32"], enum["GLOWK_PREC_F16X3"], enum["GLOWK_PREC_F16X2"]) == (_lib.PREC_F32, _lib.PREC_F16X3, _lib.PREC_F16X2)
+
+
+def test_range_policy_and_widths_on_the_host_side(lib):
+    """Host-only entry points: the range policy defaults to GLOWK_RANGE_ERROR and validates; glowk_create takes exactly the
+    instantiated network widths (the reference's own trained flows used n_filters = 256)."""
+    for F in (128, 256, 384, 512):
+        rc, h = _create(lib, dict(BASE, F=F))
+        assert rc == 0, F
+        assert lib.glowk_get_range_policy(h) == _lib.RANGE_ERROR
+        assert lib.glowk_set_range_policy(h, _lib.RANGE_FALLBACK) == 0 and lib.glowk_get_range_policy(h) == _lib.RANGE_FALLBACK
+        assert lib.glowk_set_range_policy(h, 7) != 0
+        assert lib.glowk_tensor_size(h, 0, _lib.STEP_TENSOR_IDS["inv1x1/P_inv"]) == 16
+        # gradient-path bytes need the launch policy, i.e. finalised weights, only for the split modes: fp32 is closed form
+        assert lib.glowk_workspace_bytes(h, 8, 1) > lib.glowk_workspace_bytes(h, 8, 0) > 0
+        assert lib.glowk_destroy(h) == 0
+    for F in (0, 64, 100, 640, 1024):
+        rc, h = _create(lib, dict(BASE, F=F))
+        assert rc != 0 and b"n_filters" in lib.glowk_last_error()
+
+
+def test_bench_launches_its_own_ranks(monkeypatch, repo_root):
+    """`python bench.py --gpus N` outside torch.distributed.run must start N ranks itself, before touching the GPU, and
+    hand back their exit code; a WORLD_SIZE that contradicts --gpus is an error."""
+    import importlib
+    import sys
+    bench = importlib.import_module("bench")
+    calls = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        calls["cmd"], calls["env"] = cmd, env
+        return Done()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = calls["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE" in str(e.value.code)

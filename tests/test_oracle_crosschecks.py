@@ -148,3 +148,86 @@ def test_data_dependent_init_normalises_first_step():
     per_step = {4: 294940, 8: 322648, 16: 378160}
     n = sum(CONFIG_B.K * per_step[c] for (_, _, c) in CONFIG_B.level_shapes())
     assert abs(n - 31.9e6) < 0.1e6
+
+
+# ---- third, structurally different restatement of the parts nothing in the reference pins: module objects with loaded state ----
+def _keras_like_convnet(p, pre, ci, F, c, eps):
+    """ShiftAndLogScaleConvNet (flow_tfk_layers.py:31-84) as a stack of stateful torch.nn modules in inference mode -- the way
+    Keras holds it (Conv2D / BatchNormalization layer objects whose moving statistics are used because no ``training=`` is
+    passed, :76,78) -- loaded with the oracle's tensors: HWIO kernels -> OIHW, NHWC activations -> NCHW."""
+    net = torch.nn.Sequential(
+        torch.nn.Conv2d(ci, F, 3, padding=1), torch.nn.ReLU(), torch.nn.BatchNorm2d(F, eps=eps),
+        torch.nn.Conv2d(F, F, 1), torch.nn.ReLU(), torch.nn.BatchNorm2d(F, eps=eps),
+        torch.nn.Conv2d(F, c, 3, padding=1)).double()
+    t = lambda name: torch.as_tensor(np.asarray(p[pre + name]), dtype=torch.float64)   # noqa: E731
+    with torch.no_grad():
+        for idx, conv in ((0, "conv1"), (3, "conv2"), (6, "conv3")):
+            net[idx].weight.copy_(t("nn/%s/kernel" % conv).permute(3, 2, 0, 1))
+            net[idx].bias.copy_(t("nn/%s/bias" % conv))
+        for idx, bn in ((2, "bn1"), (5, "bn2")):
+            net[idx].weight.copy_(t("nn/%s/gamma" % bn))
+            net[idx].bias.copy_(t("nn/%s/beta" % bn))
+            net[idx].running_mean.copy_(t("nn/%s/mean" % bn))
+            net[idx].running_var.copy_(t("nn/%s/var" % bn))
+    return net.eval()
+
+
+@pytest.mark.parametrize("c,F", [(4, 16), (8, 32), (16, 8)])
+def test_convnet_against_torch_nn_modules(c, F):
+    cfg = GlowConfig(H=8, W=16, C=1, L=2, K=1, F=F)
+    p = {k.replace("b0/s0/", "s/"): v for k, v in synthetic_params(cfg, dtype=np.float64).items()}
+    rng = np.random.default_rng(c)
+    ci = c // 2
+    # tensors of the requested channel count (the synthetic generator's level 0 has c = 4)
+    p["s/nn/conv1/kernel"] = rng.normal(0, 0.2, (3, 3, ci, F))
+    p["s/nn/conv3/kernel"] = rng.normal(0, 0.1, (3, 3, F, c))
+    p["s/nn/conv3/bias"] = rng.normal(0, 0.1, c)
+    xb = rng.standard_normal((3, 6, 5, ci))
+    log_s, t = R.convnet(xb, p, "s/", cfg.bn_eps)
+    net = _keras_like_convnet(p, "s/", ci, F, c, cfg.bn_eps)
+    with torch.no_grad():
+        o = net(torch.from_numpy(xb).permute(0, 3, 1, 2)).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(log_s, np.tanh(o[..., :ci]), rtol=1e-11, atol=1e-13)     # flow_tfk_layers.py:80-84
+    np.testing.assert_allclose(t, o[..., ci:], rtol=1e-11, atol=1e-13)
+    # and the modules' TRAINING mode gives something else: the oracle (like Keras without training=) is the inference reading
+    net.train()
+    with torch.no_grad():
+        o_tr = net(torch.from_numpy(xb).permute(0, 3, 1, 2)).permute(0, 2, 3, 1).numpy()
+    assert np.abs(o_tr - o).max() > 1e-3
+
+
+@pytest.mark.parametrize("learntop", [True, False])
+def test_prior_against_torch_distributions(learntop):
+    """flow_builder.py:131-144: Independent(MultivariateNormalDiag(loc, scale_diag=exp(v)), 2) / iid N(0, 1) over [h, w, c]."""
+    import torch.distributions as D
+    cfg = GlowConfig(H=8, W=8, C=1, L=2, K=1, F=8, learntop=learntop)
+    p = synthetic_params(cfg, dtype=np.float64)
+    z = np.random.default_rng(1).standard_normal((4,) + cfg.latent_shape())
+    if learntop:
+        base = D.Normal(torch.from_numpy(p["prior/loc"]), torch.exp(torch.from_numpy(p["prior/log_scale"])))
+    else:
+        base = D.Normal(torch.zeros(cfg.latent_shape(), dtype=torch.float64), torch.ones(cfg.latent_shape(), dtype=torch.float64))
+    ref = D.Independent(base, 3).log_prob(torch.from_numpy(z)).numpy()
+    np.testing.assert_allclose(R.prior_log_prob(z, p, cfg.as_dict()), ref, rtol=1e-12)
+    # sample_from_eps uses the same reparameterisation as rsample: loc + scale * eps
+    if learntop:
+        eps = np.random.default_rng(2).standard_normal((2,) + cfg.latent_shape())
+        zs = p["prior/loc"] + np.exp(p["prior/log_scale"]) * eps
+        x = R.sample_from_eps(eps, p, cfg.as_dict())
+        np.testing.assert_allclose(R.bijector_forward(x, p, cfg.as_dict())[0], zs, atol=1e-8)
+
+
+def test_stored_p_inv_is_what_the_inverse_uses():
+    """Invertible1x1Conv._inverse multiplies by the VARIABLE P_inv (flow_tfp_bijectors.py:313), initialised to inv(P) (:282-284):
+    with it the step inverts exactly; a checkpoint holding another P_inv changes the inverse and nothing else."""
+    cfg = GlowConfig(H=4, W=4, C=1, L=2, K=1, F=8)
+    p = synthetic_params(cfg, dtype=np.float64)
+    x = np.random.default_rng(3).standard_normal((2, 2, 2, 4))
+    y, _ = R.step_forward(x, p, "b0/s0/", cfg.as_dict())
+    np.testing.assert_allclose(R.step_inverse(y, p, "b0/s0/", cfg.as_dict()), x, atol=1e-10)
+    q = dict(p)
+    q["b0/s0/inv1x1/P_inv"] = np.linalg.inv(p["b0/s0/inv1x1/P"])
+    np.testing.assert_allclose(R.step_inverse(y, q, "b0/s0/", cfg.as_dict()), x, atol=1e-10)
+    q["b0/s0/inv1x1/P_inv"] = np.eye(4)[[1, 0, 2, 3]] @ q["b0/s0/inv1x1/P_inv"]
+    assert np.abs(R.step_inverse(y, q, "b0/s0/", cfg.as_dict()) - x).max() > 1e-3
+    np.testing.assert_allclose(R.step_forward(x, q, "b0/s0/", cfg.as_dict())[0], y, atol=0)
