@@ -2,20 +2,32 @@
 
 Mirrors the glow branch of the reference's ``run_basis_sep.py``: ``get_sigmas`` (ncsn/utils.py:7-14), the dB mixing
 process ``g`` / ``grad_g`` (run_basis_sep.py:131-147), ``basis_inner_loop`` (:152-214) and ``basis_outer_loop`` (:217-260).
-The per-step arithmetic outside ``compute_grad_logprob`` is a handful of elementwise ops on ``[n_mixed, H, W, 1]`` tensors
-(< 0.1 % of a step); it runs as torch ops on the same stream.  The noise source is injectable so that tests can replay
-the oracle's draws (the reference draws fresh ``tf.random.normal`` noise, unseeded).
+On the GPU the per-step arithmetic outside ``compute_grad_logprob`` -- the two noise draws, the dB mixture ``g``, its softmax
+weights ``grad_g`` and both updates -- is ONE HIP kernel (``glowk_basis_update``, csrc/glowk_basis.h) with the engine's
+counter-based device RNG (Philox4x32-10: the draw of element e at step t is a pure function of (seed, t, e)); torch supplies
+storage and streams only.  The noise source stays injectable so that tests can replay the oracle's draws (the reference draws
+fresh ``tf.random.normal`` noise, unseeded).  CPU tensors (the host-side tests of ``g`` / ``grad_g``) take the torch formulas.
 
 Convention: ``x1, x2, mixed`` live in the space the two flows were built for -- with
 ``build_glow(..., data_type='melspec')`` that is dB; the flows' own SpecPreprocessing maps it to the network's range.
 Tiles are independent, so ``shard`` splits ``n_mixed`` over the ranks of a process group with no collective in the loop.
 """
+import ctypes
 import math
 
 import numpy as np
 import torch
 
+from . import _lib
 from .distributed import shard_bounds
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _s(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
 def get_sigmas(sigma1, sigmaL, num_classes, progression="geometric"):
@@ -32,8 +44,27 @@ def get_sigmas(sigma1, sigmaL, num_classes, progression="geometric"):
 def mixing_db(*sources):
     """``g`` of the dB branch, sum in power (run_basis_sep.py:133-141): 10/ln10 * (logsumexp(s ln10/10) - ln K)."""
     k = len(sources)
+    if k == 2 and sources[0].is_cuda and sources[0].dtype == torch.float32:
+        a, b = sources[0].contiguous(), sources[1].contiguous()
+        out = torch.empty_like(a)
+        _lib.check(_lib.load().glowk_basis_mix(_p(a), _p(b), _p(out), a.numel(), _s(a)))
+        return out
     s = torch.stack(sources, dim=0)
     return (10.0 / math.log(10.0)) * (torch.logsumexp(s * (math.log(10.0) / 10.0), dim=0) - math.log(float(k)))
+
+
+def device_randn(shape, device, seed, step=0, which=0, uniform=False):
+    """Standard-normal (or U(0, 1)) tensor from the engine's Philox stream (seed, step, which): the draws
+    ``glowk_basis_update`` makes itself when no noise is injected."""
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    _lib.check(_lib.load().glowk_random(_p(out), out.numel(), int(seed), int(step), int(which), int(bool(uniform)), _s(out)))
+    return out
+
+
+def langevin_update(mixed, x1, x2, g1, g2, eta, lambda_recon, eps1=None, eps2=None, seed=0, step=0, nonfinite=None):
+    """run_basis_sep.py:163-181 for two sources, IN PLACE on x1 / x2 (contiguous float32 CUDA tensors): one kernel."""
+    _lib.check(_lib.load().glowk_basis_update(_p(x1), _p(x2), _p(g1), _p(g2), _p(mixed), x1.numel(), float(eta), float(lambda_recon),
+                                              _p(eps1), _p(eps2), int(seed), int(step), _p(nonfinite), _s(x1)))
 
 
 def grad_mixing_db(*sources):
@@ -69,9 +100,11 @@ def _grad_pair(x1, x2, model1, model2, streams):
 
 
 def basis_inner_loop(mixed, x1, x2, model1, model2, sigma_idx, sigmas, delta=2e-5, T=100, noise_fn=None, debug=False,
-                     streams="auto"):
-    """run_basis_sep.py:152-214 (model_type == 'glow').  ``noise_fn(t, which, shape) -> standard normal tensor``.
-    ``streams``: "auto" (two side streams when on the GPU and the models are distinct engines), None, or (s1, s2)."""
+                     streams="auto", seed=0, step0=0):
+    """run_basis_sep.py:152-214 (model_type == 'glow').  ``noise_fn(t, which, shape) -> standard normal tensor`` replays given
+    draws; without it the update kernel draws from the device RNG stream (seed, step0 + t).
+    ``streams``: "auto" (two side streams when on the GPU and the models are distinct engines), None, or (s1, s2).
+    ``debug``: the reference's NaN asserts (:183-191), from a flag the update kernel raises (one word read back per step)."""
     if streams == "auto":
         streams = None
         if x1.device.type == "cuda" and getattr(model1, "engine", None) is not getattr(model2, "engine", None):
@@ -80,24 +113,39 @@ def basis_inner_loop(mixed, x1, x2, model1, model2, sigma_idx, sigmas, delta=2e-
     sigma_l = float(sigmas[-1])
     eta = float(np.float32(delta * (sigma / sigma_l) ** 2))
     lambda_recon = 1.0 / (sigma ** 2)
+    if x1.device.type != "cuda":
+        return _inner_loop_host(mixed, x1, x2, model1, model2, eta, lambda_recon, T, noise_fn, debug)
+    mixed = mixed.to(torch.float32).contiguous()
+    x1, x2 = x1.to(torch.float32).clone().contiguous(), x2.to(torch.float32).clone().contiguous()   # (the update is in place)
+    flag = torch.zeros(1, dtype=torch.int32, device=x1.device) if debug else None
+    for t in range(T):
+        g1, g2 = _grad_pair(x1, x2, model1, model2, streams)
+        e1 = noise_fn(t, 0, x1.shape).to(torch.float32).contiguous() if noise_fn is not None else None
+        e2 = noise_fn(t, 1, x2.shape).to(torch.float32).contiguous() if noise_fn is not None else None
+        langevin_update(mixed, x1, x2, g1, g2, eta, lambda_recon, e1, e2, seed=seed, step=step0 + t, nonfinite=flag)
+        if debug:
+            assert int(flag.item()) == 0, (sigma, t)   # run_basis_sep.py:183-191
+    return x1, x2
+
+
+def _inner_loop_host(mixed, x1, x2, model1, model2, eta, lambda_recon, T, noise_fn, debug):
+    """The same loop on torch formulas (CPU tensors: host-side tests with stand-in models)."""
     if noise_fn is None:
-        noise_fn = lambda t, which, shape: torch.randn(shape, device=x1.device, dtype=torch.float32)  # noqa: E731
+        noise_fn = lambda t, which, shape: torch.randn(shape, dtype=torch.float32)  # noqa: E731
     for t in range(T):
         eps1 = math.sqrt(2.0 * eta) * noise_fn(t, 0, x1.shape)
         eps2 = math.sqrt(2.0 * eta) * noise_fn(t, 1, x2.shape)
-        g1, g2 = _grad_pair(x1, x2, model1, model2, streams)
+        g1, g2 = compute_grad_logprob(x1, model1), compute_grad_logprob(x2, model2)
         mix = mixing_db(x1, x2)
         m1, m2 = grad_mixing_db(x1, x2)
-        x1n = x1 + eta * (g1 + lambda_recon * m1 * (mixed - mix)) + eps1
-        x2n = x2 + eta * (g2 + lambda_recon * m2 * (mixed - mix)) + eps2
-        x1, x2 = x1n, x2n
+        x1, x2 = x1 + eta * (g1 + lambda_recon * m1 * (mixed - mix)) + eps1, x2 + eta * (g2 + lambda_recon * m2 * (mixed - mix)) + eps2
         if debug:
-            assert torch.isfinite(x1).all() and torch.isfinite(x2).all(), (sigma, t)   # run_basis_sep.py:183-191
+            assert torch.isfinite(x1).all() and torch.isfinite(x2).all(), t
     return x1, x2
 
 
 def basis_outer_loop(mixed, x1, x2, model1, model2, sigmas, restore_1=None, restore_2=None, T=100, delta=2e-5, noise_fn=None,
-                     debug=False):
+                     debug=False, seed=0):
     """run_basis_sep.py:217-260.  ``restore_k``: optional ``{sigma: state_dict | path | GlowFlow}`` with the noise-conditioned
     weights of model k for each noise level (the per-sigma checkpoints of train_noisy_glow.py:309-358); a ``GlowFlow`` value is
     used as is (all ten noise levels of both priors resident: 2 x 10 x 0.5 GB of packed weights)."""
@@ -116,7 +164,8 @@ def basis_outer_loop(mixed, x1, x2, model1, model2, sigmas, restore_1=None, rest
             current.append(model)
         model1_s, model2_s = current
         nf = None if noise_fn is None else (lambda t, which, shape, _s=sigma_idx: noise_fn(_s, t, which, shape))
-        x1, x2 = basis_inner_loop(mixed, x1, x2, model1_s, model2_s, sigma_idx, sigmas, delta=delta, T=T, noise_fn=nf, debug=debug)
+        x1, x2 = basis_inner_loop(mixed, x1, x2, model1_s, model2_s, sigma_idx, sigmas, delta=delta, T=T, noise_fn=nf, debug=debug,
+                                  seed=seed, step0=sigma_idx * T)
         x_arr["x1"].append(x1.cpu().numpy())
         x_arr["x2"].append(x2.cpu().numpy())
     return x1, x2, x_arr

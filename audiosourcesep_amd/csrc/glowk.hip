@@ -3,6 +3,7 @@
 #include "../../include/glowk.h"
 #include "glowk_kernels.h"
 #include "glowk_light.h"
+#include "glowk_basis.h"
 #include "glowk_launch.h"
 
 #include <algorithm>
@@ -1743,6 +1744,44 @@ int glowk_coupling_net(glowk_handle* h, int level, int step, const float* xb_dev
     ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0; ca.flag = flagp(h);
     return launch_couple(lv.c, ca, N, s);
   });
+}
+
+int glowk_basis_update(float* x1_dev, float* x2_dev, const float* g1_dev, const float* g2_dev, const float* mixed_dev, size_t n,
+                       float eta, float lambda_recon, const float* eps1_dev, const float* eps2_dev, uint64_t seed, uint64_t step,
+                       int* nonfinite_dev, void* stream) {
+  if (!x1_dev || !x2_dev || !g1_dev || !g2_dev || !mixed_dev) return fail("null tensor");
+  if (n == 0) return 0;
+  if (n > ((size_t)1 << 40)) return fail("basis_update: too many elements");
+  if (!(eta >= 0.0f)) return fail("basis_update: eta must be non-negative");
+  DeviceGuard dg(ptr_device(x1_dev));
+  BasisArgs a;
+  a.x1 = x1_dev; a.x2 = x2_dev; a.g1 = g1_dev; a.g2 = g2_dev; a.mixed = mixed_dev; a.eps1 = eps1_dev; a.eps2 = eps2_dev; a.n = n;
+  a.eta = eta; a.lambda_recon = lambda_recon; a.noise_scale = std::sqrt(2.0f * eta); a.seed = seed; a.step = step; a.nonfinite = nonfinite_dev;
+  const size_t threads = (n + 3) / 4;
+  hipLaunchKernelGGL(k_basis_update, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  LAUNCHCHK("k_basis_update");
+  return 0;
+}
+
+int glowk_basis_mix(const float* x1_dev, const float* x2_dev, float* out_dev, size_t n, void* stream) {
+  if (!x1_dev || !x2_dev || !out_dev) return fail("null tensor");
+  if (n == 0) return 0;
+  DeviceGuard dg(ptr_device(x1_dev));
+  hipLaunchKernelGGL(k_basis_mix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x1_dev, x2_dev, out_dev, n);
+  LAUNCHCHK("k_basis_mix");
+  return 0;
+}
+
+int glowk_random(float* out_dev, size_t n, uint64_t seed, uint64_t step, int which, int uniform, void* stream) {
+  if (!out_dev) return fail("null tensor");
+  if (which < 0 || which > 15) return fail("random: stream id must be 0..15");
+  if (n == 0) return 0;
+  DeviceGuard dg(ptr_device(out_dev));
+  const size_t threads = (n + 3) / 4;
+  hipLaunchKernelGGL(k_basis_noise, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out_dev, n, seed, step,
+                     (uint32_t)which, uniform);
+  LAUNCHCHK("k_basis_noise");
+  return 0;
 }
 
 }  // extern "C"

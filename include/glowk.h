@@ -198,6 +198,24 @@ int glowk_step_inverse(glowk_handle* h, int level, int step, const float* y_dev,
 /* ShiftAndLogScaleConvNet.call (flow_tfk_layers.py:73-84) of one step: xb [N,h,w,c/2] -> log_s, t [N,h,w,c/2] */
 int glowk_coupling_net(glowk_handle* h, int level, int step, const float* xb_dev, int N, float* log_s_dev, float* t_dev, void* stream);
 
+/* --- BASIS: the annealed-Langevin update around two log_prob_grad calls (run_basis_sep.py:152-181, dB branch) ------------- */
+/* One step of basis_inner_loop for two sources, in place, as ONE kernel:
+ *     mix = g(x1, x2) (:133-141),  (m1, m2) = grad_g(x1, x2) (:143-147),
+ *     x_k <- x_k + eta (g_k + lambda_recon m_k (mixed - mix)) + sqrt(2 eta) N(0, I)        (:163-164, :180-181)
+ * with g_k = compute_grad_logprob(x_k, model_k) supplied by the caller (glowk_log_prob_grad).  All tensors hold n floats.
+ * The normal draws come from the engine's counter-based device RNG (Philox4x32-10 keyed by `seed`, counter = element, `step`,
+ * source) unless eps1_dev / eps2_dev supply them (tests replay the oracle's draws; the reference draws unseeded).
+ * nonfinite_dev (optional, one int on the device): set to 1 when a gradient, the mixture or an updated value is not finite --
+ * the reference's debug asserts (:183-191). */
+int glowk_basis_update(float* x1_dev, float* x2_dev, const float* g1_dev, const float* g2_dev, const float* mixed_dev, size_t n,
+                       float eta, float lambda_recon, const float* eps1_dev, const float* eps2_dev, uint64_t seed, uint64_t step,
+                       int* nonfinite_dev, void* stream);
+/* g(x1, x2) alone: the mixture of two sources in dB, sum in power (:133-141) */
+int glowk_basis_mix(const float* x1_dev, const float* x2_dev, float* out_dev, size_t n, void* stream);
+/* the device RNG itself: out[e] = the draw glowk_basis_update makes for element e of (seed, step, which); uniform != 0 gives
+ * U(0, 1) from the same stream instead of N(0, 1) (the chain's initial state, run_basis_sep.py:360-361) */
+int glowk_random(float* out_dev, size_t n, uint64_t seed, uint64_t step, int which, int uniform, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,3 +66,84 @@ def test_basis_inner_loop_matches_oracle():
                                          restore_1={float(s): m1.state_dict() for s in sigmas[-2:]})
     assert torch.isfinite(o1).all() and torch.isfinite(o2).all() and len(arr["x1"]) == 3
     assert basis.shard(dev(mixed), 3, 1).shape[0] == 1
+
+
+@pytest.mark.gpu
+def test_device_rng_moments_and_streams():
+    """The engine's Philox4x32-10 / Box-Muller stream: standard-normal moments, U(0, 1) support, a pure function of
+    (seed, step, which, element), and distinct streams uncorrelated."""
+    n = 1 << 22
+    a = basis.device_randn((n,), "cuda", seed=1234, step=0, which=0)
+    assert torch.isfinite(a).all()
+    m, v = float(a.mean()), float(a.var())
+    k = float(((a - m) ** 4).mean() / v ** 2)
+    assert abs(m) < 4.0 / n ** 0.5 * 1.0 and abs(v - 1.0) < 5e-3 and abs(k - 3.0) < 2e-2, (m, v, k)
+    assert float((a.abs() > 4.0).float().mean()) < 2e-4 and float(a.abs().max()) < 7.0
+    # a pure function of its counters: the same call twice, a shorter call, another launch geometry
+    assert torch.equal(a, basis.device_randn((n,), "cuda", seed=1234, step=0, which=0))
+    assert torch.equal(a[:1001], basis.device_randn((1001,), "cuda", seed=1234, step=0, which=0))
+    others = [basis.device_randn((n,), "cuda", seed=1234, step=0, which=1), basis.device_randn((n,), "cuda", seed=1234, step=1, which=0),
+              basis.device_randn((n,), "cuda", seed=1235, step=0, which=0)]
+    for b in others:
+        assert not torch.equal(a, b)
+        assert abs(float((a * b).mean())) < 5.0 / n ** 0.5                   # uncorrelated streams
+    assert abs(float((a[:-1] * a[1:]).mean())) < 5.0 / n ** 0.5              # and no lag-1 correlation within one
+    u = basis.device_randn((n,), "cuda", seed=7, uniform=True)
+    assert float(u.min()) > 0.0 and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 1e-3 and abs(float(u.var()) - 1.0 / 12) < 1e-3
+
+
+@pytest.mark.gpu
+def test_fused_update_kernel_against_the_formulas():
+    """glowk_basis_update == run_basis_sep.py:163-181 written out in float64, with injected noise; with its own RNG it is
+    bitwise the injected-noise result for the draws glowk_random reports; a non-finite gradient raises the flag."""
+    rng = np.random.default_rng(5)
+    shape = (7, 16, 12, 1)                                   # 1344 elements: not a multiple of the 1024-element workgroup
+    x1, x2, mixed = rng.uniform(-80, 10, (3,) + shape)
+    g1, g2 = rng.normal(0, 5, (2,) + shape)
+    e1, e2 = rng.standard_normal((2,) + shape)
+    eta, lam = 2e-5 * 37.0, 1.0 / 0.3 ** 2
+    mix = basis_ref.g_db(x1, x2)
+    m1, m2 = basis_ref.grad_g_db(x1, x2)
+    r1 = x1 + eta * (g1 + lam * m1 * (mixed - mix)) + np.sqrt(2 * eta) * e1
+    r2 = x2 + eta * (g2 + lam * m2 * (mixed - mix)) + np.sqrt(2 * eta) * e2
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()   # noqa: E731
+    np.testing.assert_allclose(basis.mixing_db(dev(x1), dev(x2)).cpu().numpy(), mix, rtol=2e-6, atol=2e-5)
+    y1, y2 = dev(x1), dev(x2)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    basis.langevin_update(dev(mixed), y1, y2, dev(g1), dev(g2), eta, lam, dev(e1), dev(e2), nonfinite=flag)
+    np.testing.assert_allclose(y1.cpu().numpy(), r1, rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(y2.cpu().numpy(), r2, rtol=1e-5, atol=1e-4)
+    assert int(flag.item()) == 0
+    # device RNG: same result as injecting the draws the RNG reports for (seed, step, source)
+    z1, z2 = dev(x1), dev(x2)
+    basis.langevin_update(dev(mixed), z1, z2, dev(g1), dev(g2), eta, lam, seed=99, step=5)
+    w1, w2 = dev(x1), dev(x2)
+    basis.langevin_update(dev(mixed), w1, w2, dev(g1), dev(g2), eta, lam, basis.device_randn(shape, "cuda", 99, 5, 0),
+                          basis.device_randn(shape, "cuda", 99, 5, 1))
+    assert torch.equal(z1, w1) and torch.equal(z2, w2) and not torch.equal(z1, y1)
+    # the reference's NaN asserts (run_basis_sep.py:183-191)
+    gbad = dev(g1)
+    gbad[3, 2, 1, 0] = float("nan")
+    basis.langevin_update(dev(mixed), dev(x1), dev(x2), gbad, dev(g2), eta, lam, nonfinite=flag)
+    assert int(flag.item()) == 1
+
+
+@pytest.mark.gpu
+def test_inner_loop_with_device_rng_is_reproducible_and_leaves_inputs_alone():
+    from audiosourcesep_amd.flow_models.flow_glow import GlowFlow
+    from audiosourcesep_amd.synthetic import calibrated_engine
+    cfg = GlowConfig(H=16, W=16, C=1, L=2, K=2, F=128)
+    e1, _ = calibrated_engine(cfg, device=0, init_tiles=16, seed=1)
+    e2, _ = calibrated_engine(cfg, device=0, init_tiles=16, seed=2)
+    m1, m2 = GlowFlow(e1), GlowFlow(e2)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()   # noqa: E731
+    x1, x2 = dev(synthetic_mel_tiles(5, cfg, seed=12)), dev(synthetic_mel_tiles(5, cfg, seed=13))
+    mixed = basis.mixing_db(dev(synthetic_mel_tiles(5, cfg, seed=10)), dev(synthetic_mel_tiles(5, cfg, seed=11)))
+    x1c, x2c = x1.clone(), x2.clone()
+    sig = basis.get_sigmas(1.0, 0.01, 10)
+    a1, a2 = basis.basis_inner_loop(mixed, x1, x2, m1, m2, 9, sig, T=3, seed=4, debug=True)
+    b1, b2 = basis.basis_inner_loop(mixed, x1, x2, m1, m2, 9, sig, T=3, seed=4)
+    c1, _ = basis.basis_inner_loop(mixed, x1, x2, m1, m2, 9, sig, T=3, seed=5)
+    assert torch.equal(x1, x1c) and torch.equal(x2, x2c)
+    assert torch.equal(a1, b1) and torch.equal(a2, b2) and not torch.equal(a1, c1)
+    assert torch.isfinite(a1).all() and float((a1 - x1).abs().max()) > 1e-3
