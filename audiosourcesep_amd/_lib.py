@@ -90,6 +90,10 @@ SYMBOLS = {
     "glowk_step_forward": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "glowk_step_inverse": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
     "glowk_coupling_net": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "glowk_param_vector_size": (ctypes.c_size_t, [_vp]),
+    "glowk_param_offset": (_i, [_vp, _i, _i, _i, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
+    "glowk_param_grad": (_i, [_vp, _vp, _i, ctypes.c_float, _vp, _vp, _vp]),
+    "glowk_apply_gradients": (_i, [_vp, _vp, _i, ctypes.c_float, _vp]),
     "glowk_basis_update": (_i, [_vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, _vp, _vp,
                                 ctypes.c_uint64, ctypes.c_uint64, _vp, _vp]),
     "glowk_basis_mix": (_i, [_vp, _vp, _vp, ctypes.c_size_t, _vp]),

@@ -4,6 +4,7 @@
 #include "glowk_kernels.h"
 #include "glowk_light.h"
 #include "glowk_basis.h"
+#include "glowk_train.h"
 #include "glowk_launch.h"
 
 #include <algorithm>
@@ -114,6 +115,22 @@ struct glowk_handle {
   std::vector<int> save_parts;   // partials actually written per step by the last forward pass with saves
   unsigned short* saveM = nullptr;
   std::vector<size_t> offV, offP, offM;   // per forward-order step
+  // training (glowk_param_grad / glowk_apply_gradients): device master copy of every parameter, optimizer state, scratch
+  bool tr_active = false;        // tr_params holds the current parameters
+  bool host_stale = false;       // ... and the host tensors of the conv / BatchNorm / prior parameters are behind it
+  bool split_stale = false;      // ... and so are the f16 images (rebuilt by the host packer at the next split-precision call)
+  float *tr_params = nullptr, *tr_m = nullptr, *tr_v = nullptr;
+  size_t tr_n = 0;
+  long tr_t = 0;                 // optimizer steps taken
+  std::vector<size_t> tr_level_off;
+  size_t tr_prior_off = 0;
+  std::vector<int*> tr_map;      // per level: packed-image position -> position in the step's parameter block (k_repack_f32)
+  std::vector<size_t> tr_map_n;
+  int trN = 0;
+  float *trR1 = nullptr, *trR2 = nullptr, *trM1 = nullptr, *trM2 = nullptr, *trXcol = nullptr, *trGcol = nullptr, *trCpart = nullptr;
+  float *trC1 = nullptr, *trC2 = nullptr, *trC3 = nullptr, *trT = nullptr, *trGv = nullptr;
+  double *trAffPart = nullptr, *trAffSum = nullptr;
+  float* trSmall = nullptr;      // staging of the small (ActNorm / 1x1 / conv3-bias) parameters, device side
   // HIP-event profiler of k_net
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
@@ -896,6 +913,8 @@ int max_tiles(const glowk_handle* h) {
   return m < 1 ? 1 : (int)m;
 }
 
+extern "C" int glowk_finalize_weights(glowk_handle* h);
+
 int check_batch(const glowk_handle* h, int N) {
   if (N <= 0) return fail("batch size must be positive");
   if (N > max_tiles(h)) return fail("batch of " + std::to_string(N) + " tiles exceeds glowk_max_tiles() = " + std::to_string(max_tiles(h)) +
@@ -905,6 +924,8 @@ int check_batch(const glowk_handle* h, int N) {
 
 int check_ready(glowk_handle* h, int N) {
   if (!h) return fail("null handle");
+  if (h->finalized && h->split_stale && h->precision != GLOWK_PREC_F32)   // trained since the f16 images were packed: re-pack (host, ~0.3 s)
+    if (int rc = glowk_finalize_weights(h)) return rc;
   if (!h->finalized) return fail("glowk_finalize_weights has not been called");
   if (int rc = check_batch(h, N)) return rc;
   return ensure_ws(h, N);
@@ -916,7 +937,7 @@ NetArgs net_args(glowk_handle* h, const Level& lv, const StepDev& sd, const floa
   a.Q = N * lv.h * lv.w; a.h = lv.h; a.w = lv.w;
   a.K1p = sd.K1p; a.ep = sd.ep; a.R0p = sd.R0p; a.mask1 = nullptr; a.mask2 = nullptr; a.P = h->bufP;
   a.RHp = sd.RHp; a.RSp = sd.RSp; a.fam16 = (sd.RSp && sd.RSBp) ? 1 : 0; a.eph = sd.epH; a.pstride = h->pstride; a.max_np = 4; a.sc1 = sd.sc1; a.sc2 = sd.sc2; a.sc3 = sd.sc3;
-  a.flag = flagp(h); a.xlim = sd.xlim_f;
+  a.flag = flagp(h); a.xlim = sd.xlim_f; a.st1 = nullptr; a.st2 = nullptr;
   return a;
 }
 
@@ -1004,8 +1025,172 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
   return 0;
 }
 
-// d sum_n log_prob[n] / dx, after run_forward(save = true) on the same x; z is that run's latent
-int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* dx, hipStream_t s) {
+// ---- training: layout of the flat parameter / gradient vector, scratch, per-step weight gradients ------------------------
+// One block per step (creation order k within a level, levels in order), then the prior:
+//   [actnorm log_scale c | actnorm shift c | L c^2 | log_S c | U c^2 | K1 9 ci F | K2 F^2 | K3 9 F c | b1 F | b2 F | b3 c |
+//    gamma1 beta1 mean1 var1 gamma2 beta2 mean2 var2 (8 F)]          ... [prior loc E | prior log_scale E]
+// (the frozen P, P_inv, sign_S stay on the host; the BatchNorm moving statistics ride along with zero gradient)
+struct TrainOff { size_t als, ash, L, logS, U, K1, K2, K3, b1, b2, b3, bn, total; };
+TrainOff train_off(int c, int F) {
+  TrainOff t;
+  size_t o = 0;
+  const size_t ci = c / 2;
+  t.als = o; o += c; t.ash = o; o += c; t.L = o; o += (size_t)c * c; t.logS = o; o += c; t.U = o; o += (size_t)c * c;
+  o = pad4(o);
+  t.K1 = o; o += 9 * ci * F; t.K2 = o; o += (size_t)F * F; t.K3 = o; o += (size_t)9 * F * c;
+  t.b1 = o; o += F; t.b2 = o; o += F; t.b3 = o; o += pad4(c); t.bn = o; o += (size_t)8 * F;
+  t.total = pad4(o);
+  return t;
+}
+int train_tensor_off(const TrainOff& t, int id, size_t* off) {
+  switch (id) {
+    case GLOWK_ACTNORM_LOG_SCALE: *off = t.als; return 0;
+    case GLOWK_ACTNORM_SHIFT: *off = t.ash; return 0;
+    case GLOWK_INV1X1_L: *off = t.L; return 0;
+    case GLOWK_INV1X1_LOG_S: *off = t.logS; return 0;
+    case GLOWK_INV1X1_U: *off = t.U; return 0;
+    case GLOWK_CONV1_KERNEL: *off = t.K1; return 0;
+    case GLOWK_CONV2_KERNEL: *off = t.K2; return 0;
+    case GLOWK_CONV3_KERNEL: *off = t.K3; return 0;
+    case GLOWK_CONV1_BIAS: *off = t.b1; return 0;
+    case GLOWK_CONV2_BIAS: *off = t.b2; return 0;
+    case GLOWK_CONV3_BIAS: *off = t.b3; return 0;
+    default: return 1;
+  }
+}
+// (BatchNorm tensors: bn + {0..3} F for layer 1, bn + {4..7} F for layer 2; needs F, so resolved by the caller)
+const int TRAIN_IDS[] = {GLOWK_ACTNORM_LOG_SCALE, GLOWK_ACTNORM_SHIFT, GLOWK_INV1X1_L, GLOWK_INV1X1_LOG_S, GLOWK_INV1X1_U, GLOWK_CONV1_KERNEL,
+                         GLOWK_CONV2_KERNEL, GLOWK_CONV3_KERNEL, GLOWK_CONV1_BIAS, GLOWK_CONV2_BIAS, GLOWK_CONV3_BIAS, GLOWK_BN1_GAMMA, GLOWK_BN1_BETA,
+                         GLOWK_BN1_MEAN, GLOWK_BN1_VAR, GLOWK_BN2_GAMMA, GLOWK_BN2_BETA, GLOWK_BN2_MEAN, GLOWK_BN2_VAR};
+bool train_id_off(const TrainOff& t, int F, int id, size_t* off) {
+  if (id >= GLOWK_BN1_GAMMA && id <= GLOWK_BN1_VAR) { *off = t.bn + (size_t)(id - GLOWK_BN1_GAMMA) * F; return true; }
+  if (id >= GLOWK_BN2_GAMMA && id <= GLOWK_BN2_VAR) { *off = t.bn + (size_t)(4 + id - GLOWK_BN2_GAMMA) * F; return true; }
+  return train_tensor_off(t, id, off) == 0;
+}
+
+void train_layout(glowk_handle* h) {
+  h->tr_level_off.clear();
+  size_t o = 0;
+  for (const Level& lv : h->levels) {
+    h->tr_level_off.push_back(o);
+    o += train_off(lv.c, h->cfg.F).total * h->cfg.K;
+  }
+  h->tr_prior_off = o;
+  o += 2 * pad4(h->prior_loc.size());
+  h->tr_n = o;
+}
+size_t train_step_pos(const glowk_handle* h, int lvl, int k) { return h->tr_level_off[lvl] + train_off(h->levels[lvl].c, h->cfg.F).total * (size_t)k; }
+
+constexpr int AFF_BLOCKS = 128;
+constexpr size_t AFF_NOUT_MAX = 32 * 32 + 32;
+constexpr size_t CPART_FLOATS = (size_t)6 << 20;
+
+int ensure_train(glowk_handle* h, int N) {
+  if (N <= h->trN) return 0;
+  HIPCHK(hipDeviceSynchronize());
+  float** bufs[] = {&h->trR1, &h->trR2, &h->trM1, &h->trM2, &h->trXcol, &h->trGcol, &h->trGv};
+  for (float** b : bufs) { if (*b) hipFree(*b); *b = nullptr; }
+  h->trN = 0;
+  const size_t F = h->cfg.F;
+  size_t qmax = 0, xcol = 0, gcol = 0, gv = 0;
+  for (const Level& lv : h->levels) {
+    const size_t Q = (size_t)N * lv.h * lv.w;
+    qmax = std::max(qmax, Q);
+    xcol = std::max(xcol, (size_t)(9 * (lv.c / 2) + 1) * Q);
+    gcol = std::max(gcol, (size_t)9 * lv.c * Q);
+    gv = std::max(gv, Q * lv.c);
+  }
+  HIPCHK(hipMalloc(&h->trR1, F * qmax * 4)); HIPCHK(hipMalloc(&h->trR2, F * qmax * 4));
+  HIPCHK(hipMalloc(&h->trM1, F * qmax * 4)); HIPCHK(hipMalloc(&h->trM2, F * qmax * 4));
+  HIPCHK(hipMalloc(&h->trXcol, xcol * 4)); HIPCHK(hipMalloc(&h->trGcol, gcol * 4)); HIPCHK(hipMalloc(&h->trGv, gv * 4));
+  if (!h->trCpart) {
+    HIPCHK(hipMalloc(&h->trCpart, CPART_FLOATS * 4));
+    HIPCHK(hipMalloc(&h->trC1, (size_t)F * (9 * 16 + 1) * 4));
+    HIPCHK(hipMalloc(&h->trC2, (size_t)(F + 1) * F * 4));
+    HIPCHK(hipMalloc(&h->trC3, (size_t)(F + 1) * 9 * 32 * 4));
+    HIPCHK(hipMalloc(&h->trT, (size_t)2 * F * 4));
+    HIPCHK(hipMalloc(&h->trAffPart, (size_t)AFF_BLOCKS * AFF_NOUT_MAX * 8));
+    HIPCHK(hipMalloc(&h->trAffSum, (size_t)h->cfg.L * h->cfg.K * AFF_NOUT_MAX * 8));
+  }
+  h->trN = N;
+  return 0;
+}
+
+// C[Mp][N] = [A; 1?] . B^T over K pixels: split-K MFMA GEMM + fixed-order sum of the partials
+int launch_wgrad(glowk_handle* h, const float* A, int M, int a_ones, const float* B, int N, int K, float* C, hipStream_t s) {
+  const int Mp = M + a_ones, tm = (Mp + 63) / 64, tn = (N + 63) / 64, tiles = tm * tn;
+  int S = std::max(1, std::min((2 * num_cus() + tiles - 1) / tiles, (K + 255) / 256));
+  int kslice = (((K + S - 1) / S) + 31) / 32 * 32;
+  S = (K + kslice - 1) / kslice;
+  if ((size_t)S * Mp * N > CPART_FLOATS) return fail("wgrad: partial buffer too small");
+  WgradArgs a;
+  a.A = A; a.B = B; a.M = M; a.N = N; a.a_ones = a_ones; a.K = K; a.kslice = kslice; a.Cpart = h->trCpart;
+  hipLaunchKernelGGL(k_wgrad_nt, dim3(tm, tn, S), dim3(256), 0, s, a);
+  LAUNCHCHK("k_wgrad_nt");
+  const size_t n = (size_t)Mp * N;
+  hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)h->trCpart, S, n, C);
+  LAUNCHCHK("k_sum_parts");
+  return 0;
+}
+
+struct TrainCtx {
+  float* grad;     // [tr_n] flat gradient vector (device, caller owned)
+  float scale;     // every gradient is scale * d sum_n log_prob / d theta
+};
+
+// weight gradients of one step's coupling network.  v: the step's saved coupling input [Q][c]; g_o: gradient wrt the network output
+// [Q][c]; the backward launch (mode 8) has just left M2 / M1 in trM2 / trM1.
+int train_network_grads(glowk_handle* h, TrainCtx* tc, int lvl, int k, const float* v, const float* g_o, int N, hipStream_t s) {
+  const Level& lv = h->levels[lvl];
+  const StepDev& sd = lv.dev[k];
+  const int F = h->cfg.F, c = lv.c, ci = c / 2, Q = N * lv.h * lv.w;
+  // (1) recompute the forward network on the saved input, keeping R1 / R2 (its P output goes to a scratch partial of bufP)
+  NetArgs nf = net_args(h, lv, sd, v, c, ci, N);
+  nf.P = h->bufP + 2 * h->pstride; nf.st1 = h->trR1; nf.st2 = h->trR2;
+  if (launch_net_raw(c, F, nf, 7, s) < 0) return 1;
+  // (2) planar im2col operands
+  hipLaunchKernelGGL(k_im2col_planar, dim3((Q + 255) / 256), dim3(256), 0, s, v, c, ci, ci, Q, lv.h, lv.w, 1, 1, h->trXcol);
+  hipLaunchKernelGGL(k_im2col_planar, dim3((Q + 255) / 256), dim3(256), 0, s, g_o, c, 0, c, Q, lv.h, lv.w, -1, 0, h->trGcol);
+  LAUNCHCHK("k_im2col_planar");
+  // (3) the three GEMMs over the pixel dimension
+  if (int rc = launch_wgrad(h, h->trR2, F, 1, h->trGcol, 9 * c, Q, h->trC3, s)) return rc;
+  if (int rc = launch_wgrad(h, h->trR1, F, 1, h->trM2, F, Q, h->trC2, s)) return rc;
+  if (int rc = launch_wgrad(h, h->trM1, F, 0, h->trXcol, 9 * ci + 1, Q, h->trC1, s)) return rc;
+  hipLaunchKernelGGL(k_rowdot, dim3(F), dim3(256), 0, s, (const float*)h->trM1, (const float*)h->trR1, Q, h->trT);
+  hipLaunchKernelGGL(k_rowdot, dim3(F), dim3(256), 0, s, (const float*)h->trM2, (const float*)h->trR2, Q, h->trT + F);
+  LAUNCHCHK("k_rowdot");
+  // (4) assemble into the flat gradient vector
+  const TrainOff t = train_off(c, F);
+  const float* p = h->tr_params + train_step_pos(h, lvl, k);
+  float* g = tc->grad + train_step_pos(h, lvl, k);
+  StepGradArgs a;
+  a.F = F; a.c = c; a.K2 = p + t.K2; a.K3 = p + t.K3; a.bn = p + t.bn; a.eps = h->cfg.bn_eps;
+  a.C1 = h->trC1; a.C2 = h->trC2; a.C3 = h->trC3; a.T1 = h->trT; a.T2 = h->trT + F; a.scale = tc->scale;
+  a.dK1 = g + t.K1; a.dK2 = g + t.K2; a.dK3 = g + t.K3; a.db1 = g + t.b1; a.db2 = g + t.b2; a.db3 = g + t.b3;
+  a.dgamma1 = g + t.bn; a.dbeta1 = g + t.bn + F; a.dgamma2 = g + t.bn + 4 * (size_t)F; a.dbeta2 = g + t.bn + 5 * (size_t)F;
+  const size_t work = std::max({(size_t)F * F, (size_t)9 * F * c, (size_t)9 * ci * F});
+  hipLaunchKernelGGL(k_assemble_step_grads, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a);
+  LAUNCHCHK("k_assemble_step_grads");
+  return 0;
+}
+
+// sums for the ActNorm / 1x1 gradients of step k: dA = sum_q u^T g_v, db = sum_q g_v  ->  trAffSum[(lvl K + k)]
+int train_affine_sums(glowk_handle* h, int lvl, int k, const float* v, const float* gv, int N, hipStream_t s) {
+  const Level& lv = h->levels[lvl];
+  const StepDev& sd = lv.dev[k];
+  const int Q = N * lv.h * lv.w, c = lv.c;
+  const size_t nout = (size_t)c * c + c;
+  CDISPATCH(c, hipLaunchKernelGGL((k_affine_wgrad<CC>), dim3(AFF_BLOCKS), dim3(256), 0, s, v, gv, Q, sd.Ainv, sd.binv, h->trAffPart));
+  LAUNCHCHK("k_affine_wgrad");
+  hipLaunchKernelGGL(k_sum_parts_f64, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, s, (const double*)h->trAffPart, AFF_BLOCKS, nout,
+                     h->trAffSum + ((size_t)lvl * h->cfg.K + k) * AFF_NOUT_MAX);
+  LAUNCHCHK("k_sum_parts_f64");
+  return 0;
+}
+
+// d sum_n log_prob[n] / dx, after run_forward(save = true) on the same x; z is that run's latent.
+// tc != null: the training sweep -- exact fp32 kernels, and every step also leaves its weight gradients in tc->grad.
+int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* dx, hipStream_t s, TrainCtx* tc = nullptr) {
   const glowk_config& cfg = h->cfg;
   const int K = cfg.K, L = cfg.L, NF = cfg.F / 32;
   const int E = h->Hl * h->Wl * h->Cl;
@@ -1042,16 +1227,22 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
         ba.ghalf_in = gh_a; ba.Pg = Pg; ba.npg = npg; ba.pgstride = h->pstride; ba.gv_direct = nullptr; ba.gvd_stride = 0; ba.gvd_off = 0;
         ba.A = lv.dev[k - 1].Afwd;
       }
+      ba.gv_out = (tc && k > 0) ? h->trGv : nullptr;
       CDISPATCH(lv.c, hipLaunchKernelGGL((k_bwd_light<CC>), dim3((Q + 63) / 64), dim3(256), 0, s, ba));
       LAUNCHCHK("k_bwd_light");
+      if (tc && k > 0)   // g_v of step k-1 is complete: its ActNorm + 1x1 gradient sums
+        if (int rc = train_affine_sums(h, lvl, k - 1, h->saveV + h->offV[sidx + 1], h->trGv, N, s)) return rc;
       std::swap(gh_a, gh_b);   // gh_a now holds this step's [g_va, g_yb]
       NetArgs na = net_args(h, lv, sd, g_o, lv.c, 0, N);
       na.K1p = sd.K3bp; na.R0p = sd.RBp; na.P = Pg;
       na.mask1 = h->saveM + h->offM[sidx];
       na.mask2 = na.mask1 + blocks * NF * 64;
-      const bool h3b = h->precision != GLOWK_PREC_F32 && sd.RHBp;
+      const bool h3b = !tc && h->precision != GLOWK_PREC_F32 && sd.RHBp;
       if (h3b) { na.RHp = sd.RHBp; na.RSp = sd.RSBp; na.eph = nullptr; na.sc1 = sd.scb1; na.sc2 = sd.scb2; na.sc3 = sd.scb3; na.xlim = sd.xlim_b; }
-      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, h3b ? 5 : NET_BWD, &npg)) return rc;
+      if (tc) { na.st1 = h->trM2; na.st2 = h->trM1; }
+      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, tc ? 8 : h3b ? 5 : NET_BWD, &npg)) return rc;
+      if (tc)
+        if (int rc = train_network_grads(h, tc, lvl, k, h->saveV + h->offV[sidx], g_o, N, s)) return rc;
     }
     // first forward step of the block (k = K-1): merge, then through its ActNorm + 1x1 -> g_u of the squeezed block input
     {
@@ -1060,8 +1251,11 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       ba.ghalf_in = gh_a; ba.Pg = Pg; ba.npg = npg; ba.pgstride = h->pstride; ba.gv_direct = nullptr; ba.gvd_stride = 0; ba.gvd_off = 0;
       ba.A = lv.dev[K - 1].Afwd;
       ba.v = nullptr; ba.P = nullptr; ba.np = 1; ba.pstride = 0; ba.b3 = nullptr; ba.g_o = nullptr; ba.ghalf_out = nullptr; ba.gu_out = g_o;   // reuse g_o as g_u
+      ba.gv_out = tc ? h->trGv : nullptr;
       CDISPATCH(lv.c, hipLaunchKernelGGL((k_bwd_light<CC>), dim3((Q + 63) / 64), dim3(256), 0, s, ba));
       LAUNCHCHK("k_bwd_light");
+      if (tc)
+        if (int rc = train_affine_sums(h, lvl, K - 1, h->saveV + h->offV[(size_t)lvl * K], h->trGv, N, s)) return rc;
     }
     if (lvl > 0) {
       const Level& pv = h->levels[lvl - 1];
@@ -1141,6 +1335,173 @@ int guarded(glowk_handle* h, hipStream_t s, Run&& run) {
   return rc;
 }
 
+// ---- training: host side ------------------------------------------------------------------------------------------------
+// host tensors -> flat vector (staging); the inverse is sync_host
+void params_to_flat(const glowk_handle* h, std::vector<float>& flat) {
+  flat.assign(h->tr_n, 0.0f);
+  const int F = h->cfg.F;
+  for (size_t l = 0; l < h->levels.size(); ++l) {
+    const Level& lv = h->levels[l];
+    const TrainOff t = train_off(lv.c, F);
+    for (int k = 0; k < h->cfg.K; ++k) {
+      float* dst = flat.data() + train_step_pos(h, (int)l, k);
+      for (int id : TRAIN_IDS) {
+        size_t off;
+        train_id_off(t, F, id, &off);
+        const std::vector<float>& v = lv.host[id][k];
+        std::memcpy(dst + off, v.data(), v.size() * 4);
+      }
+    }
+  }
+  const size_t E = h->prior_loc.size();
+  std::memcpy(flat.data() + h->tr_prior_off, h->prior_loc.data(), E * 4);
+  std::memcpy(flat.data() + h->tr_prior_off + pad4(E), h->prior_log_scale.data(), E * 4);
+}
+
+int sync_host(glowk_handle* h) {
+  if (!h->host_stale) return 0;
+  std::vector<float> flat(h->tr_n);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(flat.data(), h->tr_params, h->tr_n * 4, hipMemcpyDeviceToHost));
+  const int F = h->cfg.F;
+  for (size_t l = 0; l < h->levels.size(); ++l) {
+    Level& lv = h->levels[l];
+    const TrainOff t = train_off(lv.c, F);
+    for (int k = 0; k < h->cfg.K; ++k) {
+      const float* src = flat.data() + train_step_pos(h, (int)l, k);
+      for (int id : TRAIN_IDS) {
+        size_t off;
+        train_id_off(t, F, id, &off);
+        std::vector<float>& v = lv.host[id][k];
+        std::memcpy(v.data(), src + off, v.size() * 4);
+      }
+    }
+  }
+  const size_t E = h->prior_loc.size();
+  std::memcpy(h->prior_loc.data(), flat.data() + h->tr_prior_off, E * 4);
+  std::memcpy(h->prior_log_scale.data(), flat.data() + h->tr_prior_off + pad4(E), E * 4);
+  h->host_stale = false;
+  return 0;
+}
+
+// packed-image position -> position in the step's parameter block, for the exact-fp32 images of one level: the host packer
+// itself, run on index-coded kernels (one tensor at a time: codes 1 .. n are exact in fp32)
+int build_repack_map(glowk_handle* h, int lvl, std::vector<int>& map, size_t* region_off) {
+  const glowk_config& cfg = h->cfg;
+  const Level& src = h->levels[lvl];
+  const int c = src.c, F = cfg.F;
+  const StepLayout SL = step_layout(c, F);
+  const TrainOff t = train_off(c, F);
+  const size_t lo = SL.K1p, hi = SL.RHp;      // [K1p | ep | R0p | K3bp | RBp) -- the images k_net_f32 reads
+  map.assign(hi - lo, -1);
+  for (size_t i = SL.ep; i < SL.R0p; ++i) map[i - lo] = -2;
+  Level tmp;
+  tmp.h = src.h; tmp.w = src.w; tmp.c = c; tmp.z_off = 0; tmp.z_width = 0; tmp.Cz = 0;
+  for (int id = 0; id < GLOWK_NUM_STEP_TENSORS; ++id) tmp.host[id].assign(1, std::vector<float>(step_tensor_size(cfg, src, id), 0.0f));
+  for (int i = 0; i < c; ++i) { tmp.host[GLOWK_INV1X1_P][0][(size_t)i * c + i] = 1.0f; tmp.host[GLOWK_INV1X1_SIGN_S][0][i] = 1.0f; }
+  std::fill(tmp.host[GLOWK_BN1_GAMMA][0].begin(), tmp.host[GLOWK_BN1_GAMMA][0].end(), 1.0f);
+  std::fill(tmp.host[GLOWK_BN2_GAMMA][0].begin(), tmp.host[GLOWK_BN2_GAMMA][0].end(), 1.0f);
+  std::fill(tmp.host[GLOWK_BN1_VAR][0].begin(), tmp.host[GLOWK_BN1_VAR][0].end(), 1.0f);
+  std::fill(tmp.host[GLOWK_BN2_VAR][0].begin(), tmp.host[GLOWK_BN2_VAR][0].end(), 1.0f);
+  std::vector<float> stage(SL.total);
+  const int ids[3] = {GLOWK_CONV1_KERNEL, GLOWK_CONV2_KERNEL, GLOWK_CONV3_KERNEL};
+  const size_t offs[3] = {t.K1, t.K2, t.K3};
+  for (int w = 0; w < 3; ++w) {
+    std::vector<float>& ten = tmp.host[ids[w]][0];
+    if (ten.size() >= ((size_t)1 << 24)) return fail("repack map: tensor too large for exact index codes");
+    for (size_t i = 0; i < ten.size(); ++i) ten[i] = (float)(i + 1);
+    std::fill(stage.begin(), stage.end(), 0.0f);
+    double ldc; float sc[8]; std::string err;
+    if (!pack_step(cfg, tmp, 0, stage.data(), &ldc, sc, &err)) return fail("repack map: " + err);
+    for (size_t i = lo; i < hi; ++i) {
+      if (i >= SL.ep && i < SL.R0p) continue;
+      const float v = stage[i];
+      if (v != 0.0f) {
+        if (map[i - lo] != -1) return fail("repack map: a packed position is written by two tensors");
+        map[i - lo] = (int)(offs[w] + (size_t)v - 1);
+      }
+    }
+    std::fill(ten.begin(), ten.end(), 0.0f);
+  }
+  *region_off = lo;
+  return 0;
+}
+
+int train_begin(glowk_handle* h) {
+  if (h->tr_active) return 0;
+  if (!h->finalized) return fail("glowk_finalize_weights has not been called");
+  if (h->tr_n == 0) train_layout(h);
+  if (!h->tr_params) {
+    HIPCHK(hipMalloc(&h->tr_params, h->tr_n * 4));
+    HIPCHK(hipMalloc(&h->tr_m, h->tr_n * 4));
+    HIPCHK(hipMalloc(&h->tr_v, h->tr_n * 4));
+    HIPCHK(hipMemset(h->tr_m, 0, h->tr_n * 4));
+    HIPCHK(hipMemset(h->tr_v, 0, h->tr_n * 4));
+    h->tr_map.assign(h->levels.size(), nullptr);
+    h->tr_map_n.assign(h->levels.size(), 0);
+    for (size_t l = 0; l < h->levels.size(); ++l) {
+      std::vector<int> map;
+      size_t lo;
+      if (int rc = build_repack_map(h, (int)l, map, &lo)) return rc;
+      HIPCHK(hipMalloc(&h->tr_map[l], map.size() * 4));
+      HIPCHK(hipMemcpy(h->tr_map[l], map.data(), map.size() * 4, hipMemcpyHostToDevice));
+      h->tr_map_n[l] = map.size();
+    }
+  }
+  std::vector<float> flat;
+  params_to_flat(h, flat);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(h->tr_params, flat.data(), h->tr_n * 4, hipMemcpyHostToDevice));
+  h->tr_active = true;
+  h->host_stale = false;
+  return 0;
+}
+
+// chain rule from the fused per-pixel affine v = u A + b (A = diag(e^ls) W, b = sh W, W = P Lm Um) to the reference's variables
+// (flow_tfp_bijectors.py:236-239, 289-303), fp64.  sums = [dA (c x c) | db (c)] = sum_q u^T g_v, sum_q g_v; the log-det terms
+// h w (sum ls + sum log_S) per sample add N h w to d/d ls_i and d/d log_S_i.  out: the step's [als | ash | L | logS | U] gradients.
+void affine_chain_rule(const Level& lv, int k, const double* sums, int N, double scale, float* out, const TrainOff& t) {
+  const int c = lv.c;
+  auto T = [&](int id) -> const float* { return lv.host[id][k].data(); };
+  const float *ls = T(GLOWK_ACTNORM_LOG_SCALE), *sh = T(GLOWK_ACTNORM_SHIFT), *P = T(GLOWK_INV1X1_P), *Lh = T(GLOWK_INV1X1_L), *Uh = T(GLOWK_INV1X1_U),
+              *sg = T(GLOWK_INV1X1_SIGN_S), *lS = T(GLOWK_INV1X1_LOG_S);
+  Mat Pm(c * c), Lm(c * c), Um(c * c);
+  for (int i = 0; i < c; ++i)
+    for (int j = 0; j < c; ++j) {
+      Pm[i * c + j] = P[i * c + j];
+      Lm[i * c + j] = (i > j) ? Lh[i * c + j] : (i == j ? 1.0 : 0.0);
+      Um[i * c + j] = (i < j) ? Uh[i * c + j] : (i == j ? (double)sg[i] * std::exp((double)lS[i]) : 0.0);
+    }
+  const Mat PL = matmul(Pm, Lm, c), W = matmul(PL, Um, c);
+  const double* dA = sums;
+  const double* db = sums + (size_t)c * c;
+  const double ld = (double)N * lv.h * lv.w;
+  Mat dW(c * c);
+  for (int i = 0; i < c; ++i) {
+    double dls = ld, dsh = 0.0;
+    const double e = std::exp((double)ls[i]);
+    for (int j = 0; j < c; ++j) {
+      dls += dA[i * c + j] * e * W[i * c + j];
+      dsh += db[j] * W[i * c + j];
+      dW[i * c + j] = e * dA[i * c + j] + (double)sh[i] * db[j];
+    }
+    out[t.als + i] = (float)(scale * dls);
+    out[t.ash + i] = (float)(scale * dsh);
+  }
+  // dLm = P^T dW Um^T ; dUm = (P Lm)^T dW
+  Mat Pt(c * c), Ut(c * c), PLt(c * c);
+  for (int i = 0; i < c; ++i)
+    for (int j = 0; j < c; ++j) { Pt[i * c + j] = Pm[j * c + i]; Ut[i * c + j] = Um[j * c + i]; PLt[i * c + j] = PL[j * c + i]; }
+  const Mat dLm = matmul(matmul(Pt, dW, c), Ut, c), dUm = matmul(PLt, dW, c);
+  for (int i = 0; i < c; ++i) {
+    for (int j = 0; j < c; ++j) {
+      out[t.L + i * c + j] = (i > j) ? (float)(scale * dLm[i * c + j]) : 0.0f;
+      out[t.U + i * c + j] = (i < j) ? (float)(scale * dUm[i * c + j]) : 0.0f;
+    }
+    out[t.logS + i] = (float)(scale * (dUm[i * c + i] * (double)sg[i] * std::exp((double)lS[i]) + ld));
+  }
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -1192,6 +1553,12 @@ int glowk_destroy(glowk_handle* h) {
   if (h->arena) hipFree(h->arena);
   if (h->d_flag) hipFree(h->d_flag);
   if (h->h_flag) hipHostFree(h->h_flag);
+  {
+    void* tr[] = {h->tr_params, h->tr_m, h->tr_v, h->trR1, h->trR2, h->trM1, h->trM2, h->trXcol, h->trGcol, h->trCpart, h->trC1, h->trC2, h->trC3,
+                  h->trT, h->trGv, h->trAffPart, h->trAffSum, h->trSmall};
+    for (void* p : tr) if (p) hipFree(p);
+    for (int* m : h->tr_map) if (m) hipFree(m);
+  }
   if (h->bufA) { hipFree(h->bufA); hipFree(h->bufB); hipFree(h->bufP); hipFree(h->bufZ); hipFree(h->bufLd); }
   if (h->bufC) hipFree(h->bufC);
   if (h->bufStat) hipFree(h->bufStat);
@@ -1218,6 +1585,8 @@ static std::vector<float>* locate(glowk_handle* h, int level, int step, int id) 
 
 int glowk_set_tensor(glowk_handle* h, int level, int step, int tensor_id, const float* host, size_t n) {
   if (!h || !host) return fail("null argument");
+  if (h->host_stale) { DeviceGuard dg(h->device); if (int rc = sync_host(h)) return rc; }
+  h->tr_active = false;      // the device master copy of a training run no longer holds the current parameters
   std::vector<float>* v = locate(h, level, step, tensor_id);
   if (!v) return fail("no such tensor");
   if (v->size() != n) return fail("tensor size mismatch: expected " + std::to_string(v->size()) + ", got " + std::to_string(n));
@@ -1228,6 +1597,7 @@ int glowk_set_tensor(glowk_handle* h, int level, int step, int tensor_id, const 
 
 int glowk_get_tensor(const glowk_handle* h, int level, int step, int tensor_id, float* host, size_t n) {
   if (!h || !host) return fail("null argument");
+  if (h->host_stale) { DeviceGuard dg(h->device); if (int rc = sync_host(const_cast<glowk_handle*>(h))) return rc; }
   const std::vector<float>* v = locate(const_cast<glowk_handle*>(h), level, step, tensor_id);
   if (!v) return fail("no such tensor");
   if (v->size() != n) return fail("tensor size mismatch");
@@ -1248,6 +1618,8 @@ int glowk_get_tensor(const glowk_handle* h, int level, int step, int tensor_id, 
 
 int glowk_finalize_weights(glowk_handle* h) {
   if (!h) return fail("null handle");
+  if (h->host_stale) { DeviceGuard dg0(h->device); if (int rc = sync_host(h)) return rc; }
+  h->split_stale = false;
   const glowk_config& cfg = h->cfg;
   for (const Level& lv : h->levels)
     if (lv.c != 4 && lv.c != 8 && lv.c != 16 && lv.c != 32)
@@ -1381,6 +1753,8 @@ int glowk_actnorm_data_init(glowk_handle* h, const float* x_dev, int N, int runt
   const int K = cfg.K, L = cfg.L;
   const size_t E = (size_t)cfg.H * cfg.W * cfg.C;
   if (int rc = ensure_c(h, N)) return rc;
+  if (h->host_stale) if (int rc = sync_host(h)) return rc;
+  h->tr_active = false;
   if (!h->bufStat) HIPCHK(hipMalloc(&h->bufStat, (size_t)(STAT_BLOCKS + 1) * 32 * 8));
   // y = SpecPreprocessing.forward(minibatch) (flow_builder.py:121), kept in bufZ
   hipLaunchKernelGGL(k_pre_only, dim3(N), dim3(256), 0, s, x_dev, (int)E, pre_args(cfg), 0, h->bufZ, (float*)nullptr, 0.0);
@@ -1744,6 +2118,141 @@ int glowk_coupling_net(glowk_handle* h, int level, int step, const float* xb_dev
     ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0; ca.flag = flagp(h);
     return launch_couple(lv.c, ca, N, s);
   });
+}
+
+size_t glowk_param_vector_size(glowk_handle* h) {
+  if (!h) return 0;
+  if (h->tr_n == 0) train_layout(h);
+  return h->tr_n;
+}
+
+int glowk_param_offset(glowk_handle* h, int level, int step, int tensor_id, size_t* offset, size_t* count) {
+  if (!h || !offset || !count) return fail("null argument");
+  if (h->tr_n == 0) train_layout(h);
+  if (tensor_id == GLOWK_PRIOR_LOC || tensor_id == GLOWK_PRIOR_LOG_SCALE) {
+    *offset = h->tr_prior_off + (tensor_id == GLOWK_PRIOR_LOG_SCALE ? pad4(h->prior_loc.size()) : 0);
+    *count = h->prior_loc.size();
+    return 0;
+  }
+  if (level < 0 || level >= h->cfg.L || step < 0 || step >= h->cfg.K) return fail("no such step");
+  size_t off;
+  if (!train_id_off(train_off(h->levels[level].c, h->cfg.F), h->cfg.F, tensor_id, &off)) return fail("tensor is not part of the parameter vector (frozen P, P_inv, sign_S)");
+  *offset = train_step_pos(h, level, step) + off;
+  *count = step_tensor_size(h->cfg, h->levels[level], tensor_id);
+  return 0;
+}
+
+int glowk_param_grad(glowk_handle* h, const float* x_dev, int N, float scale, float* logp_dev, float* grad_dev, void* stream) {
+  if (!h) return fail("null handle");
+  DeviceGuard dg(h->device);
+  if (!x_dev || !grad_dev) return fail("null tensor");
+  const int prec = h->precision;
+  h->precision = GLOWK_PREC_F32;       // the training sweep runs the exact kernels (see include/glowk.h)
+  struct Restore { glowk_handle* h; int p; ~Restore() { h->precision = p; } } restore{h, prec};
+  if (int rc = check_ready(h, N)) return rc;
+  if (int rc = train_begin(h)) return rc;
+  if (int rc = ensure_save(h, N)) return rc;
+  if (int rc = ensure_train(h, N)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const glowk_config& cfg = h->cfg;
+  float* z = h->bufGz;
+  HIPCHK(hipMemsetAsync(grad_dev, 0, h->tr_n * 4, s));
+  if (int rc = run_forward(h, x_dev, N, z, s, true)) return rc;
+  const int E = h->Hl * h->Wl * h->Cl;
+  if (logp_dev) {
+    hipLaunchKernelGGL(k_prior, dim3(N), dim3(256), 0, s, (const float*)z, E, h->d_loc, h->d_log_scale, (const double*)h->bufLd, logp_dev, (float*)nullptr);
+    LAUNCHCHK("k_prior");
+  }
+  if (cfg.learntop) {
+    hipLaunchKernelGGL(k_prior_wgrad, dim3((E + 255) / 256), dim3(256), 0, s, (const float*)z, N, E, h->d_loc, h->d_log_scale, scale,
+                       grad_dev + h->tr_prior_off, grad_dev + h->tr_prior_off + pad4((size_t)E));
+    LAUNCHCHK("k_prior_wgrad");
+  }
+  TrainCtx tc{grad_dev, scale};
+  // (the input gradient falls out of the sweep as well; the trainer has no use for it: it lands in the block-level scratch,
+  //  which is free again by the time the last kernel of the sweep writes it)
+  if (int rc = run_backward(h, x_dev, z, N, h->bufZ, s, &tc)) return rc;
+  // ActNorm / 1x1: the per-step sums come back once, the c x c chain rule runs on the host in fp64, the results go up in one copy
+  const size_t steps = (size_t)cfg.L * cfg.K;
+  std::vector<double> sums(steps * AFF_NOUT_MAX);
+  HIPCHK(hipMemcpyAsync(sums.data(), h->trAffSum, sums.size() * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  for (int lvl = 0; lvl < cfg.L; ++lvl) {
+    const Level& lv = h->levels[lvl];
+    const TrainOff t = train_off(lv.c, cfg.F);
+    const size_t small = t.K1;            // [als | ash | L | logS | U] (padded) sit at the head of the step block
+    std::vector<float> out((size_t)cfg.K * small, 0.0f);
+    for (int k = 0; k < cfg.K; ++k)
+      affine_chain_rule(lv, k, sums.data() + ((size_t)lvl * cfg.K + k) * AFF_NOUT_MAX, N, (double)scale, out.data() + (size_t)k * small, t);
+    HIPCHK(hipMemcpy2DAsync(grad_dev + h->tr_level_off[lvl], t.total * 4, out.data(), small * 4, small * 4, cfg.K, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));      // (out is a local)
+  }
+  return 0;
+}
+
+int glowk_apply_gradients(glowk_handle* h, const float* grad_dev, int optimizer, float lr, void* stream) {
+  if (!h) return fail("null handle");
+  DeviceGuard dg(h->device);
+  if (!grad_dev) return fail("null tensor");
+  if (optimizer != 0 && optimizer != 1) return fail("optimizer argument should be adam (0) or adamax (1)");   // train_utils.py:40
+  if (!h->tr_active) return fail("glowk_apply_gradients: no gradient has been computed for the current parameters (call glowk_param_grad first)");
+  hipStream_t s = (hipStream_t)stream;
+  const glowk_config& cfg = h->cfg;
+  const int F = cfg.F;
+  const double b1 = 0.9, b2 = 0.999;
+  h->tr_t += 1;
+  const double t = (double)h->tr_t;
+  const float lr_t = optimizer == 1 ? (float)(lr / (1.0 - std::pow(b1, t))) : (float)(lr * std::sqrt(1.0 - std::pow(b2, t)) / (1.0 - std::pow(b1, t)));
+  hipLaunchKernelGGL(k_optimizer, dim3((unsigned)((h->tr_n + 255) / 256)), dim3(256), 0, s, h->tr_params, grad_dev, h->tr_m, h->tr_v, h->tr_n, optimizer,
+                     lr_t, (float)b1, (float)b2, 1e-7f);
+  LAUNCHCHK("k_optimizer");
+  // ---- refresh what the exact-fp32 kernels read: conv images (device permutation), BatchNorm/bias block, fused affines, prior ----
+  for (int lvl = 0; lvl < cfg.L; ++lvl) {
+    Level& lv = h->levels[lvl];
+    const StepLayout SL = step_layout(lv.c, F);
+    const TrainOff t = train_off(lv.c, F);
+    const float* p0 = h->tr_params + h->tr_level_off[lvl];
+    float* img0 = h->arena + lv.dev[0].arena_off;
+    hipLaunchKernelGGL(k_repack_f32, dim3((unsigned)((h->tr_map_n[lvl] + 255) / 256), cfg.K), dim3(256), 0, s, (const int*)h->tr_map[lvl], h->tr_map_n[lvl],
+                       p0, t.total, img0 + SL.K1p, SL.total);
+    hipLaunchKernelGGL(k_fold_bn, dim3((F + 255) / 256, cfg.K), dim3(256), 0, s, p0 + t.b1, p0 + t.b2, p0 + t.bn, t.total, F, cfg.bn_eps, img0 + SL.ep, SL.total);
+    LAUNCHCHK("k_repack_f32");
+    // small tensors: down to the host (they parameterise the fp64 fold of ActNorm + 1x1), folded, back up
+    const size_t small = t.K1;
+    std::vector<float> sm((size_t)cfg.K * small), b3v((size_t)cfg.K * lv.c);
+    HIPCHK(hipMemcpy2DAsync(sm.data(), small * 4, p0, t.total * 4, small * 4, cfg.K, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpy2DAsync(b3v.data(), (size_t)lv.c * 4, p0 + t.b3, t.total * 4, (size_t)lv.c * 4, cfg.K, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const size_t tail = SL.total - SL.Afwd;
+    std::vector<float> blocks((size_t)cfg.K * tail), tmp(SL.total);
+    for (int k = 0; k < cfg.K; ++k) {
+      const float* src = sm.data() + (size_t)k * small;
+      const int c = lv.c;
+      std::memcpy(lv.host[GLOWK_ACTNORM_LOG_SCALE][k].data(), src + t.als, c * 4);
+      std::memcpy(lv.host[GLOWK_ACTNORM_SHIFT][k].data(), src + t.ash, c * 4);
+      std::memcpy(lv.host[GLOWK_INV1X1_L][k].data(), src + t.L, (size_t)c * c * 4);
+      std::memcpy(lv.host[GLOWK_INV1X1_LOG_S][k].data(), src + t.logS, c * 4);
+      std::memcpy(lv.host[GLOWK_INV1X1_U][k].data(), src + t.U, (size_t)c * c * 4);
+      std::memcpy(lv.host[GLOWK_CONV3_BIAS][k].data(), b3v.data() + (size_t)k * c, c * 4);
+      std::string err;
+      double ldc = 0;
+      if (!pack_affine(cfg, lv, k, tmp.data(), &ldc, &err)) return fail("level " + std::to_string(lvl) + " step " + std::to_string(k) + ": " + err);
+      h->ld_step[(size_t)lvl * cfg.K + k] = ldc;
+      std::memcpy(blocks.data() + (size_t)k * tail, tmp.data() + SL.Afwd, tail * 4);
+    }
+    HIPCHK(hipMemcpy2DAsync(img0 + SL.Afwd, SL.total * 4, blocks.data(), tail * 4, tail * 4, cfg.K, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  h->ld_const = 0.0;
+  for (double v : h->ld_step) h->ld_const += v;
+  if (cfg.learntop) {
+    const size_t E = h->prior_loc.size();
+    HIPCHK(hipMemcpyAsync(const_cast<float*>(h->d_loc), h->tr_params + h->tr_prior_off, E * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(const_cast<float*>(h->d_log_scale), h->tr_params + h->tr_prior_off + pad4(E), E * 4, hipMemcpyDeviceToDevice, s));
+  }
+  h->host_stale = true;
+  h->split_stale = true;
+  return 0;
 }
 
 int glowk_basis_update(float* x1_dev, float* x2_dev, const float* g1_dev, const float* g2_dev, const float* mixed_dev, size_t n,

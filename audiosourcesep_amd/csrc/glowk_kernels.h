@@ -53,6 +53,11 @@ struct NetArgs {
   float sc1, sc2, sc3;   // f16x3: 2^-S of the three layers' weight scales (sc3 also undoes the activation scale)
   int* flag;             // sticky range flag of the handle, or null
   float xlim;            // split kernels: raise the flag when a gathered input (times GLOWK_ACT_SCALE) exceeds this magnitude
+  // training (k_net_f32<..., STORE = true>): the two hidden tensors of this launch, PLANAR [F][Q] (the layout whose rows are the
+  // K-contiguous operands of the weight-gradient GEMMs, glowk_train.h).  Forward: st1 = relu(conv1 + b1), st2 = relu(conv2 + b2)
+  // (before BatchNorm); backward: st1 = mask2 * conv3^T(g_o) (gradient wrt relu2's output), st2 = mask1 * (K2 g_a2) (wrt relu1's)
+  float* st1;
+  float* st2;
 };
 
 // one 64-lane LDS-DMA piece: LDS destination = wave-uniform base + lane*16, global source per lane
@@ -134,10 +139,10 @@ __device__ __forceinline__ unsigned pick_word(const unsigned (&w)[N], int j) {
 // contribution of hidden block fi to the 16 accumulator tiles: small conv + epilogue first, then 256 MFMAs reading slot P,
 // with the DMA of the next chunk into slot P^1.  The small conv's A operands were published with the PREVIOUS chunk
 // (slot P^1, read before the barrier that frees it).
-template <int KIN, int NF, int P, int MODE>
+template <int KIN, int NF, int P, int MODE, bool STORE>
 __device__ __forceinline__ void net_step(const NetArgs& a, int fi, bool first, const float4* nsrc, float4* s0, float4* s1, float4* k1buf,
                                          const float* epl, const float (&xcol)[(9 * KIN) / 2], f32x16 (&acc2)[NF],
-                                         const unsigned (&mk)[NF / 2], size_t wblk, int wave, unsigned voff, int lane, int hh) {
+                                         const unsigned (&mk)[NF / 2], size_t wblk, int wave, unsigned voff, int lane, int hh, int q, bool qok) {
   using G = Ring1<KIN, NF>;
   constexpr int KS1 = G::KS1;
   constexpr int F = NF * 32;
@@ -176,7 +181,9 @@ __device__ __forceinline__ void net_step(const NetArgs& a, int fi, bool first, c
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int f = fi * 32 + mfma_row(r, hh);
-      h1[r] = ((w >> r) & 1u) ? h1[r] * epl[4 * F + f] : 0.0f;
+      const float m = ((w >> r) & 1u) ? h1[r] : 0.0f;
+      if (STORE && qok) a.st1[(size_t)f * a.Q + q] = m;
+      h1[r] = m * epl[4 * F + f];
     }
   } else {
     unsigned bits = 0;
@@ -185,7 +192,9 @@ __device__ __forceinline__ void net_step(const NetArgs& a, int fi, bool first, c
       const int f = fi * 32 + mfma_row(r, hh);
       const float pre = h1[r] + epl[f];
       if (MODE == NET_FWD_SAVE) bits |= (pre > 0.0f ? 1u : 0u) << r;
-      h1[r] = fmaf(epl[F + f], fmaxf(pre, 0.0f), epl[2 * F + f]);
+      const float rl = fmaxf(pre, 0.0f);
+      if (STORE && qok) a.st1[(size_t)f * a.Q + q] = rl;
+      h1[r] = fmaf(epl[F + f], rl, epl[2 * F + f]);
     }
     if (MODE == NET_FWD_SAVE) a.mask1[(wblk * NF + fi) * 64 + lane] = (unsigned short)bits;
   }
@@ -221,7 +230,7 @@ __device__ __forceinline__ void net_step(const NetArgs& a, int fi, bool first, c
 // issued while a DMA is in flight (hipcc would serialise each one behind the DMA with s_waitcnt vmcnt(0)).
 //   KIN   input channels of the small (3x3, K = 9*KIN) convolution: c/2 forward, c backward
 //   MOUT  rows of the per-tap output: 9*c forward (conv3), 9*c/2 backward (conv1^T)
-template <int KIN, int MOUT, int NF, int MODE>
+template <int KIN, int MOUT, int NF, int MODE, bool STORE = false>
 __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
   using G = Ring1<KIN, NF>;
   constexpr int KS1 = G::KS1;         // k-steps (k = 2) of the small conv's contraction over (tap, channel)
@@ -297,8 +306,8 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
 
 #pragma nounroll
   for (int fi = 0; fi < NF; fi += 2) {   // chunk fi lives in slot fi & 1 (NF is even)
-    net_step<KIN, NF, 0, MODE>(a, fi, fi == 0, ring + (size_t)(fi + 1) * SLOT4, slot0, slot1, k1buf, epl, xcol, acc2, mk2, wblk, wave, voff, lane, hh);
-    net_step<KIN, NF, 1, MODE>(a, fi + 1, false, ring + (size_t)(fi + 2) * SLOT4, slot0, slot1, k1buf, epl, xcol, acc2, mk2, wblk, wave, voff, lane, hh);
+    net_step<KIN, NF, 0, MODE, STORE>(a, fi, fi == 0, ring + (size_t)(fi + 1) * SLOT4, slot0, slot1, k1buf, epl, xcol, acc2, mk2, wblk, wave, voff, lane, hh, q, qok);
+    net_step<KIN, NF, 1, MODE, STORE>(a, fi + 1, false, ring + (size_t)(fi + 2) * SLOT4, slot0, slot1, k1buf, epl, xcol, acc2, mk2, wblk, wave, voff, lane, hh, q, qok);
   }
 
   // ---- epilogue on the 16 accumulator tiles, in place ----
@@ -309,7 +318,9 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int f = fo * 32 + mfma_row(r, hh);
-        acc2[fo][r] = ((w >> r) & 1u) ? acc2[fo][r] * epl[F + f] : 0.0f;
+        const float m = ((w >> r) & 1u) ? acc2[fo][r] : 0.0f;
+        if (STORE && qok) a.st2[(size_t)f * a.Q + q] = m;
+        acc2[fo][r] = m * epl[F + f];
       }
     } else {
       unsigned bits = 0;
@@ -318,7 +329,9 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
         const int f = fo * 32 + mfma_row(r, hh);
         const float pre = acc2[fo][r] + epl[3 * F + f];
         if (MODE == NET_FWD_SAVE) bits |= (pre > 0.0f ? 1u : 0u) << r;
-        acc2[fo][r] = fmaf(epl[4 * F + f], fmaxf(pre, 0.0f), epl[5 * F + f]);
+        const float rl = fmaxf(pre, 0.0f);
+        if (STORE && qok) a.st2[(size_t)f * a.Q + q] = rl;
+        acc2[fo][r] = fmaf(epl[4 * F + f], rl, epl[5 * F + f]);
       }
       if (MODE == NET_FWD_SAVE) a.mask2[(wblk * NF + fo) * 64 + lane] = (unsigned short)bits;
     }

@@ -431,6 +431,7 @@ struct BwdArgs {
   float* gu_out;           // [Q][C] g_y itself when no coupling follows
   int Q, h, w;
   int* flag;               // sticky range flag (see CoupleArgs); may be null
+  float* gv_out;           // training: [Q][C] the merged g_v of (1) (the weight gradients of step s's ActNorm + 1x1 need it), or null
 };
 
 template <int C>
@@ -501,6 +502,10 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
     } else {
 #pragma unroll
       for (int c = 0; c < C; ++c) gv[c] = a.gv_direct[(size_t)q * a.gvd_stride + a.gvd_off + c];
+    }
+    if (a.gv_out) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) a.gv_out[(size_t)q * C + c] = gv[c];
     }
     float gy[C];
     if (a.A) {

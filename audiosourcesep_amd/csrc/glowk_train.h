@@ -1,0 +1,356 @@
+// glowk device code, part 4: the training step's own kernels (train_glow.py:29-44: loss = sum(-log_prob) / global batch,
+// gradients wrt flow.trainable_variables, optimizer.apply_gradients).
+//
+// The data-gradient sweep of glowk_log_prob_grad already walks the steps in reverse; the training sweep adds, per step:
+//   1. k_net_f32<.., NET_FWD, STORE>   recompute the coupling network from the saved coupling input, storing
+//                                      R1 = relu(conv1 + b1), R2 = relu(conv2 + b2)           planar [F][Q]
+//   2. k_net_f32<.., NET_BWD, STORE>   the data-gradient kernel, also storing
+//                                      M2 = mask2 . conv3^T(g_o), M1 = mask1 . (K2 g_a2)       planar [F][Q]
+//   3. k_im2col_planar                 Xcol[(tap, ci)][q] = v_b[q + d(tap)][ci] (+ a row of ones), Gcol[(tap, co)][q] = g_o[q - d(tap)][co]
+//   4. k_wgrad_nt (x3)                 C = A . B^T over the pixel dimension on the fp32 MFMA, split-K, deterministic partials:
+//                                      C3 = [R2; 1] . Gcol^T   C2 = [R1; 1] . M2^T   C1 = M1 . [Xcol; 1]^T
+//   5. k_rowdot, k_assemble_*          BatchNorm gamma/beta, biases, and the per-channel factors that turn C1..C3 into dK1..dK3
+// Planar [channel][pixel] is the layout in which a channel row is K-contiguous for those GEMMs and in which the MFMA
+// accumulator tiles of k_net (row = channel in a register, column = pixel on the lane) store as 128-byte segments.
+// ActNorm / 1x1 gradients: k_affine_wgrad reduces dA = sum_q u^T g_v, db = sum_q g_v per step; the chain rule through
+// A = diag(e^ls) P L U, b = sh W is c x c algebra done by the host in fp64 (glowk.hip).  Optimizer: one elementwise kernel.
+#pragma once
+#include "glowk_kernels.h"
+#include "glowk_light.h"
+
+// ---- im2col in planar form -------------------------------------------------------------------------------------------
+// out[(tap * CH + ch)][q] = in[q + sgn * d(tap)][in_off + ch] inside the image, 0 outside; row 9 * CH (if ones) = 1
+__global__ __launch_bounds__(256) void k_im2col_planar(const float* __restrict__ in, int in_stride, int in_off, int CH, int Q, int h, int w,
+                                                      int sgn, int ones, float* __restrict__ out) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= Q) return;
+  const int hw = h * w, rem = q % hw, i = rem / w, j = rem % w;
+  for (int tap = 0; tap < 9; ++tap) {
+    const int dy = sgn * (tap / 3 - 1), dx = sgn * (tap % 3 - 1);
+    const int ii = i + dy, jj = j + dx;
+    const bool ok = ii >= 0 && ii < h && jj >= 0 && jj < w;
+    const float* src = in + (size_t)(q + dy * w + dx) * in_stride + in_off;
+    for (int ch = 0; ch < CH; ++ch) out[(size_t)(tap * CH + ch) * Q + q] = ok ? src[ch] : 0.0f;
+  }
+  if (ones) out[(size_t)(9 * CH) * Q + q] = 1.0f;
+}
+
+// ---- weight-gradient GEMM:  Cpart[s][m][n] = sum_{k in slice s} A[m][k] * B[n][k] ---------------------------------------
+// A: [M][ldk], B: [N][ldk] row-major, K = the pixel dimension (contiguous).  a_ones: row M of A is an implicit row of ones
+// (so that C[M][n] = sum_k B[n][k]: the bias / BatchNorm-offset sums come out of the same GEMM).
+// One workgroup = a 64 x 64 tile of C over one K slice: 4 waves, each a 32 x 32 tile on v_mfma_f32_32x32x2_f32 (exact fp32
+// products: the gradients feed an optimizer, no reason to round them).  Tiles of 64 x 32 are staged k-major in LDS so that
+// an MFMA operand is one conflict-free ds_read_b32 per lane; the next tile's global loads are issued before the MFMAs of
+// the current one.  Split-K partials are written, not atomically added: the reduction order is fixed (bitwise repeatable).
+struct WgradArgs {
+  const float* A;
+  const float* B;
+  int M, N;          // rows of A / B actually stored
+  int a_ones;        // 1: an extra row M of ones
+  int K;             // pixels
+  int kslice;        // pixels per split (multiple of 32)
+  float* Cpart;      // [S][Mp][Np], Mp = M + a_ones, Np = N
+};
+
+__global__ __launch_bounds__(256) void k_wgrad_nt(WgradArgs a) {
+  __shared__ float As[2][32][65];
+  __shared__ float Bs[2][32][65];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64, s = blockIdx.z;
+  const int Mp = a.M + a.a_ones;
+  const long k_begin = (long)s * a.kslice;
+  const long k_end = k_begin + a.kslice < a.K ? k_begin + a.kslice : a.K;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  // loader: thread t brings rows (t >> 3) and (t >> 3) + 32 of both tiles, 4 consecutive k each
+  const int lr = tid >> 3, lk = (tid & 7) * 4;
+  float4 ra[2], rb[2];
+  const bool vec = (a.K & 3) == 0;
+  auto fetch = [&](long k0) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int m = m0 + lr + 32 * e, n = n0 + lr + 32 * e;
+      const long k = k0 + lk;
+      float4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+      if (vec) {            // K a multiple of 4: rows are 16-byte aligned and a float4 never straddles the end of a slice
+        if (k < k_end) {
+          if (m < a.M) va = *reinterpret_cast<const float4*>(a.A + (size_t)m * a.K + k);
+          else if (m == a.M && a.a_ones) va = float4{1.f, 1.f, 1.f, 1.f};
+          if (n < a.N) vb = *reinterpret_cast<const float4*>(a.B + (size_t)n * a.K + k);
+        }
+      } else {              // odd pixel counts (1 x 1 or 3 x 1 images at the last level): element by element
+        float ta[4], tb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool in = k + j < k_end;
+          ta[j] = !in ? 0.0f : m < a.M ? a.A[(size_t)m * a.K + k + j] : (m == a.M && a.a_ones) ? 1.0f : 0.0f;
+          tb[j] = (in && n < a.N) ? a.B[(size_t)n * a.K + k + j] : 0.0f;
+        }
+        va = float4{ta[0], ta[1], ta[2], ta[3]};
+        vb = float4{tb[0], tb[1], tb[2], tb[3]};
+      }
+      ra[e] = va; rb[e] = vb;
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int r = lr + 32 * e;
+      As[buf][lk + 0][r] = ra[e].x; As[buf][lk + 1][r] = ra[e].y; As[buf][lk + 2][r] = ra[e].z; As[buf][lk + 3][r] = ra[e].w;
+      Bs[buf][lk + 0][r] = rb[e].x; Bs[buf][lk + 1][r] = rb[e].y; Bs[buf][lk + 2][r] = rb[e].z; Bs[buf][lk + 3][r] = rb[e].w;
+    }
+  };
+  const int i32 = lane & 31, kh = lane >> 5;
+  if (k_begin < k_end) {
+    fetch(k_begin);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (long k0 = k_begin; k0 < k_end; k0 += 32) {
+      const bool more = k0 + 32 < k_end;
+      if (more) fetch(k0 + 32);
+#pragma unroll
+      for (int kk = 0; kk < 32; kk += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][kk + kh][wm * 32 + i32], Bs[buf][kk + kh][wn * 32 + i32], acc, 0, 0, 0);
+      if (more) stage(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  float* C = a.Cpart + (size_t)s * Mp * a.N;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + mfma_row(r, kh), n = n0 + wn * 32 + i32;
+    if (m < Mp && n < a.N) C[(size_t)m * a.N + n] = acc[r];
+  }
+}
+
+// sum of the split-K partials: C[e] = sum_s Cpart[s][e]  (fixed order)
+__global__ __launch_bounds__(256) void k_sum_parts(const float* __restrict__ part, int S, size_t n, float* __restrict__ out) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float t = 0.0f;
+  for (int s = 0; s < S; ++s) t += part[(size_t)s * n + e];
+  out[e] = t;
+}
+
+// the same for fp64 partials (k_affine_wgrad)
+__global__ __launch_bounds__(256) void k_sum_parts_f64(const double* __restrict__ part, int S, size_t n, double* __restrict__ out) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  double t = 0.0;
+  for (int s = 0; s < S; ++s) t += part[(size_t)s * n + e];
+  out[e] = t;
+}
+
+// out[f] = sum_q X[f][q] * Y[f][q]   (one workgroup per channel row; fp64 accumulation, fixed order)
+__global__ __launch_bounds__(256) void k_rowdot(const float* __restrict__ X, const float* __restrict__ Y, int Q, float* __restrict__ out) {
+  __shared__ double red[4];
+  const int f = blockIdx.x;
+  const float* x = X + (size_t)f * Q;
+  const float* y = Y + (size_t)f * Q;
+  double t = 0.0;
+  for (int q = threadIdx.x; q < Q; q += 256) t += (double)x[q] * (double)y[q];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) out[f] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
+// ---- gradients of one step's coupling network from the GEMM results ------------------------------------------------
+// Notation (flow_tfk_layers.py:73-84): r = relu(conv + b), h = g r + d with g = gamma / sqrt(var + eps), d = beta - mean g.
+//   C3 [F+1][9c]   = [R2; 1] Gcol^T        C2 [F+1][F] = [R1; 1] M2^T        C1 [F][9ci+1] = M1 [Xcol; 1]^T
+//   T1[f] = sum_q M1 R1,  T2[f] = sum_q M2 R2
+// and with  SM2[f] = C2[F][f] = sum_q M2,  SM1[f] = C1[f][9ci] = sum_q M1,  SG[k] = C3[F][k] = sum_q Gcol[k]:
+//   dK3[tap][f][co] = g2[f] C3[f][tap c + co] + d2[f] SG[tap c + co]        db3[co] = SG[4 c + co]   (centre tap: no border)
+//   SH2[f] = sum_q g_h2 = sum_{tap,co} K3[tap][f][co] SG[tap c + co]         dbeta2 = SH2    dgamma2 = (T2 - mean2 SH2) / sqrt(var2 + eps)
+//   dK2[f1][f2] = g2[f2] (g1[f1] C2[f1][f2] + d1[f1] SM2[f2])                db2[f2] = g2[f2] SM2[f2]
+//   SH1[f1] = sum_f2 K2[f1][f2] g2[f2] SM2[f2]                               dbeta1 = SH1    dgamma1 = (T1 - mean1 SH1) / sqrt(var1 + eps)
+//   dK1[tap][ci][f] = g1[f] C1[f][tap ci_n + ci]                             db1[f] = g1[f] SM1[f]
+// Every gradient is multiplied by `scale` (= -1 / global batch: the loss is the mean negative log-likelihood).
+struct StepGradArgs {
+  int F, c;
+  const float* K2;      // [F][F] parameters (reference layout)
+  const float* K3;      // [9][F][c]
+  const float* bn;      // [8][F]: gamma1, beta1, mean1, var1, gamma2, beta2, mean2, var2
+  float eps;
+  const float *C1, *C2, *C3, *T1, *T2;
+  float scale;
+  float *dK1, *db1, *dgamma1, *dbeta1, *dK2, *db2, *dgamma2, *dbeta2, *dK3, *db3;
+};
+
+__device__ __forceinline__ void bn_fold(const float* bn, int F, int layer, int f, float eps, float& g, float& d) {
+  const float* b = bn + (size_t)layer * 4 * F;
+  const double gd = (double)b[f] / sqrt((double)b[3 * F + f] + (double)eps);   // fp64 like the host packer (glowk.hip: pack_step): the
+  g = (float)gd;                                                                // device-refreshed images equal the host-packed ones bit for bit
+  d = (float)((double)b[F + f] - (double)b[2 * F + f] * gd);
+}
+
+// grid: enough blocks of 256 threads to cover max(F * F, 9 * F * c, 9 * ci * F); per-channel vectors by the first F threads
+__global__ __launch_bounds__(256) void k_assemble_step_grads(StepGradArgs a) {
+  const int F = a.F, c = a.c, ci = c / 2, N1 = 9 * ci + 1, N3 = 9 * c;
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < (size_t)F * F) {
+    const int f1 = (int)(e / F), f2 = (int)(e % F);
+    float g1, d1, g2, d2;
+    bn_fold(a.bn, F, 0, f1, a.eps, g1, d1);
+    bn_fold(a.bn, F, 1, f2, a.eps, g2, d2);
+    a.dK2[e] = a.scale * g2 * (g1 * a.C2[(size_t)f1 * F + f2] + d1 * a.C2[(size_t)F * F + f2]);
+  }
+  if (e < (size_t)9 * F * c) {
+    const int tap = (int)(e / ((size_t)F * c)), f = (int)((e / c) % F), co = (int)(e % c);
+    float g2, d2;
+    bn_fold(a.bn, F, 1, f, a.eps, g2, d2);
+    a.dK3[e] = a.scale * (g2 * a.C3[(size_t)f * N3 + tap * c + co] + d2 * a.C3[(size_t)F * N3 + tap * c + co]);
+  }
+  if (e < (size_t)9 * ci * F) {
+    const int k = (int)(e / F), f = (int)(e % F);       // dK1 [tap][ci][F] flattened as [(tap, ci)][F]
+    float g1, d1;
+    bn_fold(a.bn, F, 0, f, a.eps, g1, d1);
+    a.dK1[e] = a.scale * g1 * a.C1[(size_t)f * N1 + k];
+  }
+  if (e < (size_t)F) {
+    const int f = (int)e;
+    float g1, d1, g2, d2;
+    bn_fold(a.bn, F, 0, f, a.eps, g1, d1);
+    bn_fold(a.bn, F, 1, f, a.eps, g2, d2);
+    double sh2 = 0.0;
+    for (int k = 0; k < N3; ++k) sh2 += (double)a.K3[((size_t)(k / c) * F + f) * c + (k % c)] * (double)a.C3[(size_t)F * N3 + k];
+    double sh1 = 0.0;
+    for (int f2 = 0; f2 < F; ++f2) {
+      float gg, dd;
+      bn_fold(a.bn, F, 1, f2, a.eps, gg, dd);
+      sh1 += (double)a.K2[(size_t)f * F + f2] * (double)gg * (double)a.C2[(size_t)F * F + f2];
+    }
+    const float* b1 = a.bn;
+    const float* b2 = a.bn + (size_t)4 * F;
+    a.db2[f] = a.scale * g2 * a.C2[(size_t)F * F + f];
+    a.dbeta2[f] = a.scale * (float)sh2;
+    a.dgamma2[f] = a.scale * (float)(((double)a.T2[f] - (double)b2[2 * F + f] * sh2) / sqrt((double)b2[3 * F + f] + (double)a.eps));
+    a.db1[f] = a.scale * g1 * a.C1[(size_t)f * N1 + 9 * ci];
+    a.dbeta1[f] = a.scale * (float)sh1;
+    a.dgamma1[f] = a.scale * (float)(((double)a.T1[f] - (double)b1[2 * F + f] * sh1) / sqrt((double)b1[3 * F + f] + (double)a.eps));
+  }
+  if (e < (size_t)c) a.db3[e] = a.scale * a.C3[(size_t)F * N3 + 4 * c + e];
+}
+
+// ---- ActNorm + 1x1: the fused per-pixel affine v = u A + b.  part[block][c*c + c]: sum_q u_i g_j, sum_q g_j over the block's pixels
+// (u is not kept by the forward pass: u = v Ainv + binv)
+template <int C>
+__global__ __launch_bounds__(256) void k_affine_wgrad(const float* __restrict__ v, const float* __restrict__ gv, int Q, const float* __restrict__ Ainv,
+                                                     const float* __restrict__ binv, double* __restrict__ part) {
+  __shared__ float us[64][C + 1];
+  __shared__ float gs[64][C + 1];
+  constexpr int NOUT = C * C + C;
+  constexpr int PER = (NOUT + 255) / 256;
+  double acc[PER];
+#pragma unroll
+  for (int o = 0; o < PER; ++o) acc[o] = 0.0;
+  const int per_block = (Q + gridDim.x - 1) / gridDim.x;
+  const int q_begin = blockIdx.x * per_block, q_end = q_begin + per_block < Q ? q_begin + per_block : Q;
+  for (int q0 = q_begin; q0 < q_end; q0 += 64) {
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int q = q0 + threadIdx.x;
+      if (q < q_end) {
+        float x[C], u[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) x[k] = v[(size_t)q * C + k];
+        affine_cc<C>(Ainv, binv, x, u);
+#pragma unroll
+        for (int k = 0; k < C; ++k) { us[threadIdx.x][k] = u[k]; gs[threadIdx.x][k] = gv[(size_t)q * C + k]; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < C; ++k) { us[threadIdx.x][k] = 0.0f; gs[threadIdx.x][k] = 0.0f; }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < PER; ++o) {
+      const int idx = threadIdx.x + 256 * o;
+      if (idx < C * C) {
+        const int i = idx / C, j = idx % C;
+        float t = 0.0f;
+        for (int p = 0; p < 64; ++p) t = fmaf(us[p][i], gs[p][j], t);
+        acc[o] += (double)t;
+      } else if (idx < NOUT) {
+        const int j = idx - C * C;
+        float t = 0.0f;
+        for (int p = 0; p < 64; ++p) t += gs[p][j];
+        acc[o] += (double)t;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < PER; ++o) {
+    const int idx = threadIdx.x + 256 * o;
+    if (idx < NOUT) part[(size_t)blockIdx.x * NOUT + idx] = acc[o];
+  }
+}
+
+// ---- prior (flow_builder.py:131-139): d sum_n logN / d loc = sum_n (z - loc) / s^2,  d / d log s = sum_n ((z - loc)^2 / s^2 - 1)
+__global__ __launch_bounds__(256) void k_prior_wgrad(const float* __restrict__ z, int N, int E, const float* __restrict__ loc,
+                                                    const float* __restrict__ log_scale, float scale, float* __restrict__ dloc, float* __restrict__ dls) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  const float l = loc[e], v = log_scale[e], inv2 = expf(-2.0f * v);
+  double a = 0.0, b = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const float d = z[(size_t)n * E + e] - l;
+    a += (double)(d * inv2);
+    b += (double)(d * d * inv2 - 1.0f);
+  }
+  dloc[e] = scale * (float)a;
+  dls[e] = scale * (float)b;
+}
+
+// ---- optimizers (train_utils.py:23-41: tfk.optimizers.Adam(lr) / Adamax(lr), Keras defaults beta1 0.9, beta2 0.999, eps 1e-7)
+//   adamax:  m = b1 m + (1 - b1) g;  u = max(b2 u, |g|);  p -= lr / (1 - b1^t) * m / (u + eps)
+//   adam:    m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps)
+__global__ __launch_bounds__(256) void k_optimizer(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                  size_t n, int adamax, float lr_t, float b1, float b2, float eps) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const float ge = g[e];
+  const float me = b1 * m[e] + (1.0f - b1) * ge;
+  float ve;
+  if (adamax) {
+    ve = fmaxf(b2 * v[e], fabsf(ge));
+    p[e] -= lr_t * me / (ve + eps);
+  } else {
+    ve = b2 * v[e] + (1.0f - b2) * ge * ge;
+    p[e] -= lr_t * me / (sqrtf(ve) + eps);
+  }
+  m[e] = me;
+  v[e] = ve;
+}
+
+// ---- device-side refresh of the exact-fp32 kernel images after an optimizer step ---------------------------------------
+// img[i] = map[i] < 0 ? 0 : params[map[i]]: the packed images are permutations (with zero padding) of the three conv kernels;
+// the map is the host packer's own output on index-coded tensors, one map per level (glowk.hip: build_repack_map).
+__global__ __launch_bounds__(256) void k_repack_f32(const int* __restrict__ map, size_t n, const float* __restrict__ params, size_t param_stride,
+                                                   float* __restrict__ img, size_t img_stride) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int s = map[i];
+  if (s == -2) return;               // not a permutation of the conv kernels (the BatchNorm / bias block: k_fold_bn)
+  const size_t step = blockIdx.y;    // one grid row per step of the level
+  img[step * img_stride + i] = s < 0 ? 0.0f : params[step * param_stride + s];
+}
+
+// ep block of a step: [b1 | g1 | d1 | b2 | g2 | d2] from biases and BatchNorm tensors
+__global__ __launch_bounds__(256) void k_fold_bn(const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ bn, size_t param_stride,
+                                                int F, float eps, float* __restrict__ ep, size_t img_stride) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  const size_t po = (size_t)blockIdx.y * param_stride;
+  float* e = ep + (size_t)blockIdx.y * img_stride;
+  float g1, d1, g2, d2;
+  bn_fold(bn + po, F, 0, f, eps, g1, d1);
+  bn_fold(bn + po, F, 1, f, eps, g2, d2);
+  e[f] = b1[po + f]; e[F + f] = g1; e[2 * F + f] = d1;
+  e[3 * F + f] = b2[po + f]; e[4 * F + f] = g2; e[5 * F + f] = d2;
+}

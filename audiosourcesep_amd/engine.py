@@ -257,6 +257,37 @@ class GlowEngine:
             self._compute(self.lib.glowk_log_prob_grad(self.h, _ptr(x[a:b]), b - a, _ptr(lp[a:b]), _ptr(dx[a:b]), self._stream()))
         return lp, dx
 
+    # ---- training step (train_glow.py:29-44) ------------------------------------------------------------
+    @property
+    def param_vector_size(self):
+        return int(self.lib.glowk_param_vector_size(self.h))
+
+    def param_slice(self, name):
+        """(offset, count) of a named tensor in the flat parameter / gradient vector (glowk_param_offset)."""
+        level, step, tid = self._split_name(name)
+        off, cnt = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        _lib.check(self.lib.glowk_param_offset(self.h, level, step, tid, ctypes.byref(off), ctypes.byref(cnt)))
+        return int(off.value), int(cnt.value)
+
+    def param_grad(self, x, scale, grad=None):
+        """-> (log_prob [N], grad [param_vector_size]) with grad = scale * d sum_n log_prob(x_n) / d theta, exact fp32 kernels."""
+        x = self._in(x, self.data_shape)
+        n = x.shape[0]
+        if n > self.grad_max_tiles:
+            raise ValueError("param_grad takes at most %d tiles per call (split the batch and add the gradients)" % self.grad_max_tiles)
+        lp = self._new(n)
+        if grad is None:
+            grad = self._new(self.param_vector_size)
+        _lib.check(self.lib.glowk_param_grad(self.h, _ptr(x), n, float(scale), _ptr(lp), _ptr(grad), self._stream()))
+        return lp, grad
+
+    def apply_gradients(self, grad, optimizer="adamax", lr=1e-3):
+        opt = {"adam": 0, "adamax": 1}
+        if optimizer not in opt:
+            raise ValueError("optimizer argument should be adam or adamax")      # train_utils.py:40
+        _lib.check(self.lib.glowk_apply_gradients(self.h, _ptr(grad), opt[optimizer], float(lr), self._stream()))
+        self._finalized = True
+
     def sample_from_eps(self, eps):
         eps = self._in(eps, self.cfg.latent_shape())
         n = eps.shape[0]

@@ -202,6 +202,20 @@ class GlowFlow:
         eps = torch.randn((int(n),) + tuple(self.cfg.latent_shape()), device=self.engine.device, dtype=torch.float32, generator=g)
         return self.engine.sample_from_eps(eps)
 
+    def train_step(self, x, optimizer="adamax", lr=1e-3, global_batch_size=None, group=None, noise_std=0.0, seed=0, step=0):
+        """One step of train_glow.py's ``distributed_train_step`` (:37-54) on this rank's tiles ``x``: loss =
+        sum(-log_prob(x)) / global_batch_size, gradients wrt ``trainable_variables``, summed over the ranks of ``group``
+        (one all-reduce of the flat gradient vector), ``optimizer.apply_gradients``.  ``noise_std`` > 0 adds N(0, noise_std^2) to
+        the tiles first (train_noisy_glow.py:31: the noise-conditioned priors of BASIS), drawn by the engine's device RNG from
+        the stream (seed, step).  Returns the global loss (fp64 scalar tensor)."""
+        from ..distributed import distributed_train_step
+        x = self.engine._in(x, self.engine.data_shape)
+        if noise_std:
+            from ..basis import device_randn
+            x = x + float(noise_std) * device_randn(tuple(x.shape), x.device, seed, step, which=2)
+        gb = int(global_batch_size) if global_batch_size else x.shape[0]
+        return distributed_train_step(self.engine.param_grad, lambda g: self.engine.apply_gradients(g, optimizer, lr), x, gb, group=group)
+
     def set_precision(self, precision):
         """``"f32"`` (exact fp32 MFMA) or ``"f16x3"`` (error-compensated fp16 split) for every later call."""
         modes = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3, "f16x2": _lib.PREC_F16X2}

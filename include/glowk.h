@@ -198,6 +198,27 @@ int glowk_step_inverse(glowk_handle* h, int level, int step, const float* y_dev,
 /* ShiftAndLogScaleConvNet.call (flow_tfk_layers.py:73-84) of one step: xb [N,h,w,c/2] -> log_s, t [N,h,w,c/2] */
 int glowk_coupling_net(glowk_handle* h, int level, int step, const float* xb_dev, int N, float* log_s_dev, float* t_dev, void* stream);
 
+/* --- training step (train_glow.py:29-44, train_noisy_glow.py:31-44) -------------------------------------------------------
+ * The reference's train_step is  loss = sum(-flow.log_prob(X)) / global_batch;  gradients = tape.gradient(loss,
+ * flow.trainable_variables);  optimizer.apply_gradients(...)  under MirroredStrategy (per-replica gradients summed by an
+ * all-reduce).  Here: glowk_param_grad fills ONE flat fp32 vector with  scale * d sum_n log_prob(x_n) / d theta  for this rank's
+ * tiles (scale = -1 / global batch), the caller all-reduces that vector across ranks (RCCL; torch.distributed in the mirror),
+ * glowk_apply_gradients takes the optimizer step on the engine's device-resident master copy of the parameters and refreshes
+ * the packed kernel images on the device.  The training sweep always runs the exact fp32 kernels, whatever glowk_set_precision
+ * says (the split kernels' images are re-packed lazily, by the host, at the next split-precision call).
+ * Layout of the vector: glowk_param_offset.  It holds every tf.Variable of the flow except the frozen P, P_inv, sign_S; the
+ * BatchNorm moving mean / variance (non-trainable, never updated by the reference: the layers are called without training=)
+ * are carried with zero gradient. */
+size_t glowk_param_vector_size(glowk_handle* h);
+/* where tensor `tensor_id` of (level, step) -- or a prior tensor (level, step ignored) -- sits in the vector */
+int glowk_param_offset(glowk_handle* h, int level, int step, int tensor_id, size_t* offset, size_t* count);
+/* x [N,H,W,C] -> grad_dev [glowk_param_vector_size] (overwritten) and, if logp_dev != NULL, log_prob [N].  Synchronises the
+ * stream (the ActNorm / 1x1 chain rule is c x c fp64 algebra on the host). */
+int glowk_param_grad(glowk_handle* h, const float* x_dev, int N, float scale, float* logp_dev, float* grad_dev, void* stream);
+/* one optimizer step: optimizer 0 = Adam, 1 = Adamax (train_utils.py:23-41; Keras defaults beta_1 0.9, beta_2 0.999, epsilon 1e-7).
+ * glowk_get_tensor / flow.variables see the new values. */
+int glowk_apply_gradients(glowk_handle* h, const float* grad_dev, int optimizer, float lr, void* stream);
+
 /* --- BASIS: the annealed-Langevin update around two log_prob_grad calls (run_basis_sep.py:152-181, dB branch) ------------- */
 /* One step of basis_inner_loop for two sources, in place, as ONE kernel:
  *     mix = g(x1, x2) (:133-141),  (m1, m2) = grad_g(x1, x2) (:143-147),

@@ -76,3 +76,50 @@ def test_test_step_without_process_group():
     np.testing.assert_allclose(distributed_test_step(_oracle_log_prob, x, 3).item(), -ref.mean(), rtol=1e-6)
     with pytest.raises(ValueError):
         distributed_test_step(_oracle_log_prob, x, 0)
+
+
+def _train_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from audiosourcesep_amd.distributed import distributed_train_step, shard_bounds
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    x = torch.randn(11, 6, dtype=torch.float32)                   # 11 "tiles": ragged over 2 and 3 ranks
+    theta = torch.linspace(-1, 1, 6)
+
+    def param_grad(xl, scale):   # stand-in for GlowEngine.param_grad: log_prob_n = -0.5 |x_n - theta|^2
+        d = xl - theta
+        return -0.5 * (d * d).sum(1), scale * d.sum(0)
+
+    applied = {}
+    a, b = shard_bounds(11, world, rank)
+    loss = distributed_train_step(param_grad, lambda g: applied.setdefault("g", g.clone()), x[a:b], 11)
+    lp_all, g_all = param_grad(x, -1.0 / 11)
+    q.put((rank, float(loss), float(-lp_all.sum() / 11), applied["g"].tolist(), g_all.tolist()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_gradients_sum_to_the_single_process_ones(world):
+    """train_glow.py:37-54 over batch shards: per-rank gradients of the pre-scaled loss, all-reduced, equal the gradient of the
+    whole batch in one process; every rank applies the same vector and sees the same global loss."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, loss, loss_ref, g, g_ref in res:
+        assert abs(loss - loss_ref) < 1e-6 * abs(loss_ref)
+        np.testing.assert_allclose(g, g_ref, rtol=1e-5, atol=1e-6)
+    assert len({tuple(r[3]) for r in res}) == 1          # bit-identical on every rank

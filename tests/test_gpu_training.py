@@ -1,0 +1,172 @@
+"""GPU tests of the training step (train_glow.py:29-44): every parameter gradient of the mean negative
+log-likelihood against the fp64 autograd of the torch oracle, the optimizer step against the Keras Adamax / Adam formulas, the
+device-side refresh of the packed kernel images against the oracle evaluated on the updated variables, and a short loop."""
+import numpy as np
+import pytest
+import torch
+
+from audiosourcesep_amd import _lib
+from audiosourcesep_amd.config import GlowConfig
+from audiosourcesep_amd.flow_models.flow_glow import GlowFlow
+from audiosourcesep_amd.synthetic import synthetic_mel_tiles, calibrated_engine
+from oracle import glowref as R
+from oracle import glowref_torch as RT
+
+pytestmark = pytest.mark.gpu
+
+TRAINABLE = ("actnorm/log_scale", "actnorm/shift", "inv1x1/L", "inv1x1/log_S", "inv1x1/U", "nn/conv1/kernel", "nn/conv1/bias",
+             "nn/bn1/gamma", "nn/bn1/beta", "nn/conv2/kernel", "nn/conv2/bias", "nn/bn2/gamma", "nn/bn2/beta", "nn/conv3/kernel",
+             "nn/conv3/bias", "prior/loc", "prior/log_scale")
+FROZEN_IN_VECTOR = ("nn/bn1/mean", "nn/bn1/var", "nn/bn2/mean", "nn/bn2/var")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def oracle_param_grads(x, params, cfg, scale):
+    """d (scale * sum_n log_prob(x_n)) / d theta for every trainable tensor, fp64 reverse mode over oracle/glowref_torch.py."""
+    p = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=k.split("/", 2)[-1] in TRAINABLE or k in TRAINABLE)
+         for k, v in params.items()}
+    lp, _ = RT.log_prob(torch.from_numpy(x.astype(np.float64)), p, cfg.as_dict())
+    names = [k for k, v in p.items() if v.requires_grad]
+    grads = torch.autograd.grad(scale * lp.sum(), [p[k] for k in names], allow_unused=True)
+    return lp.detach().numpy(), {k: (g.numpy() if g is not None else np.zeros_like(params[k], dtype=np.float64)) for k, g in zip(names, grads)}
+
+
+def engine_grads(eng, params, x, scale):
+    lp, g = eng.param_grad(dev(x), scale)
+    g = g.cpu().numpy()
+    out = {}
+    for name in params:
+        if name.endswith(("inv1x1/P", "inv1x1/P_inv", "inv1x1/sign_S")):
+            continue
+        off, cnt = eng.param_slice(name)
+        out[name] = g[off:off + cnt].reshape(np.asarray(params[name]).shape)
+    return lp.cpu().numpy(), out, g
+
+
+CASES = {
+    "L2_K2_F128": (GlowConfig(H=16, W=16, C=1, L=2, K=2, F=128), 5),
+    "L3_K2_F128_rect": (GlowConfig(H=16, W=32, C=1, L=3, K=2, F=128), 3),
+    "L2_K3_F256_notop": (GlowConfig(H=16, W=16, C=1, L=2, K=3, F=256, learntop=False), 4),
+    "L4_K1_F128": (GlowConfig(H=16, W=16, C=1, L=4, K=1, F=128), 3),
+    "configB_shape_K2": (GlowConfig(H=64, W=64, C=1, L=3, K=2, F=512), 3),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_parameter_gradients_match_fp64_autograd(name):
+    cfg, n = CASES[name]
+    eng, params = calibrated_engine(cfg, device=0, init_tiles=8)
+    x = synthetic_mel_tiles(n, cfg, seed=17)
+    scale = -1.0 / 32.0                                     # loss = sum(-log_prob) / global batch (train_glow.py:29-31), global batch 32
+    lp_ref, ref = oracle_param_grads(x, params, cfg, scale)
+    lp, got, flat = engine_grads(eng, params, x, scale)
+    np.testing.assert_allclose(lp, lp_ref, rtol=1e-6)
+    worst = {}
+    for k, r in ref.items():
+        g = got[k]
+        denom = max(np.abs(r).max(), 1e-12)
+        worst[k.split("/", 2)[-1] if k[0] == "b" else k] = max(worst.get(k, 0.0), float(np.abs(g - r).max() / denom))
+        # fp32 kernels, sums over up to 12 288 pixels: a few 1e-5 of the tensor's largest entry; 2e-4 asserted
+        np.testing.assert_allclose(g, r, atol=2e-4 * denom, rtol=2e-3, err_msg=k)
+    print(name, "worst |g - fp64| / max|g| per tensor kind:", {k: "%.1e" % v for k, v in sorted(worst.items())})
+    # non-trainable entries of the vector carry zero gradient; nothing else is in it
+    used = np.zeros(flat.shape, bool)
+    for k in params:
+        if k.endswith(("inv1x1/P", "inv1x1/P_inv", "inv1x1/sign_S")):
+            continue
+        off, cnt = eng.param_slice(k)
+        if k.split("/", 2)[-1] in FROZEN_IN_VECTOR or (not cfg.learntop and k.startswith("prior/")):
+            assert not flat[off:off + cnt].any(), k
+        used[off:off + cnt] = True
+    assert not flat[~used].any()
+    # repeatable bit for bit (fixed-order split-K sums, no atomics)
+    _, _, flat2 = engine_grads(eng, params, x, scale)
+    assert np.array_equal(flat, flat2)
+
+
+def keras_update(opt, p, g, m, v, t, lr):
+    b1, b2, eps = 0.9, 0.999, 1e-7
+    m = b1 * m + (1 - b1) * g
+    if opt == "adamax":
+        v = np.maximum(b2 * v, np.abs(g))
+        p = p - lr / (1 - b1 ** t) * m / (v + eps)
+    else:
+        v = b2 * v + (1 - b2) * g * g
+        p = p - lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t) * m / (np.sqrt(v) + eps)
+    return p, m, v
+
+
+@pytest.mark.parametrize("opt", ["adamax", "adam"])
+def test_optimizer_step_and_image_refresh(opt):
+    """Two optimizer steps: the variables follow the Keras formulas on the engine's own gradients, and -- the part that
+    exercises the device-side re-packing of the kernel images and the re-folded ActNorm + 1x1 -- log_prob / inverse / the input
+    gradient of the updated flow equal the fp64 oracle evaluated on the variables the flow reports, in every arithmetic."""
+    cfg = GlowConfig(H=16, W=32, C=1, L=3, K=2, F=128)
+    eng, params = calibrated_engine(cfg, device=0, init_tiles=8)
+    flow = GlowFlow(eng)
+    x = synthetic_mel_tiles(6, cfg, seed=23)
+    lr = 2e-3
+    state = {k: (np.zeros_like(v, dtype=np.float64), np.zeros_like(v, dtype=np.float64)) for k, v in params.items()}
+    cur = {k: np.asarray(v, dtype=np.float64) for k, v in params.items()}
+    with pytest.raises(ValueError):
+        eng.apply_gradients(torch.zeros(eng.param_vector_size, device="cuda"), optimizer="sgd")
+    for t in (1, 2):
+        _, got, flat = engine_grads(eng, cur, x, -1.0 / 6.0)
+        eng.apply_gradients(dev(flat), optimizer=opt, lr=lr)
+        sd = flow.state_dict()
+        for k, g in got.items():
+            m, v = state[k]
+            cur[k], m, v = keras_update(opt, cur[k], g.astype(np.float64), m, v, t, lr)
+            state[k] = (m, v)
+            np.testing.assert_allclose(sd[k], cur[k], rtol=2e-5, atol=2e-6, err_msg="%s step %d" % (k, t))
+        for k in params:
+            if k.endswith(("inv1x1/P", "inv1x1/sign_S", "bn1/mean", "bn1/var", "bn2/mean", "bn2/var")):
+                np.testing.assert_array_equal(sd[k], np.asarray(params[k], dtype=np.float32), err_msg=k)   # frozen
+        assert np.abs(sd["b0/s0/nn/conv2/kernel"] - params["b0/s0/nn/conv2/kernel"]).max() > 1e-4          # it did move
+        cur = {k: np.asarray(v, dtype=np.float64) for k, v in sd.items()}     # continue from the fp32 values the engine holds
+    p64 = R.cast_params(flow.state_dict(), np.float64)
+    lp_ref, g_ref = RT.log_prob_and_grad(x.astype(np.float64), flow.state_dict(), cfg.as_dict())
+    lp32, z = eng.log_prob(dev(x), return_latent=True)
+    np.testing.assert_allclose(lp32.cpu().numpy(), lp_ref, rtol=1e-6)
+    np.testing.assert_allclose(eng.inverse(z).cpu().numpy(), x, atol=5e-3)
+    _, gx = eng.log_prob_grad(dev(x))
+    np.testing.assert_allclose(gx.cpu().numpy(), g_ref, atol=2e-4 * np.abs(g_ref).max(), rtol=2e-3)
+    # the split kernels' images are re-packed (host) on demand
+    eng.set_range_policy("error")
+    for prec, tol in ((_lib.PREC_F16X3, 2e-6), (_lib.PREC_F16X2, 5e-5)):
+        eng.set_precision(prec)
+        np.testing.assert_allclose(eng.log_prob(dev(x)).cpu().numpy(), lp_ref, rtol=tol)
+    # and training continues from there (the sweep itself always runs the exact kernels)
+    lp_t, _, _ = engine_grads(eng, cur, x, -1.0 / 6.0)
+    np.testing.assert_allclose(lp_t, lp_ref, rtol=1e-6)
+    assert R.log_prob(x.astype(np.float64), p64, cfg.as_dict()).shape == (6,)
+
+
+def test_short_training_loop_lowers_the_loss():
+    """train_glow.py's loop in miniature: the mean negative log-likelihood of a fixed batch falls under Adamax, set_tensor
+    between steps is honoured (the device master copy is re-uploaded), and the result survives a save / restore."""
+    cfg = GlowConfig(H=16, W=16, C=1, L=2, K=4, F=128)
+    eng, params = calibrated_engine(cfg, device=0, init_tiles=16)
+    flow = GlowFlow(eng)
+    x = dev(synthetic_mel_tiles(32, cfg, seed=31))
+    losses = []
+    for it in range(12):
+        lp, g = eng.param_grad(x, -1.0 / 32.0)
+        losses.append(float(-lp.mean()))
+        eng.apply_gradients(g, optimizer="adamax", lr=1e-3)
+    assert np.isfinite(losses).all() and losses[-1] < losses[0] - 1.0, losses
+    assert all(b < a + 0.5 for a, b in zip(losses, losses[1:])), losses
+    lp_after = flow.log_prob(x)
+    assert abs(float(-lp_after.mean()) - losses[-1]) < abs(losses[-1] - losses[-2]) + 5.0
+    sd = flow.state_dict()
+    other = GlowFlow(calibrated_engine(cfg, device=0, init_tiles=16)[0])
+    other.load_state_dict(sd)
+    assert torch.equal(other.log_prob(x), lp_after)
+    # a variable assigned by hand between steps is what the next step differentiates
+    v = [v for v in flow.variables if v.name == "b1/s0/nn/conv3/bias"][0]
+    v.assign(v.numpy() + 0.25)
+    lp2, _ = eng.param_grad(x, -1.0 / 32.0)
+    assert torch.equal(lp2, flow.log_prob(x)) and not torch.equal(lp2, lp_after)
