@@ -131,6 +131,9 @@ struct glowk_handle {
   float *trC1 = nullptr, *trC2 = nullptr, *trC3 = nullptr, *trT = nullptr, *trGv = nullptr;
   double *trAffPart = nullptr, *trAffSum = nullptr;
   float* trSmall = nullptr;      // staging of the small (ActNorm / 1x1 / conv3-bias) parameters, device side
+  float* trKeep = nullptr;       // R1 | R2 of EVERY step, written by the saving forward pass itself when the memory is there (else recomputed per step)
+  std::vector<size_t> trKeepOff; // per forward-order step: offset of its R1 (R2 follows at + F Q), in floats per tile
+  int trKeepN = 0;
   // HIP-event profiler of k_net
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
@@ -965,7 +968,7 @@ int ensure_save(glowk_handle* h, int N) {
 
 // data -> latent (+ log-det accumulated in h->bufLd); z_dst [N,Hl,Wl,Cl].  save: keep every step's coupling input v,
 // per-tap conv3 outputs P and the two ReLU masks for run_backward.
-int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_t s, bool save = false) {
+int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_t s, bool save = false, bool keep_hidden = false) {
   const glowk_config& cfg = h->cfg;
   const int K = cfg.K, L = cfg.L, NF = cfg.F / 32;
   float* cur = save ? h->saveV + h->offV[0] : h->bufA;
@@ -993,7 +996,11 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
         na.mask2 = na.mask1 + blocks * NF * 64;
       }
       int np = 1;   // the f16x3 kernels leave P as np partial sums (one per pass over the hidden width)
-      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, save ? (h->precision == GLOWK_PREC_F32 ? NET_FWD_SAVE : 4) : fwd_mode(h), &np)) return rc;
+      if (keep_hidden) {   // training, exact fp32: this launch also leaves relu(conv1 + b1), relu(conv2 + b2) planar for the weight gradients
+        na.st1 = h->trKeep + h->trKeepOff[sidx] * (size_t)N;
+        na.st2 = na.st1 + (size_t)cfg.F * Q;
+      }
+      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, keep_hidden ? 9 : save ? (h->precision == GLOWK_PREC_F32 ? NET_FWD_SAVE : 4) : fwd_mode(h), &np)) return rc;
       if (save) h->save_parts[sidx] = np;
       CoupleArgs ca;
       ca.vin = cur; ca.P = na.P; ca.np = np; ca.pstride = na.pstride; ca.b3 = sd.b3; ca.logdet = h->bufLd; ca.log_s_out = nullptr; ca.t_out = nullptr;
@@ -1112,6 +1119,23 @@ int ensure_train(glowk_handle* h, int N) {
     HIPCHK(hipMalloc(&h->trAffPart, (size_t)AFF_BLOCKS * AFF_NOUT_MAX * 8));
     HIPCHK(hipMalloc(&h->trAffSum, (size_t)h->cfg.L * h->cfg.K * AFF_NOUT_MAX * 8));
   }
+  // R1 / R2 of all steps at once (4 KB per pixel and step at n_filters 512: 5.6 GB for 32 tiles of 64x64, K = 32, L = 3): kept
+  // by the saving forward pass when they fit a quarter of the free memory, otherwise every step re-runs its forward network
+  {
+    if (h->trKeep) { hipFree(h->trKeep); h->trKeep = nullptr; h->trKeepN = 0; }
+    size_t per_tile = 0;
+    h->trKeepOff.assign((size_t)h->cfg.L * h->cfg.K, 0);
+    for (int lvl = 0; lvl < h->cfg.L; ++lvl)
+      for (int j = 0; j < h->cfg.K; ++j) {
+        h->trKeepOff[(size_t)lvl * h->cfg.K + j] = per_tile;
+        per_tile += 2 * F * (size_t)h->levels[lvl].h * h->levels[lvl].w;
+      }
+    size_t free_b = 0, tot_b = 0;
+    if (hipMemGetInfo(&free_b, &tot_b) == hipSuccess && per_tile * N * 4 <= free_b / 4 && !getenv("GLOWK_TRAIN_RECOMPUTE")) {
+      HIPCHK(hipMalloc(&h->trKeep, per_tile * N * 4));
+      h->trKeepN = N;
+    }
+  }
   h->trN = N;
   return 0;
 }
@@ -1144,27 +1168,34 @@ int train_network_grads(glowk_handle* h, TrainCtx* tc, int lvl, int k, const flo
   const Level& lv = h->levels[lvl];
   const StepDev& sd = lv.dev[k];
   const int F = h->cfg.F, c = lv.c, ci = c / 2, Q = N * lv.h * lv.w;
-  // (1) recompute the forward network on the saved input, keeping R1 / R2 (its P output goes to a scratch partial of bufP)
-  NetArgs nf = net_args(h, lv, sd, v, c, ci, N);
-  nf.P = h->bufP + 2 * h->pstride; nf.st1 = h->trR1; nf.st2 = h->trR2;
-  if (launch_net_raw(c, F, nf, 7, s) < 0) return 1;
+  // (1) R1 / R2: kept by the saving forward pass, or recomputed now from the saved input (the P output of that launch goes to a
+  //     scratch partial of bufP)
+  const float *R1 = h->trR1, *R2 = h->trR2;
+  if (h->trKeep && N <= h->trKeepN) {
+    R1 = h->trKeep + h->trKeepOff[(size_t)lvl * h->cfg.K + (h->cfg.K - 1 - k)] * (size_t)N;   // (blocks are per tile: they scale with the batch)
+    R2 = R1 + (size_t)F * Q;
+  } else {
+    NetArgs nf = net_args(h, lv, sd, v, c, ci, N);
+    nf.P = h->bufP + 2 * h->pstride; nf.st1 = h->trR1; nf.st2 = h->trR2;
+    if (launch_net_raw(c, F, nf, 7, s) < 0) return 1;
+  }
   // (2) planar im2col operands
   hipLaunchKernelGGL(k_im2col_planar, dim3((Q + 255) / 256), dim3(256), 0, s, v, c, ci, ci, Q, lv.h, lv.w, 1, 1, h->trXcol);
   hipLaunchKernelGGL(k_im2col_planar, dim3((Q + 255) / 256), dim3(256), 0, s, g_o, c, 0, c, Q, lv.h, lv.w, -1, 0, h->trGcol);
   LAUNCHCHK("k_im2col_planar");
   // (3) the three GEMMs over the pixel dimension
-  if (int rc = launch_wgrad(h, h->trR2, F, 1, h->trGcol, 9 * c, Q, h->trC3, s)) return rc;
-  if (int rc = launch_wgrad(h, h->trR1, F, 1, h->trM2, F, Q, h->trC2, s)) return rc;
+  if (int rc = launch_wgrad(h, R2, F, 1, h->trGcol, 9 * c, Q, h->trC3, s)) return rc;
+  if (int rc = launch_wgrad(h, R1, F, 1, h->trM2, F, Q, h->trC2, s)) return rc;
   if (int rc = launch_wgrad(h, h->trM1, F, 0, h->trXcol, 9 * ci + 1, Q, h->trC1, s)) return rc;
-  hipLaunchKernelGGL(k_rowdot, dim3(F), dim3(256), 0, s, (const float*)h->trM1, (const float*)h->trR1, Q, h->trT);
-  hipLaunchKernelGGL(k_rowdot, dim3(F), dim3(256), 0, s, (const float*)h->trM2, (const float*)h->trR2, Q, h->trT + F);
+  hipLaunchKernelGGL(k_rowdot, dim3(F), dim3(256), 0, s, (const float*)h->trM1, R1, Q, h->trT);
+  hipLaunchKernelGGL(k_rowdot, dim3(F), dim3(256), 0, s, (const float*)h->trM2, R2, Q, h->trT + F);
   LAUNCHCHK("k_rowdot");
   // (4) assemble into the flat gradient vector
   const TrainOff t = train_off(c, F);
   const float* p = h->tr_params + train_step_pos(h, lvl, k);
   float* g = tc->grad + train_step_pos(h, lvl, k);
   StepGradArgs a;
-  a.F = F; a.c = c; a.K2 = p + t.K2; a.K3 = p + t.K3; a.bn = p + t.bn; a.eps = h->cfg.bn_eps;
+  a.F = F; a.c = c; a.K2 = p + t.K2; a.K3 = p + t.K3; a.bn = p + t.bn; a.ep = sd.ep; a.eps = h->cfg.bn_eps;
   a.C1 = h->trC1; a.C2 = h->trC2; a.C3 = h->trC3; a.T1 = h->trT; a.T2 = h->trT + F; a.scale = tc->scale;
   a.dK1 = g + t.K1; a.dK2 = g + t.K2; a.dK3 = g + t.K3; a.db1 = g + t.b1; a.db2 = g + t.b2; a.db3 = g + t.b3;
   a.dgamma1 = g + t.bn; a.dbeta1 = g + t.bn + F; a.dgamma2 = g + t.bn + 4 * (size_t)F; a.dbeta2 = g + t.bn + 5 * (size_t)F;
@@ -1555,7 +1586,7 @@ int glowk_destroy(glowk_handle* h) {
   if (h->h_flag) hipHostFree(h->h_flag);
   {
     void* tr[] = {h->tr_params, h->tr_m, h->tr_v, h->trR1, h->trR2, h->trM1, h->trM2, h->trXcol, h->trGcol, h->trCpart, h->trC1, h->trC2, h->trC3,
-                  h->trT, h->trGv, h->trAffPart, h->trAffSum, h->trSmall};
+                  h->trT, h->trGv, h->trAffPart, h->trAffSum, h->trSmall, h->trKeep};
     for (void* p : tr) if (p) hipFree(p);
     for (int* m : h->tr_map) if (m) hipFree(m);
   }
@@ -2157,7 +2188,7 @@ int glowk_param_grad(glowk_handle* h, const float* x_dev, int N, float scale, fl
   const glowk_config& cfg = h->cfg;
   float* z = h->bufGz;
   HIPCHK(hipMemsetAsync(grad_dev, 0, h->tr_n * 4, s));
-  if (int rc = run_forward(h, x_dev, N, z, s, true)) return rc;
+  if (int rc = run_forward(h, x_dev, N, z, s, true, h->trKeep && N <= h->trKeepN)) return rc;
   const int E = h->Hl * h->Wl * h->Cl;
   if (logp_dev) {
     hipLaunchKernelGGL(k_prior, dim3(N), dim3(256), 0, s, (const float*)z, E, h->d_loc, h->d_log_scale, (const double*)h->bufLd, logp_dev, (float*)nullptr);

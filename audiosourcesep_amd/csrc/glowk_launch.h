@@ -89,6 +89,7 @@ int launch_net_t(const NetArgs& a, int mode, hipStream_t s, bool dry) {
     // training (exact fp32 only): the same two kernels, also storing their hidden tensors planar (NetArgs::st1 / st2)
     case 7:            if (!dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD, true>), dim3(ntiles), dim3(256), 0, s, a); break;
     case 8:            if (!dry) hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD, true>), dim3(ntiles), dim3(256), 0, s, a); break;
+    case 9:            if (!dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE, true>), dim3(ntiles), dim3(256), 0, s, a); break;   // saving forward pass that keeps its hiddens
     case 3:   // f16x3 arithmetic: forward / forward with saves / backward; shapes without an instance run the exact fp32 kernel
       if (a.RSp && h3_shape16()) np = launch_h3s<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
       if (!np && a.RHp) np = launch_h3<CI, 18 * CI, NF, NET_FWD>(a, s, dry);

@@ -176,6 +176,7 @@ struct StepGradArgs {
   const float* K2;      // [F][F] parameters (reference layout)
   const float* K3;      // [9][F][c]
   const float* bn;      // [8][F]: gamma1, beta1, mean1, var1, gamma2, beta2, mean2, var2
+  const float* ep;      // [6][F]: b1, g1, d1, b2, g2, d2 -- the step's folded BatchNorm block as the kernels read it (k_fold_bn / pack_step)
   float eps;
   const float *C1, *C2, *C3, *T1, *T2;
   float scale;
@@ -192,45 +193,32 @@ __device__ __forceinline__ void bn_fold(const float* bn, int F, int layer, int f
 // grid: enough blocks of 256 threads to cover max(F * F, 9 * F * c, 9 * ci * F); per-channel vectors by the first F threads
 __global__ __launch_bounds__(256) void k_assemble_step_grads(StepGradArgs a) {
   const int F = a.F, c = a.c, ci = c / 2, N1 = 9 * ci + 1, N3 = 9 * c;
+  const float *g1 = a.ep + F, *d1 = a.ep + 2 * (size_t)F, *g2 = a.ep + 4 * (size_t)F, *d2 = a.ep + 5 * (size_t)F;
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e < (size_t)F * F) {
     const int f1 = (int)(e / F), f2 = (int)(e % F);
-    float g1, d1, g2, d2;
-    bn_fold(a.bn, F, 0, f1, a.eps, g1, d1);
-    bn_fold(a.bn, F, 1, f2, a.eps, g2, d2);
-    a.dK2[e] = a.scale * g2 * (g1 * a.C2[(size_t)f1 * F + f2] + d1 * a.C2[(size_t)F * F + f2]);
+    a.dK2[e] = a.scale * g2[f2] * (g1[f1] * a.C2[(size_t)f1 * F + f2] + d1[f1] * a.C2[(size_t)F * F + f2]);
   }
   if (e < (size_t)9 * F * c) {
     const int tap = (int)(e / ((size_t)F * c)), f = (int)((e / c) % F), co = (int)(e % c);
-    float g2, d2;
-    bn_fold(a.bn, F, 1, f, a.eps, g2, d2);
-    a.dK3[e] = a.scale * (g2 * a.C3[(size_t)f * N3 + tap * c + co] + d2 * a.C3[(size_t)F * N3 + tap * c + co]);
+    a.dK3[e] = a.scale * (g2[f] * a.C3[(size_t)f * N3 + tap * c + co] + d2[f] * a.C3[(size_t)F * N3 + tap * c + co]);
   }
   if (e < (size_t)9 * ci * F) {
     const int k = (int)(e / F), f = (int)(e % F);       // dK1 [tap][ci][F] flattened as [(tap, ci)][F]
-    float g1, d1;
-    bn_fold(a.bn, F, 0, f, a.eps, g1, d1);
-    a.dK1[e] = a.scale * g1 * a.C1[(size_t)f * N1 + k];
+    a.dK1[e] = a.scale * g1[f] * a.C1[(size_t)f * N1 + k];
   }
   if (e < (size_t)F) {
     const int f = (int)e;
-    float g1, d1, g2, d2;
-    bn_fold(a.bn, F, 0, f, a.eps, g1, d1);
-    bn_fold(a.bn, F, 1, f, a.eps, g2, d2);
     double sh2 = 0.0;
     for (int k = 0; k < N3; ++k) sh2 += (double)a.K3[((size_t)(k / c) * F + f) * c + (k % c)] * (double)a.C3[(size_t)F * N3 + k];
     double sh1 = 0.0;
-    for (int f2 = 0; f2 < F; ++f2) {
-      float gg, dd;
-      bn_fold(a.bn, F, 1, f2, a.eps, gg, dd);
-      sh1 += (double)a.K2[(size_t)f * F + f2] * (double)gg * (double)a.C2[(size_t)F * F + f2];
-    }
+    for (int f2 = 0; f2 < F; ++f2) sh1 += (double)a.K2[(size_t)f * F + f2] * (double)(g2[f2] * a.C2[(size_t)F * F + f2]);
     const float* b1 = a.bn;
     const float* b2 = a.bn + (size_t)4 * F;
-    a.db2[f] = a.scale * g2 * a.C2[(size_t)F * F + f];
+    a.db2[f] = a.scale * g2[f] * a.C2[(size_t)F * F + f];
     a.dbeta2[f] = a.scale * (float)sh2;
     a.dgamma2[f] = a.scale * (float)(((double)a.T2[f] - (double)b2[2 * F + f] * sh2) / sqrt((double)b2[3 * F + f] + (double)a.eps));
-    a.db1[f] = a.scale * g1 * a.C1[(size_t)f * N1 + 9 * ci];
+    a.db1[f] = a.scale * g1[f] * a.C1[(size_t)f * N1 + 9 * ci];
     a.dbeta1[f] = a.scale * (float)sh1;
     a.dgamma1[f] = a.scale * (float)(((double)a.T1[f] - (double)b1[2 * F + f] * sh1) / sqrt((double)b1[3 * F + f] + (double)a.eps));
   }

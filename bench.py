@@ -156,6 +156,15 @@ def secondary_workload(args, cfg, eng, params, rank, world, local_rank, dist):
         def step():
             eng.log_prob_grad(x)
         unit, metric, per_step = "tiles/s", "Glow log_prob + input-gradient tiles/sec", n
+    elif args.workload == "train":
+        # one step of train_glow.py:37-54: loss + all parameter gradients (exact fp32 kernels), ONE all-reduce of the flat gradient
+        # vector (RCCL), Adamax, device-side refresh of the kernel images
+        from audiosourcesep_amd.distributed import distributed_train_step
+        state = {}
+
+        def step():
+            state["loss"] = distributed_train_step(eng.param_grad, lambda g: eng.apply_gradients(g, "adamax", 1e-4), x, n * world)
+        unit, metric, per_step = "tiles/s", "Glow training step tiles/sec (loss + all gradients + Adamax)", n
     else:
         eng2, _ = calibrated_engine(cfg, device=local_rank, init_tiles=max(n, 64), seed=4048)
         eng2.set_precision(eng.get_precision())
@@ -185,6 +194,8 @@ def secondary_workload(args, cfg, eng, params, rank, world, local_rank, dist):
     elapsed = time.perf_counter() - t0
     if args.workload == "basis":
         assert torch.isfinite(state["y1"]).all() and torch.isfinite(state["y2"]).all(), "BASIS update left the finite range"
+    if args.workload == "train":
+        assert torch.isfinite(state["loss"]).all(), "training diverged"
     if dist is not None:
         t = torch.tensor([elapsed], device="cpu" if dist.get_backend() == "gloo" else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -193,8 +204,10 @@ def secondary_workload(args, cfg, eng, params, rank, world, local_rank, dist):
         print(json.dumps({
             "metric": metric, "value": per_step * world * args.steps / elapsed, "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.workload == "train" else args.precision, "data": "synthetic",
             "config": {"workload": "%s, %dx%dx%d tiles, L=%d K=%d n_filters=%d, %d tiles/GPU" % (args.workload, cfg.H, cfg.W, cfg.C, cfg.L, cfg.K, cfg.F, n)},
+            **({"param_vector_floats": eng.param_vector_size, "gflop_per_tile_fwd": cfg.flop_per_tile() / 1e9,
+                "tflops_at_4x_fwd_flops": per_step * world * args.steps / elapsed * 4 * cfg.flop_per_tile() / 1e12 / world} if args.workload == "train" else {}),
         }), flush=True)
     if dist is not None:
         dist.barrier()
@@ -237,8 +250,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="tiles per GPU per step")
     ap.add_argument("--config", default="B", choices=["A", "B", "YAML"])
-    ap.add_argument("--workload", default="log_prob", choices=["log_prob", "log_prob_grad", "basis"],
-                    help="log_prob = BASELINE.json's headline metric; the other two are secondary lines (SURVEY section 8f-1)")
+    ap.add_argument("--workload", default="log_prob", choices=["log_prob", "log_prob_grad", "basis", "train"],
+                    help="log_prob = BASELINE.json's headline metric; the others are secondary lines (SURVEY section 8f-1, 8f-3)")
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "f16x2"],
                     help="f16x3: error-compensated fp16 split on the fp16 MFMA (fp32-class accuracy, demonstrated in the line); "
                          "f32: exact fp32-input MFMA")
