@@ -94,6 +94,7 @@ SYMBOLS = {
     "glowk_param_offset": (_i, [_vp, _i, _i, _i, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     "glowk_param_grad": (_i, [_vp, _vp, _i, ctypes.c_float, _vp, _vp, _vp]),
     "glowk_apply_gradients": (_i, [_vp, _vp, _i, ctypes.c_float, _vp]),
+    "glowk_crc32c": (ctypes.c_uint32, [_vp, ctypes.c_size_t]),
     "glowk_basis_update": (_i, [_vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, _vp, _vp,
                                 ctypes.c_uint64, ctypes.c_uint64, _vp, _vp]),
     "glowk_basis_mix": (_i, [_vp, _vp, _vp, ctypes.c_size_t, _vp]),

@@ -2324,4 +2324,34 @@ int glowk_random(float* out_dev, size_t n, uint64_t seed, uint64_t step, int whi
   return 0;
 }
 
+uint32_t glowk_crc32c(const void* host_data, size_t n) {
+  static uint32_t table[8][256];
+  static std::atomic<bool> ready(false);
+  if (!ready.load(std::memory_order_acquire)) {
+    uint32_t t[8][256];
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+      t[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int s = 1; s < 8; ++s) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xFF];
+    std::memcpy(table, t, sizeof(t));      // (idempotent: concurrent first calls write the same bytes)
+    ready.store(true, std::memory_order_release);
+  }
+  const unsigned char* p = static_cast<const unsigned char*>(host_data);
+  uint32_t c = 0xFFFFFFFFu;
+  while (n >= 8) {                         // slicing-by-8
+    uint32_t lo, hi;
+    std::memcpy(&lo, p, 4);
+    std::memcpy(&hi, p + 4, 4);
+    lo ^= c;
+    c = table[7][lo & 0xFF] ^ table[6][(lo >> 8) & 0xFF] ^ table[5][(lo >> 16) & 0xFF] ^ table[4][lo >> 24] ^
+        table[3][hi & 0xFF] ^ table[2][(hi >> 8) & 0xFF] ^ table[1][(hi >> 16) & 0xFF] ^ table[0][hi >> 24];
+    p += 8; n -= 8;
+  }
+  while (n--) c = table[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+  return c ^ 0xFFFFFFFFu;
+}
+
 }  // extern "C"

@@ -255,6 +255,20 @@ class GlowFlow:
     def save(self, path):
         np.savez(path, **self.state_dict())
 
-    def restore(self, path):
+    def restore(self, path, order=None):
+        """``path``: an ``.npz`` written by ``save`` -- or the prefix of a TensorFlow checkpoint (``.../tf_ckpts/ckpt-21``, i.e. what
+        ``CheckpointManager`` of train_utils.py:62-75 wrote and run_basis_sep.py:28-38 restores): its tensor bundle is read without
+        TensorFlow and mapped through the derived ``flow.variables`` order (audiosourcesep_amd/tf_checkpoint.py; ``order``
+        overrides it)."""
+        import os
+        if os.path.exists(path + ".index"):
+            from ..tf_checkpoint import state_dict_from_checkpoint
+            self.load_state_dict(state_dict_from_checkpoint(path, self.cfg, order))
+            return
         with np.load(path) as f:
             self.load_state_dict({k: f[k] for k in f.files})
+
+    def save_tf(self, prefix, order=None):
+        """Write the variables as a TensorFlow tensor bundle under the reference's checkpoint keys (``variables/<i>/...``)."""
+        from ..tf_checkpoint import save_checkpoint_bundle
+        save_checkpoint_bundle(prefix, self.state_dict(), self.cfg, order)

@@ -237,6 +237,11 @@ int glowk_basis_mix(const float* x1_dev, const float* x2_dev, float* out_dev, si
  * U(0, 1) from the same stream instead of N(0, 1) (the chain's initial state, run_basis_sep.py:360-361) */
 int glowk_random(float* out_dev, size_t n, uint64_t seed, uint64_t step, int which, int uniform, void* stream);
 
+/* --- host utility ----------------------------------------------------------------------------------------------------------- */
+/* CRC-32C (Castagnoli) of a host buffer: the checksum of TFRecord frames (datasets/preprocessing.py:197-271) and of TensorFlow
+ * checkpoint bundles (train_utils.py:62-75), whose tensors are too large for an interpreted byte loop */
+uint32_t glowk_crc32c(const void* host_data, size_t n);
+
 #ifdef __cplusplus
 }
 #endif
