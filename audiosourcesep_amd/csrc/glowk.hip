@@ -484,7 +484,7 @@ void train_layout(glowk_handle* h) {
 }
 size_t train_step_pos(const glowk_handle* h, int lvl, int k) { return h->tr_level_off[lvl] + train_off(h->levels[lvl].c, h->cfg.F).total * (size_t)k; }
 
-constexpr int AFF_BLOCKS = 128;
+constexpr int AFF_BLOCKS = 32;
 constexpr size_t AFF_NOUT_MAX = 32 * 32 + 32;
 constexpr size_t CPART_FLOATS = (size_t)6 << 20;
 
@@ -511,7 +511,7 @@ int ensure_train(glowk_handle* h, int N) {
     HIPCHK(hipMalloc(&h->trC1, (size_t)F * (9 * 16 + 1) * 4));
     HIPCHK(hipMalloc(&h->trC2, (size_t)(F + 1) * F * 4));
     HIPCHK(hipMalloc(&h->trC3, (size_t)(F + 1) * 9 * 32 * 4));
-    HIPCHK(hipMalloc(&h->trT, (size_t)2 * F * 4));
+    HIPCHK(hipMalloc(&h->trT, ((size_t)2 * F + 64) * 4));   // T1 | T2 | 64 floats where ragged column blocks dump their stores
     HIPCHK(hipMalloc(&h->trAffPart, (size_t)AFF_BLOCKS * AFF_NOUT_MAX * 8));
     HIPCHK(hipMalloc(&h->trAffSum, (size_t)h->cfg.L * h->cfg.K * AFF_NOUT_MAX * 8));
   }
@@ -597,6 +597,7 @@ int train_network_grads(glowk_handle* h, TrainCtx* tc, int lvl, int k, const flo
   a.dgamma1 = g + t.bn; a.dbeta1 = g + t.bn + F; a.dgamma2 = g + t.bn + 4 * (size_t)F; a.dbeta2 = g + t.bn + 5 * (size_t)F;
   const size_t work = std::max({(size_t)F * F, (size_t)9 * F * c, (size_t)9 * ci * F});
   hipLaunchKernelGGL(k_assemble_step_grads, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_assemble_channel_grads, dim3(F), dim3(256), 0, s, a);
   LAUNCHCHK("k_assemble_step_grads");
   return 0;
 }

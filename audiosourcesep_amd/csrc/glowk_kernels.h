@@ -60,11 +60,31 @@ struct NetArgs {
   float* st2;
 };
 
+// planar store of one 32 x 32 accumulator tile of a hidden block (16 registers per lane: rows 0-3, 8-11, 16-19, 24-27, + 4 for the
+// upper lane half) into a [F][Q] array.  The block base is wave-uniform (SGPR pair), the lane's part a running 32-bit byte
+// offset: global_store_dword voffset, data, saddr.  Written as asm because hipcc turns the C form into sixteen hoisted
+// 64-bit per-lane addresses (1.9 KB of spills, each reload queued behind the weight DMA: the storing kernels ran 2x slower).
+__device__ __forceinline__ void st_tile_planar(float* blk_base, unsigned lane_byte, unsigned row_bytes, const f32x16& v) {
+  const unsigned long long base = reinterpret_cast<unsigned long long>(blk_base);
+  unsigned off = lane_byte;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(v[r]), "s"(base) : "memory");
+    off += ((r & 3) == 3 ? 5u : 1u) * row_bytes;
+  }
+}
+
 // one 64-lane LDS-DMA piece: LDS destination = wave-uniform base + lane*16, global source per lane
 __device__ __forceinline__ void glds16(const float4* src_lane, float4* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(GLOWK_GPTR(src_lane), GLOWK_LPTR(lds_wave_base), 16, 0, 0);
 }
 
+__device__ __forceinline__ float* uniform_fptr(float* p) {            // the same for a pointer stores go through
+  const unsigned long long b = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ const char* uniform_ptr(const void* p) {   // force a wave-uniform pointer into SGPRs
   const unsigned long long b = reinterpret_cast<unsigned long long>(p);
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
@@ -142,7 +162,7 @@ __device__ __forceinline__ unsigned pick_word(const unsigned (&w)[N], int j) {
 template <int KIN, int NF, int P, int MODE, bool STORE>
 __device__ __forceinline__ void net_step(const NetArgs& a, int fi, bool first, const float4* nsrc, float4* s0, float4* s1, float4* k1buf,
                                          const float* epl, const float (&xcol)[(9 * KIN) / 2], f32x16 (&acc2)[NF],
-                                         const unsigned (&mk)[NF / 2], size_t wblk, int wave, unsigned voff, int lane, int hh, int q, bool qok) {
+                                         const unsigned (&mk)[NF / 2], size_t wblk, int wave, unsigned voff, int lane, int hh, int q, bool qok, bool wok) {
   using G = Ring1<KIN, NF>;
   constexpr int KS1 = G::KS1;
   constexpr int F = NF * 32;
@@ -175,16 +195,17 @@ __device__ __forceinline__ void net_step(const NetArgs& a, int fi, bool first, c
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[ks * 64], xcol[ks], h1, 0, 0, 0);
   }
+  float* st_blk = STORE ? uniform_fptr(a.st1 + (size_t)fi * 32 * a.Q) : nullptr;                   // rows 32 fi .. of the planar array
+  const unsigned st_lane = STORE ? ((unsigned)(4 * hh) * (unsigned)a.Q + (unsigned)q) * 4u : 0u;   // this lane's pixel, row 4 hh
+  const unsigned st_row = (unsigned)a.Q * 4u;
   if (MODE == NET_BWD) {
     // g_a2 = g_h2 * g2 * [a2 + b2 > 0]
     const unsigned w = pick_word<NF / 2>(mk, fi >> 1) >> ((fi & 1) * 16);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int f = fi * 32 + mfma_row(r, hh);
-      const float m = ((w >> r) & 1u) ? h1[r] : 0.0f;
-      if (STORE && qok) a.st1[(size_t)f * a.Q + q] = m;
-      h1[r] = m * epl[4 * F + f];
-    }
+    for (int r = 0; r < 16; ++r) h1[r] = ((w >> r) & 1u) ? h1[r] : 0.0f;
+    if (STORE && qok) st_tile_planar(st_blk, st_lane, st_row, h1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h1[r] *= epl[4 * F + fi * 32 + mfma_row(r, hh)];
   } else {
     unsigned bits = 0;
 #pragma unroll
@@ -192,9 +213,13 @@ __device__ __forceinline__ void net_step(const NetArgs& a, int fi, bool first, c
       const int f = fi * 32 + mfma_row(r, hh);
       const float pre = h1[r] + epl[f];
       if (MODE == NET_FWD_SAVE) bits |= (pre > 0.0f ? 1u : 0u) << r;
-      const float rl = fmaxf(pre, 0.0f);
-      if (STORE && qok) a.st1[(size_t)f * a.Q + q] = rl;
-      h1[r] = fmaf(epl[F + f], rl, epl[2 * F + f]);
+      h1[r] = fmaxf(pre, 0.0f);
+    }
+    if (STORE && qok) st_tile_planar(st_blk, st_lane, st_row, h1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = fi * 32 + mfma_row(r, hh);
+      h1[r] = fmaf(epl[F + f], h1[r], epl[2 * F + f]);
     }
     if (MODE == NET_FWD_SAVE) a.mask1[(wblk * NF + fi) * 64 + lane] = (unsigned short)bits;
   }
@@ -202,7 +227,15 @@ __device__ __forceinline__ void net_step(const NetArgs& a, int fi, bool first, c
     // ALSO at the first step: block 0's small-conv operands were staged behind slot 1's main part, and the DMA below rewrites
     // that slot -- without this barrier a wave still in conv1(0) could read block 2's operands (seen as run-to-run
     // differences of the K = 72 backward kernel in 1 % of the calls: its 36 MFMAs leave the widest window)
-    if (!first || G::K1_IN_BUF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing is in flight at the first step)
+    // The stores of this step (STORE: 16 planar rows; NET_FWD_SAVE: the mask word) were issued AFTER the DMA that must have
+    // landed, and vmcnt counts in order: waiting until only that many operations are outstanding completes every DMA piece
+    // without waiting for the stores' round trip to HBM (with vmcnt(0) the storing kernels ran 2x slower at small grids).
+    // (a wave without a single pixel issues none of them -- the compiler branches around exec = 0 -- and waits for everything)
+    constexpr int NST = (STORE ? 16 : 0) + (MODE == NET_FWD_SAVE ? 1 : 0);
+    if (!first || G::K1_IN_BUF) {   // (nothing is in flight at the first step)
+      if (NST && wok) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();   // chunk fi landed in every wave's view; slot P^1 (and the separate operand buffer) is no longer read
   }
   stage_range<0, G::PIECES>(nsrc, ring_slot<P ^ 1>(s0, s1), wave, voff);
@@ -254,6 +287,7 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
   const size_t wblk = (size_t)blockIdx.x * 4 + (tid >> 6);   // 32-pixel column block of this wave
   const int q = (int)wblk * 32 + pix;
   const bool qok = q < a.Q;
+  const bool wok = (long)(blockIdx.x * 4 + wave) * 32 < a.Q;   // this wave holds at least one pixel (scalar)
   const float4* ring = a.R0p;
 
   // im2col column of this lane's pixel: xcol[ks] = in[pixel +- d(tap)][ch], k = 2*ks + hh = tap*KIN + ch
@@ -306,8 +340,8 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
 
 #pragma nounroll
   for (int fi = 0; fi < NF; fi += 2) {   // chunk fi lives in slot fi & 1 (NF is even)
-    net_step<KIN, NF, 0, MODE, STORE>(a, fi, fi == 0, ring + (size_t)(fi + 1) * SLOT4, slot0, slot1, k1buf, epl, xcol, acc2, mk2, wblk, wave, voff, lane, hh, q, qok);
-    net_step<KIN, NF, 1, MODE, STORE>(a, fi + 1, false, ring + (size_t)(fi + 2) * SLOT4, slot0, slot1, k1buf, epl, xcol, acc2, mk2, wblk, wave, voff, lane, hh, q, qok);
+    net_step<KIN, NF, 0, MODE, STORE>(a, fi, fi == 0, ring + (size_t)(fi + 1) * SLOT4, slot0, slot1, k1buf, epl, xcol, acc2, mk2, wblk, wave, voff, lane, hh, q, qok, wok);
+    net_step<KIN, NF, 1, MODE, STORE>(a, fi + 1, false, ring + (size_t)(fi + 2) * SLOT4, slot0, slot1, k1buf, epl, xcol, acc2, mk2, wblk, wave, voff, lane, hh, q, qok, wok);
   }
 
   // ---- epilogue on the 16 accumulator tiles, in place ----
@@ -316,12 +350,10 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
     if (MODE == NET_BWD) {
       const unsigned w = mk1[fo >> 1] >> ((fo & 1) * 16);   // g_a1 = g_h1 * g1 * [a1 + b1 > 0]
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int f = fo * 32 + mfma_row(r, hh);
-        const float m = ((w >> r) & 1u) ? acc2[fo][r] : 0.0f;
-        if (STORE && qok) a.st2[(size_t)f * a.Q + q] = m;
-        acc2[fo][r] = m * epl[F + f];
-      }
+      for (int r = 0; r < 16; ++r) acc2[fo][r] = ((w >> r) & 1u) ? acc2[fo][r] : 0.0f;
+      if (STORE && qok) st_tile_planar(uniform_fptr(a.st2 + (size_t)fo * 32 * a.Q), ((unsigned)(4 * hh) * (unsigned)a.Q + (unsigned)q) * 4u, (unsigned)a.Q * 4u, acc2[fo]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[fo][r] *= epl[F + fo * 32 + mfma_row(r, hh)];
     } else {
       unsigned bits = 0;
 #pragma unroll
@@ -329,9 +361,13 @@ __global__ __launch_bounds__(256, 1) void k_net_f32(NetArgs a) {
         const int f = fo * 32 + mfma_row(r, hh);
         const float pre = acc2[fo][r] + epl[3 * F + f];
         if (MODE == NET_FWD_SAVE) bits |= (pre > 0.0f ? 1u : 0u) << r;
-        const float rl = fmaxf(pre, 0.0f);
-        if (STORE && qok) a.st2[(size_t)f * a.Q + q] = rl;
-        acc2[fo][r] = fmaf(epl[4 * F + f], rl, epl[5 * F + f]);
+        acc2[fo][r] = fmaxf(pre, 0.0f);
+      }
+      if (STORE && qok) st_tile_planar(uniform_fptr(a.st2 + (size_t)fo * 32 * a.Q), ((unsigned)(4 * hh) * (unsigned)a.Q + (unsigned)q) * 4u, (unsigned)a.Q * 4u, acc2[fo]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = fo * 32 + mfma_row(r, hh);
+        acc2[fo][r] = fmaf(epl[4 * F + f], acc2[fo][r], epl[5 * F + f]);
       }
       if (MODE == NET_FWD_SAVE) a.mask2[(wblk * NF + fo) * 64 + lane] = (unsigned short)bits;
     }

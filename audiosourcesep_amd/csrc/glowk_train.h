@@ -207,22 +207,33 @@ __global__ __launch_bounds__(256) void k_assemble_step_grads(StepGradArgs a) {
     const int k = (int)(e / F), f = (int)(e % F);       // dK1 [tap][ci][F] flattened as [(tap, ci)][F]
     a.dK1[e] = a.scale * g1[f] * a.C1[(size_t)f * N1 + k];
   }
-  if (e < (size_t)F) {
-    const int f = (int)e;
-    double sh2 = 0.0;
-    for (int k = 0; k < N3; ++k) sh2 += (double)a.K3[((size_t)(k / c) * F + f) * c + (k % c)] * (double)a.C3[(size_t)F * N3 + k];
-    double sh1 = 0.0;
-    for (int f2 = 0; f2 < F; ++f2) sh1 += (double)a.K2[(size_t)f * F + f2] * (double)(g2[f2] * a.C2[(size_t)F * F + f2]);
-    const float* b1 = a.bn;
-    const float* b2 = a.bn + (size_t)4 * F;
-    a.db2[f] = a.scale * g2[f] * a.C2[(size_t)F * F + f];
-    a.dbeta2[f] = a.scale * (float)sh2;
-    a.dgamma2[f] = a.scale * (float)(((double)a.T2[f] - (double)b2[2 * F + f] * sh2) / sqrt((double)b2[3 * F + f] + (double)a.eps));
-    a.db1[f] = a.scale * g1[f] * a.C1[(size_t)f * N1 + 9 * ci];
-    a.dbeta1[f] = a.scale * (float)sh1;
-    a.dgamma1[f] = a.scale * (float)(((double)a.T1[f] - (double)b1[2 * F + f] * sh1) / sqrt((double)b1[3 * F + f] + (double)a.eps));
-  }
   if (e < (size_t)c) a.db3[e] = a.scale * a.C3[(size_t)F * N3 + 4 * c + e];
+}
+
+// the per-channel part (biases, BatchNorm gamma / beta): one workgroup per hidden channel f, the two matrix-vector products
+// SH2[f] = sum_k K3[k][f] SG[k] and SH1[f] = sum_f2 K2[f][f2] g2[f2] SM2[f2] reduced across its threads (fp64, fixed order)
+__global__ __launch_bounds__(256) void k_assemble_channel_grads(StepGradArgs a) {
+  __shared__ double red[2][4];
+  const int F = a.F, c = a.c, ci = c / 2, N1 = 9 * ci + 1, N3 = 9 * c, f = blockIdx.x;
+  const float *g1 = a.ep + F, *g2 = a.ep + 4 * (size_t)F;
+  double sh2 = 0.0, sh1 = 0.0;
+  for (int k = threadIdx.x; k < N3; k += 256) sh2 += (double)a.K3[((size_t)(k / c) * F + f) * c + (k % c)] * (double)a.C3[(size_t)F * N3 + k];
+  for (int f2 = threadIdx.x; f2 < F; f2 += 256) sh1 += (double)a.K2[(size_t)f * F + f2] * (double)(g2[f2] * a.C2[(size_t)F * F + f2]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sh2 += __shfl_down(sh2, o, 64); sh1 += __shfl_down(sh1, o, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sh2; red[1][threadIdx.x >> 6] = sh1; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  sh2 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  sh1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  const float* b1 = a.bn;
+  const float* b2 = a.bn + (size_t)4 * F;
+  a.db2[f] = a.scale * g2[f] * a.C2[(size_t)F * F + f];
+  a.dbeta2[f] = a.scale * (float)sh2;
+  a.dgamma2[f] = a.scale * (float)(((double)a.T2[f] - (double)b2[2 * F + f] * sh2) / sqrt((double)b2[3 * F + f] + (double)a.eps));
+  a.db1[f] = a.scale * g1[f] * a.C1[(size_t)f * N1 + 9 * ci];
+  a.dbeta1[f] = a.scale * (float)sh1;
+  a.dgamma1[f] = a.scale * (float)(((double)a.T1[f] - (double)b1[2 * F + f] * sh1) / sqrt((double)b1[3 * F + f] + (double)a.eps));
 }
 
 // ---- ActNorm + 1x1: the fused per-pixel affine v = u A + b.  part[block][c*c + c]: sum_q u_i g_j, sum_q g_j over the block's pixels
