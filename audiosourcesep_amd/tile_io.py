@@ -158,11 +158,17 @@ def read_tfrecord(path, check_crc=True):
             if len(hdr) != 8:
                 raise ValueError("truncated TFRecord header")
             (n,) = struct.unpack("<Q", hdr)
-            (hcrc,) = struct.unpack("<I", f.read(4))
+            hc = f.read(4)
+            if len(hc) != 4:
+                raise ValueError("truncated TFRecord header checksum")
+            (hcrc,) = struct.unpack("<I", hc)
+            if check_crc and hcrc != _masked_crc(hdr):      # (before trusting the length it protects)
+                raise ValueError("TFRecord CRC mismatch (length)")
             data = f.read(n)
-            (dcrc,) = struct.unpack("<I", f.read(4))
-            if len(data) != n:
+            dc = f.read(4)
+            if len(data) != n or len(dc) != 4:
                 raise ValueError("truncated TFRecord payload")
+            (dcrc,) = struct.unpack("<I", dc)
             if check_crc and (hcrc != _masked_crc(hdr) or dcrc != _masked_crc(data)):
                 raise ValueError("TFRecord CRC mismatch")
             yield parse_example(data)

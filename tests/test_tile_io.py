@@ -84,3 +84,21 @@ def test_real_tiles_through_the_engine_yaml_geometry():
     # the shipped mixture is the power sum of the shipped sources up to the K = 2 normalisation of g (run_basis_sep.py:139)
     mix = basis.mixing_db(torch.from_numpy(g["gt1"]), torch.from_numpy(g["gt2"])).numpy()
     assert np.median(np.abs(mix + 10 * np.log10(2.0) - g["mixed"])) < 1.5
+
+
+def test_truncated_records_raise_clean_errors(tmp_path):
+    """A TFRecord file cut anywhere inside a record is a ValueError naming the part that is missing (never a struct.error)."""
+    from audiosourcesep_amd import tile_io
+    p = str(tmp_path / "a.tfrecord")
+    tile_io.write_tfrecord(p, [np.arange(12, dtype=np.float32).reshape(3, 4)])
+    raw = open(p, "rb").read()
+    assert len(list(tile_io.read_tfrecord(p))) == 1
+    for cut in (3, 8, 10, 12, 20, len(raw) - 5, len(raw) - 1):
+        open(p, "wb").write(raw[:cut])
+        with pytest.raises(ValueError, match="truncated"):
+            list(tile_io.read_tfrecord(p))
+    bad = bytearray(raw)
+    bad[2] ^= 1                                        # a flipped length byte is caught by the length CRC before it is believed
+    open(p, "wb").write(bytes(bad))
+    with pytest.raises(ValueError, match="CRC mismatch"):
+        list(tile_io.read_tfrecord(p))
