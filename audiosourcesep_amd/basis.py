@@ -81,17 +81,45 @@ def compute_grad_logprob(inputs, model):
 
 def _grad_pair(x1, x2, model1, model2, streams):
     """The two priors' gradients are independent: evaluate them concurrently on two HIP streams (at BASIS batch sizes the
-    deeper levels launch only tens of workgroups each, so the two kernel sequences interleave on the 256 CUs)."""
+    deeper levels launch only tens of workgroups each, so the two kernel sequences interleave on the 256 CUs).
+
+    The range guard of the split arithmetics would make each call wait for its own stream before returning (policy "error" /
+    "fallback"), i.e. serialise the two models; so both calls run under "ignore" (fully asynchronous) and the flags are read
+    once both sequences are enqueued -- a tripped one re-runs that model's gradient on the exact fp32 kernels, like "fallback"."""
     if streams is None or x1.device.type != "cuda":
         return compute_grad_logprob(x1, model1), compute_grad_logprob(x2, model2)
-    cur = torch.cuda.current_stream()
+    cur = torch.cuda.current_stream(x1.device)
     s1, s2 = streams
     s1.wait_stream(cur)
     s2.wait_stream(cur)
-    with torch.cuda.stream(s1):
-        g1 = compute_grad_logprob(x1, model1)
-    with torch.cuda.stream(s2):
-        g2 = compute_grad_logprob(x2, model2)
+    engines = (model1.engine, model2.engine)
+    guarded = [e.get_precision() != _lib.PREC_F32 for e in engines]
+    saved = [int(e.lib.glowk_get_range_policy(e.h)) for e in engines]
+    for e, gd in zip(engines, guarded):
+        if gd:
+            e.set_range_policy("ignore")
+    try:
+        with torch.cuda.stream(s1):
+            g1 = compute_grad_logprob(x1, model1)
+        with torch.cuda.stream(s2):
+            g2 = compute_grad_logprob(x2, model2)
+        out = [g1, g2]
+        for i, (e, gd, st, x, m) in enumerate(zip(engines, guarded, (s1, s2), (x1, x2), (model1, model2))):
+            if not gd or saved[i] == _lib.RANGE_IGNORE:
+                continue
+            with torch.cuda.stream(st):
+                if e.range_status()[0]:
+                    if saved[i] == _lib.RANGE_ERROR:
+                        raise _lib.GlowkRangeError("BASIS: a prior's gradient left the fp16 range of the split arithmetic")
+                    prec = e.get_precision()
+                    e.set_precision(_lib.PREC_F32)
+                    out[i] = compute_grad_logprob(x, m)
+                    e.set_precision(prec)
+        g1, g2 = out
+    finally:
+        for e, gd, pol in zip(engines, guarded, saved):
+            if gd:
+                e.set_range_policy(pol)
     cur.wait_stream(s1)
     cur.wait_stream(s2)
     g1.record_stream(cur)

@@ -180,7 +180,7 @@ def test_range_policy_and_widths_on_the_host_side(lib):
         assert rc != 0 and b"n_filters" in lib.glowk_last_error()
 
 
-def test_bench_launches_its_own_ranks(monkeypatch, repo_root):
+def test_bench_launches_its_own_ranks(monkeypatch, repo_root, capsys):
     """`python bench.py --gpus N` outside torch.distributed.run must start N ranks itself, before touching the GPU, and
     hand back their exit code; a WORLD_SIZE that contradicts --gpus is an error."""
     import importlib
@@ -190,6 +190,7 @@ def test_bench_launches_its_own_ranks(monkeypatch, repo_root):
 
     class Done:
         returncode = 7
+        stdout = "[Gloo] Rank 0 is connected to 1 peer ranks.\n{\"metric\": \"m\", \"value\": 1}\n"
 
     def fake_run(cmd, env=None, **kw):
         calls["cmd"], calls["env"] = cmd, env
@@ -201,6 +202,8 @@ def test_bench_launches_its_own_ranks(monkeypatch, repo_root):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 7
+    out = capsys.readouterr()
+    assert out.out.strip() == '{"metric": "m", "value": 1}' and "[Gloo]" in out.err      # only the JSON line reaches stdout
     cmd = calls["cmd"]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
