@@ -119,14 +119,16 @@ def _cpu_baseline_pinned(RT, cfg, params, budget_s, threads):
         RT.log_prob(x[:2], p, d)
         t1 = (time.perf_counter() - t0) / 2.0
         share = budget_s / 3.0 / 3.0                  # three variants x three passes
-        tiles = int(max(1, min(128, share / max(t1, 1e-3))))
+        # (the same tile count for the deduplicated and the faithful graph: per-tile CPU time depends on the batch --
+        #  hidden activations of 64 tiles no longer fit the caches -- and the two variants are meant to be compared)
+        tiles = int(max(1, min(32, share / max(1.5 * t1, 1e-3))))
         med, tot = timed(tiles, 1)
         spent += tot
         out = {"value": tiles / med, "unit": "passes/s", "cores": threads, "kind": "port",
                "sample": "median of 3 passes over %d tiles of the same config (%.1f s of CPU work in all three variants), torch-CPU "
                          "fp32 restatement of the reference graph (oracle/glowref_torch.py; NOT TensorFlow), deduplicated graph "
                          "(one network evaluation per step)" % (tiles, 0.0)}
-        tf = max(1, tiles // 2)
+        tf = tiles
         med, tot = timed(tf, 2)
         spent += tot
         out["faithful"] = {"value": tf / med, "unit": "passes/s", "cores": threads, "tiles": tf,
