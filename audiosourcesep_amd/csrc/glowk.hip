@@ -396,7 +396,8 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
         na.st1 = h->trKeep + h->trKeepOff[sidx] * (size_t)N;
         na.st2 = na.st1 + (size_t)cfg.F * Q;
       }
-      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, keep_hidden ? 9 : save ? (h->precision == GLOWK_PREC_F32 ? NET_FWD_SAVE : 4) : fwd_mode(h), &np)) return rc;
+      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, keep_hidden ? (h->precision == GLOWK_PREC_F32 ? 9 : 10)
+                                                            : save ? (h->precision == GLOWK_PREC_F32 ? NET_FWD_SAVE : 4) : fwd_mode(h), &np)) return rc;
       if (save) h->save_parts[sidx] = np;
       CoupleArgs ca;
       ca.vin = cur; ca.P = na.P; ca.np = np; ca.pstride = na.pstride; ca.b3 = sd.b3; ca.logdet = h->bufLd; ca.log_s_out = nullptr; ca.t_out = nullptr;
@@ -556,6 +557,7 @@ int launch_wgrad(glowk_handle* h, const float* A, int M, int a_ones, const float
 struct TrainCtx {
   float* grad;     // [tr_n] flat gradient vector (device, caller owned)
   float scale;     // every gradient is scale * d sum_n log_prob / d theta
+  bool split;      // the sweep runs the fp16-split kernels (k_net_h3, MODE | 8): planar arrays in scaled units (StepGradArgs::scaled)
 };
 
 // weight gradients of one step's coupling network.  v: the step's saved coupling input [Q][c]; g_o: gradient wrt the network output
@@ -591,7 +593,7 @@ int train_network_grads(glowk_handle* h, TrainCtx* tc, int lvl, int k, const flo
   const float* p = h->tr_params + train_step_pos(h, lvl, k);
   float* g = tc->grad + train_step_pos(h, lvl, k);
   StepGradArgs a;
-  a.F = F; a.c = c; a.K2 = p + t.K2; a.K3 = p + t.K3; a.bn = p + t.bn; a.ep = sd.ep; a.eps = h->cfg.bn_eps;
+  a.F = F; a.c = c; a.K2 = p + t.K2; a.K3 = p + t.K3; a.bn = p + t.bn; a.ep = sd.ep; a.eps = h->cfg.bn_eps; a.scaled = tc->split ? 1 : 0;
   a.C1 = h->trC1; a.C2 = h->trC2; a.C3 = h->trC3; a.T1 = h->trT; a.T2 = h->trT + F; a.scale = tc->scale;
   a.dK1 = g + t.K1; a.dK2 = g + t.K2; a.dK3 = g + t.K3; a.db1 = g + t.b1; a.db2 = g + t.b2; a.db3 = g + t.b3;
   a.dgamma1 = g + t.bn; a.dbeta1 = g + t.bn + F; a.dgamma2 = g + t.bn + 4 * (size_t)F; a.dbeta2 = g + t.bn + 5 * (size_t)F;
@@ -665,10 +667,10 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       na.K1p = sd.K3bp; na.R0p = sd.RBp; na.P = Pg;
       na.mask1 = h->saveM + h->offM[sidx];
       na.mask2 = na.mask1 + blocks * NF * 64;
-      const bool h3b = !tc && h->precision != GLOWK_PREC_F32 && sd.RHBp;
+      const bool h3b = (tc ? tc->split : h->precision != GLOWK_PREC_F32) && sd.RHBp;
       if (h3b) { na.RHp = sd.RHBp; na.RSp = sd.RSBp; na.eph = nullptr; na.sc1 = sd.scb1; na.sc2 = sd.scb2; na.sc3 = sd.scb3; na.xlim = sd.xlim_b; }
       if (tc) { na.st1 = h->trM2; na.st2 = h->trM1; }
-      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, tc ? 8 : h3b ? 5 : NET_BWD, &npg)) return rc;
+      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, tc ? (tc->split ? 11 : 8) : h3b ? 5 : NET_BWD, &npg)) return rc;
       if (tc)
         if (int rc = train_network_grads(h, tc, lvl, k, h->saveV + h->offV[sidx], g_o, N, s)) return rc;
     }
@@ -1558,17 +1560,28 @@ int glowk_param_offset(glowk_handle* h, int level, int step, int tensor_id, size
   return 0;
 }
 
-int glowk_param_grad(glowk_handle* h, const float* x_dev, int N, float scale, float* logp_dev, float* grad_dev, void* stream) {
-  if (!h) return fail("null handle");
-  DeviceGuard dg(h->device);
-  if (!x_dev || !grad_dev) return fail("null tensor");
+static int param_grad_impl(glowk_handle* h, const float* x_dev, int N, float scale, float* logp_dev, float* grad_dev, void* stream, bool allow_split,
+                           bool* tripped) {
   const int prec = h->precision;
-  h->precision = GLOWK_PREC_F32;       // the training sweep runs the exact kernels (see include/glowk.h)
   struct Restore { glowk_handle* h; int p; ~Restore() { h->precision = p; } } restore{h, prec};
-  if (int rc = check_ready(h, N)) return rc;
+  if (int rc = check_ready(h, N)) return rc;       // (in a split precision this re-packs stale f16 images first)
   if (int rc = train_begin(h)) return rc;
-  if (int rc = ensure_save(h, N)) return rc;
   if (int rc = ensure_train(h, N)) return rc;
+  // The sweep runs in the handle's arithmetic where the split kernels have training instances for every level (32x32x16 family,
+  // forward and backward images) and the hiddens are kept by the forward pass; otherwise on the exact fp32 kernels.
+  bool split = allow_split && prec != GLOWK_PREC_F32 && h->trKeep && N <= h->trKeepN && !getenv("GLOWK_TRAIN_F32");
+  for (const Level& lv : h->levels) {
+    if (!split) break;
+    const StepDev& sd = lv.dev[0];
+    split = sd.RHp && sd.RHBp;
+    if (split) {      // ... and the launch policy has an instance of both storing kernels for this level at this batch size
+      NetArgs pf = net_args(h, lv, sd, nullptr, lv.c, lv.c / 2, N), pb = net_args(h, lv, sd, nullptr, lv.c, 0, N);
+      pb.RHp = sd.RHBp;
+      split = launch_net_raw(lv.c, h->cfg.F, pf, 10, nullptr, true) > 0 && launch_net_raw(lv.c, h->cfg.F, pb, 11, nullptr, true) > 0;
+    }
+  }
+  h->precision = split ? GLOWK_PREC_F16X3 : GLOWK_PREC_F32;
+  if (int rc = ensure_save(h, N)) return rc;
   hipStream_t s = (hipStream_t)stream;
   const glowk_config& cfg = h->cfg;
   float* z = h->bufGz;
@@ -1584,7 +1597,7 @@ int glowk_param_grad(glowk_handle* h, const float* x_dev, int N, float scale, fl
                        grad_dev + h->tr_prior_off, grad_dev + h->tr_prior_off + pad4((size_t)E));
     LAUNCHCHK("k_prior_wgrad");
   }
-  TrainCtx tc{grad_dev, scale};
+  TrainCtx tc{grad_dev, scale, split};
   // (the input gradient falls out of the sweep as well; the trainer has no use for it: it lands in the block-level scratch,
   //  which is free again by the time the last kernel of the sweep writes it)
   if (int rc = run_backward(h, x_dev, z, N, h->bufZ, s, &tc)) return rc;
@@ -1592,7 +1605,14 @@ int glowk_param_grad(glowk_handle* h, const float* x_dev, int N, float scale, fl
   const size_t steps = (size_t)cfg.L * cfg.K;
   std::vector<double> sums(steps * AFF_NOUT_MAX);
   HIPCHK(hipMemcpyAsync(sums.data(), h->trAffSum, sums.size() * 8, hipMemcpyDeviceToHost, s));
+  if (split) HIPCHK(hipMemcpyAsync(h->h_flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  if (split && h->h_flag[0]) {       // the range guard of the split arithmetic fired somewhere in the sweep: its gradients are not usable
+    h->h_flag[0] = 0;
+    HIPCHK(hipMemsetAsync(h->d_flag, 0, sizeof(int), s));
+    *tripped = true;
+    return 0;
+  }
   for (int lvl = 0; lvl < cfg.L; ++lvl) {
     const Level& lv = h->levels[lvl];
     const TrainOff t = train_off(lv.c, cfg.F);
@@ -1604,6 +1624,21 @@ int glowk_param_grad(glowk_handle* h, const float* x_dev, int N, float scale, fl
     HIPCHK(hipStreamSynchronize(s));      // (out is a local)
   }
   return 0;
+}
+
+int glowk_param_grad(glowk_handle* h, const float* x_dev, int N, float scale, float* logp_dev, float* grad_dev, void* stream) {
+  if (!h) return fail("null handle");
+  DeviceGuard dg(h->device);
+  if (!x_dev || !grad_dev) return fail("null tensor");
+  bool tripped = false;
+  if (int rc = param_grad_impl(h, x_dev, N, scale, logp_dev, grad_dev, stream, true, &tripped)) return rc;
+  if (!tripped) return 0;
+  if (h->range_policy == GLOWK_RANGE_ERROR) {
+    g_err = "training sweep: a hidden activation or gradient left the fp16 range of the split arithmetic -- use GLOWK_PREC_F32 or GLOWK_RANGE_FALLBACK";
+    return GLOWK_ERR_RANGE;
+  }
+  ++h->range_fallbacks;      // FALLBACK (and IGNORE: a gradient vector of NaNs would poison the parameters): the exact kernels
+  return param_grad_impl(h, x_dev, N, scale, logp_dev, grad_dev, stream, false, &tripped);
 }
 
 int glowk_apply_gradients(glowk_handle* h, const float* grad_dev, int optimizer, float lr, void* stream) {

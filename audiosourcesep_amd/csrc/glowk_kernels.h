@@ -449,7 +449,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 // need the registers, and for small grids, where each pass becomes a workgroup of its own).
 template <int KIN, int MOUT, int NF, int MODE, int NP>
 struct RingH {
-  static constexpr bool BWD = MODE == NET_BWD;
+  static constexpr bool BWD = (MODE & 7) == NET_BWD;
   static constexpr int NFH = NF / NP;                             // accumulator tiles (hidden 32-blocks) per pass
   static constexpr int K1 = 9 * KIN;
   static constexpr int KROWS = K1 + (BWD ? 0 : 1);                // forward: a spare k row carries conv1's bias
@@ -607,9 +607,13 @@ struct H3Ctx {                      // wave-uniform pointers of the kernel (LDS 
 
 // activation epilogue of 16 accumulator values: forward max(acc * sc, 0) (+ the ReLU decisions as bits), backward
 // acc * sc where the forward pass's ReLU was open
+// (MODE & 8: training -- the 16 activation values, in the scaled units they are split in, also go to a planar [F][Q] array:
+//  st_blk = wave-uniform base of the hidden block's 32 rows, st_lane = this lane's byte offset, st_row = bytes per row)
 template <int MODE>
-__device__ __forceinline__ unsigned h3_act(const f32x16& acc, float sc, unsigned mask, h8 (&bh)[2], h8 (&bl)[2]) {
+__device__ __forceinline__ unsigned h3_act(const f32x16& acc, float sc, unsigned mask, h8 (&bh)[2], h8 (&bl)[2], bool do_st = false,
+                                           float* st_blk = nullptr, unsigned st_lane = 0, unsigned st_row = 0) {
   unsigned bits = 0;
+  const unsigned long long st_base = reinterpret_cast<unsigned long long>(st_blk);
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     float v[8];
@@ -620,11 +624,19 @@ __device__ __forceinline__ unsigned h3_act(const f32x16& acc, float sc, unsigned
       const float t[2] = {t2.x, t2.y};
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        if (MODE == NET_BWD) v[j + e] = __int_as_float(__float_as_int(t[e]) & __builtin_amdgcn_sbfe((int)mask, r + e, 1));   // bit ? t : 0
+        if ((MODE & 7) == NET_BWD) v[j + e] = __int_as_float(__float_as_int(t[e]) & __builtin_amdgcn_sbfe((int)mask, r + e, 1));   // bit ? t : 0
         else {
           v[j + e] = fmaxf(t[e], 0.0f);
-          if (MODE == NET_FWD_SAVE) bits |= (acc[r + e] > 0.0f ? 1u : 0u) << (r + e);
+          if ((MODE & 7) == NET_FWD_SAVE) bits |= (acc[r + e] > 0.0f ? 1u : 0u) << (r + e);
         }
+      }
+    }
+    if ((MODE & 8) && do_st) {
+      unsigned off = st_lane + (unsigned)(16 * s) * st_row;      // rows 8 (r >> 2) + (r & 3): registers 8 s .. 8 s + 7 = rows 16 s + {0..3, 8..11}
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(v[j]), "s"(st_base) : "memory");
+        off += (j == 3 ? 5u : 1u) * st_row;
       }
     }
     split8(v, bh[s], bl[s]);
@@ -643,7 +655,7 @@ __device__ __forceinline__ void h3_X(const NetArgs& a, const H3Ctx& c, int fi, c
   for (int r = 0; r < 16; ++r) h1[r] = 0.0f;
   const h8* k1 = reinterpret_cast<const h8*>(KP ? c.k1s1 : c.k1s0) + lane;   // [s][hi|lo][64]
   unsigned mask = 0;
-  if (MODE == NET_BWD) mask = c.mkl[((size_t)(8 + (threadIdx.x >> 6)) * NF + fi) * 64 + lane];  // mask2: the ReLU after conv2
+  if ((MODE & 7) == NET_BWD) mask = c.mkl[((size_t)(8 + (threadIdx.x >> 6)) * NF + fi) * 64 + lane];  // mask2: the ReLU after conv2
   if constexpr (G::KS <= 3) {       // all operand reads in flight before the first MFMA
     h8 kf[2 * G::KS];
 #pragma unroll
@@ -655,8 +667,11 @@ __device__ __forceinline__ void h3_X(const NetArgs& a, const H3Ctx& c, int fi, c
 #pragma unroll
     for (int s = 0; s < G::KS; ++s) h1 = mfma3(k1[(2 * s + 0) * 64], k1[(2 * s + 1) * 64], xh[s], xl[s], h1);
   }
-  const unsigned bits = h3_act<MODE>(h1, a.sc1, mask, bh, bl);
-  if (MODE == NET_FWD_SAVE && PASS == 0 && c.wok) a.mask1[(c.wblk * NF + fi) * 64 + lane] = (unsigned short)bits;
+  const int stq = (int)c.wblk * 32 + (lane & 31);
+  const unsigned bits = h3_act<MODE>(h1, a.sc1, mask, bh, bl, (MODE & 8) && PASS == 0 && stq < a.Q,
+                                     (MODE & 8) ? uniform_fptr(a.st1 + (size_t)fi * 32 * a.Q) : nullptr,
+                                     ((unsigned)(4 * (lane >> 5)) * (unsigned)a.Q + (unsigned)stq) * 4u, (unsigned)a.Q * 4u);
+  if ((MODE & 7) == NET_FWD_SAVE && PASS == 0 && c.wok) a.mask1[(c.wblk * NF + fi) * 64 + lane] = (unsigned short)bits;
 }
 
 // Y: main contraction's contribution of one hidden block to this pass's NFH accumulator tiles (chunk in `slot`).  The wave
@@ -739,9 +754,11 @@ __device__ __forceinline__ void h3_Z(const NetArgs& a, const H3Ctx& c, const flo
     const int ml = first_group ? mt : mt - G::G0N;     // this row tile's accumulator within its group
     if (ml == 0) {
       unsigned mask = 0;
-      if (MODE == NET_BWD) mask = c.mkl[((size_t)(threadIdx.x >> 6) * NF + PASS * NFH + fo) * 64 + lane];   // mask1: the ReLU after conv1
-      const unsigned bits = h3_act<MODE>(acc2[fo], a.sc2, mask, bh, bl);
-      if (MODE == NET_FWD_SAVE && first_group && c.wok) a.mask2[(c.wblk * NF + PASS * NFH + fo) * 64 + lane] = (unsigned short)bits;
+      if ((MODE & 7) == NET_BWD) mask = c.mkl[((size_t)(threadIdx.x >> 6) * NF + PASS * NFH + fo) * 64 + lane];   // mask1: the ReLU after conv1
+      const unsigned bits = h3_act<MODE>(acc2[fo], a.sc2, mask, bh, bl, (MODE & 8) && qok,
+                                         (MODE & 8) ? uniform_fptr(a.st2 + (size_t)(PASS * NFH + fo) * 32 * a.Q) : nullptr,
+                                         ((unsigned)(4 * hh) * (unsigned)a.Q + (unsigned)q) * 4u, (unsigned)a.Q * 4u);
+      if ((MODE & 7) == NET_FWD_SAVE && first_group && c.wok) a.mask2[(c.wblk * NF + PASS * NFH + fo) * 64 + lane] = (unsigned short)bits;
     }
     if (fo == 0) {
 #pragma unroll
@@ -753,7 +770,7 @@ __device__ __forceinline__ void h3_Z(const NetArgs& a, const H3Ctx& c, const flo
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mt * 32 + mfma_row(r, hh);
-        if (m < M3 && qok) Pp[(size_t)m * a.Q + q] = (PASS == 0 && MODE != NET_BWD) ? fmaf(acc3[ml][r], a.sc3, pb[m]) : acc3[ml][r] * a.sc3;
+        if (m < M3 && qok) Pp[(size_t)m * a.Q + q] = (PASS == 0 && (MODE & 7) != NET_BWD) ? fmaf(acc3[ml][r], a.sc3, pb[m]) : acc3[ml][r] * a.sc3;
       }
     }
   }
@@ -780,7 +797,7 @@ __device__ __forceinline__ void h3_pass(const NetArgs& a, const H3Ctx& c, const 
 #pragma unroll
   for (int fo = 0; fo < NFH; ++fo)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[fo][r] = MODE == NET_BWD ? 0.0f : epl[f2base + fo * 32 + mfma_row(r, hh)];   // conv2 bias (scaled)
+    for (int r = 0; r < 16; ++r) acc2[fo][r] = (MODE & 7) == NET_BWD ? 0.0f : epl[f2base + fo * 32 + mfma_row(r, hh)];   // conv2 bias (scaled)
 
   h8 bh[2], bl[2];
 #pragma nounroll
@@ -824,7 +841,7 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
   using G = RingH<KIN, MOUT, NF, MODE, NP>;
   constexpr int K1 = G::K1;
   constexpr int KS = G::KS;
-  constexpr int SGN = (MODE == NET_BWD) ? -1 : 1;   // backward gathers at q - d(tap)
+  constexpr int SGN = ((MODE & 7) == NET_BWD) ? -1 : 1;   // backward gathers at q - d(tap)
   static_assert(G::FITS, "shape");
 
   __shared__ float4 slotA[G::MAIN4];
@@ -859,12 +876,12 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
   if (!g) {
     stage4<G::MAINP, 60>(G::main_chunk(c.img, solo_pass, 0), slotA, c.w4, c.voff);       // main chunk 0
     stage4<G::MAINP, 61>(G::out_chunk(c.img, solo_pass, 0), slotD, c.w4, c.voff);        // first output chunk
-    if (MODE == NET_BWD)   // the forward pass's ReLU decisions of this workgroup's 8 column blocks: [mask1 | mask2][wave][block][lane]
+    if ((MODE & 7) == NET_BWD)   // the forward pass's ReLU decisions of this workgroup's 8 column blocks: [mask1 | mask2][wave][block][lane]
       stage4<NF, 64>(reinterpret_cast<const float4*>(a.mask1 + (size_t)blockIdx.x * 8 * NF * 64), reinterpret_cast<float4*>(mkl), c.w4, c.voff);
   } else {
     stage4<G::K1P, 62>(c.k1img, k1slot0, c.w4, c.voff);                                   // small-conv operands of blocks 0, 1
     stage4<G::K1P, 63>(c.k1img + G::K14, k1slot1, c.w4, c.voff);
-    if (MODE == NET_BWD)
+    if ((MODE & 7) == NET_BWD)
       stage4<NF, 65>(reinterpret_cast<const float4*>(a.mask2 + (size_t)blockIdx.x * 8 * NF * 64), reinterpret_cast<float4*>(mkl + 8 * NF * 64), c.w4, c.voff);
   }
   // im2col fragments of this lane's pixel: k-step s holds k = 16 s + 8 hh + j (natural order), scaled and split
@@ -879,12 +896,12 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       float v[8];
-      gather8<KIN, MODE != NET_BWD, SGN>(base, i, j0, a.h, a.w, a.in_stride, qok, 16 * s + 8 * hh, v);
+      gather8<KIN, (MODE & 7) != NET_BWD, SGN>(base, i, j0, a.h, a.w, a.in_stride, qok, 16 * s + 8 * hh, v);
       xmax = range8(xmax, v);
       split8(v, xh[s], xl[s]);
     }
   }
-  if (MODE != NET_BWD)
+  if ((MODE & 7) != NET_BWD)
     for (int i = tid; i < G::EPN; i += 512) epl[i] = a.eph[i];
   if (xmax > a.xlim && a.flag) *a.flag = 1;                // beyond this input magnitude the host cannot rule out an fp16 overflow
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -89,6 +89,15 @@ int launch_net_t(const NetArgs& a, int mode, hipStream_t s, bool dry) {
     // training (exact fp32 only): the same two kernels, also storing their hidden tensors planar (NetArgs::st1 / st2)
     case 7:            if (!dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD, true>), dim3(ntiles), dim3(256), 0, s, a); break;
     case 8:            if (!dry) hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD, true>), dim3(ntiles), dim3(256), 0, s, a); break;
+    // training in the split arithmetic: the 32x32x16 family's saving forward and backward launches, storing their hiddens (MODE | 8)
+    case 10:   // (dry: returns 0 when the shape has no instance -- glowk_param_grad asks before it chooses the arithmetic of the sweep)
+      if (a.RHp) np = launch_h3<CI, 18 * CI, NF, (NET_FWD_SAVE | 8)>(a, s, dry);
+      if (!np) { if (dry) return 0; launch_fail("no split-arithmetic training instance for this shape"); return -1; }
+      break;
+    case 11:
+      if (a.RHp) np = launch_h3<2 * CI, 9 * CI, NF, (NET_BWD | 8)>(a, s, dry);
+      if (!np) { if (dry) return 0; launch_fail("no split-arithmetic training instance for this shape"); return -1; }
+      break;
     case 9:            if (!dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE, true>), dim3(ntiles), dim3(256), 0, s, a); break;   // saving forward pass that keeps its hiddens
     case 3:   // f16x3 arithmetic: forward / forward with saves / backward; shapes without an instance run the exact fp32 kernel
       if (a.RSp && h3_shape16()) np = launch_h3s<CI, 18 * CI, NF, NET_FWD>(a, s, dry);

@@ -178,6 +178,12 @@ struct StepGradArgs {
   const float* bn;      // [8][F]: gamma1, beta1, mean1, var1, gamma2, beta2, mean2, var2
   const float* ep;      // [6][F]: b1, g1, d1, b2, g2, d2 -- the step's folded BatchNorm block as the kernels read it (k_fold_bn / pack_step)
   float eps;
+  // scaled = 1: the planar arrays came from the split kernels (k_net_h3, MODE | 8) in the units those kernels split in:
+  //   A1 = ACT 2^e1[f] R1,  A2 = ACT 2^e2[f] R2  (g = m 2^e: the power of two of the BatchNorm gain is folded into the producer),
+  //   G2 = ACT g2[f] M2 = ACT g_a2,  G1 = ACT g1[f] M1 = ACT g_a1  (the backward images carry the gains),  ACT = GLOWK_ACT_SCALE.
+  // The GEMMs ran on those; the per-row factors are undone here (powers of two and the gains themselves; a gain of exactly zero
+  // -- a dead channel -- gets a zero gamma gradient).
+  int scaled;
   const float *C1, *C2, *C3, *T1, *T2;
   float scale;
   float *dK1, *db1, *dgamma1, *dbeta1, *dK2, *db2, *dgamma2, *dbeta2, *dK3, *db3;
@@ -190,35 +196,48 @@ __device__ __forceinline__ void bn_fold(const float* bn, int F, int layer, int f
   d = (float)((double)b[F + f] - (double)b[2 * F + f] * gd);
 }
 
-// grid: enough blocks of 256 threads to cover max(F * F, 9 * F * c, 9 * ci * F); per-channel vectors by the first F threads
+__device__ __forceinline__ float pow2_of_gain_inv(float g) {   // 2^-e with g = m 2^e, |m| in [0.5, 1) (e = 0 for g = 0: pack_step)
+  int e = 0;
+  if (g != 0.0f) frexpf(g, &e);
+  return ldexpf(1.0f, -e);
+}
+
+// grid: enough blocks of 256 threads to cover max(F * F, 9 * F * c, 9 * ci * F)
 __global__ __launch_bounds__(256) void k_assemble_step_grads(StepGradArgs a) {
   const int F = a.F, c = a.c, ci = c / 2, N1 = 9 * ci + 1, N3 = 9 * c;
   const float *g1 = a.ep + F, *d1 = a.ep + 2 * (size_t)F, *g2 = a.ep + 4 * (size_t)F, *d2 = a.ep + 5 * (size_t)F;
+  const float iact = a.scaled ? 1.0f / GLOWK_ACT_SCALE : 1.0f;
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e < (size_t)F * F) {
     const int f1 = (int)(e / F), f2 = (int)(e % F);
-    a.dK2[e] = a.scale * g2[f2] * (g1[f1] * a.C2[(size_t)f1 * F + f2] + d1[f1] * a.C2[(size_t)F * F + f2]);
+    const float c2 = a.C2[(size_t)f1 * F + f2], s2 = a.C2[(size_t)F * F + f2];
+    // exact:  g2[f2] (g1[f1] R1.M2 + d1[f1] sum M2);  scaled:  (g1[f1] a1[f1] A1.G2 + d1[f1] sum G2) / ACT  with a1 = 2^-e1 / ACT
+    a.dK2[e] = a.scaled ? a.scale * iact * (g1[f1] * pow2_of_gain_inv(g1[f1]) * iact * c2 + d1[f1] * s2)
+                        : a.scale * g2[f2] * (g1[f1] * c2 + d1[f1] * s2);
   }
   if (e < (size_t)9 * F * c) {
     const int tap = (int)(e / ((size_t)F * c)), f = (int)((e / c) % F), co = (int)(e % c);
-    a.dK3[e] = a.scale * (g2[f] * a.C3[(size_t)f * N3 + tap * c + co] + d2[f] * a.C3[(size_t)F * N3 + tap * c + co]);
+    const float r2 = a.scaled ? pow2_of_gain_inv(g2[f]) * iact : 1.0f;
+    a.dK3[e] = a.scale * (g2[f] * r2 * a.C3[(size_t)f * N3 + tap * c + co] + d2[f] * a.C3[(size_t)F * N3 + tap * c + co]);
   }
   if (e < (size_t)9 * ci * F) {
     const int k = (int)(e / F), f = (int)(e % F);       // dK1 [tap][ci][F] flattened as [(tap, ci)][F]
-    a.dK1[e] = a.scale * g1[f] * a.C1[(size_t)f * N1 + k];
+    a.dK1[e] = a.scale * (a.scaled ? iact : g1[f]) * a.C1[(size_t)f * N1 + k];
   }
   if (e < (size_t)c) a.db3[e] = a.scale * a.C3[(size_t)F * N3 + 4 * c + e];
 }
 
 // the per-channel part (biases, BatchNorm gamma / beta): one workgroup per hidden channel f, the two matrix-vector products
-// SH2[f] = sum_k K3[k][f] SG[k] and SH1[f] = sum_f2 K2[f][f2] g2[f2] SM2[f2] reduced across its threads (fp64, fixed order)
+// SH2[f] = sum_k K3[k][f] SG[k] and SH1[f] = sum_f2 K2[f][f2] (sum_q g_a2[f2]) reduced across its threads (fp64, fixed order)
 __global__ __launch_bounds__(256) void k_assemble_channel_grads(StepGradArgs a) {
   __shared__ double red[2][4];
   const int F = a.F, c = a.c, ci = c / 2, N1 = 9 * ci + 1, N3 = 9 * c, f = blockIdx.x;
   const float *g1 = a.ep + F, *g2 = a.ep + 4 * (size_t)F;
+  const float iact = a.scaled ? 1.0f / GLOWK_ACT_SCALE : 1.0f;
   double sh2 = 0.0, sh1 = 0.0;
   for (int k = threadIdx.x; k < N3; k += 256) sh2 += (double)a.K3[((size_t)(k / c) * F + f) * c + (k % c)] * (double)a.C3[(size_t)F * N3 + k];
-  for (int f2 = threadIdx.x; f2 < F; f2 += 256) sh1 += (double)a.K2[(size_t)f * F + f2] * (double)(g2[f2] * a.C2[(size_t)F * F + f2]);
+  for (int f2 = threadIdx.x; f2 < F; f2 += 256)      // sum_q g_a2[f2] = g2 sum M2 (exact) = sum G2 / ACT (scaled)
+    sh1 += (double)a.K2[(size_t)f * F + f2] * (double)((a.scaled ? iact : g2[f2]) * a.C2[(size_t)F * F + f2]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { sh2 += __shfl_down(sh2, o, 64); sh1 += __shfl_down(sh1, o, 64); }
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sh2; red[1][threadIdx.x >> 6] = sh1; }
@@ -228,12 +247,18 @@ __global__ __launch_bounds__(256) void k_assemble_channel_grads(StepGradArgs a) 
   sh1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
   const float* b1 = a.bn;
   const float* b2 = a.bn + (size_t)4 * F;
-  a.db2[f] = a.scale * g2[f] * a.C2[(size_t)F * F + f];
+  // T = sum_q M R (exact); scaled: sum_q G A = (ACT g M)(ACT 2^e R) -> T = Ts 2^-e / (ACT^2 g)
+  double t1 = (double)a.T1[f], t2 = (double)a.T2[f];
+  if (a.scaled) {
+    t1 = g1[f] != 0.0f ? t1 * (double)pow2_of_gain_inv(g1[f]) * (double)iact * (double)iact / (double)g1[f] : 0.0;
+    t2 = g2[f] != 0.0f ? t2 * (double)pow2_of_gain_inv(g2[f]) * (double)iact * (double)iact / (double)g2[f] : 0.0;
+  }
+  a.db2[f] = a.scale * (a.scaled ? iact : g2[f]) * a.C2[(size_t)F * F + f];
   a.dbeta2[f] = a.scale * (float)sh2;
-  a.dgamma2[f] = a.scale * (float)(((double)a.T2[f] - (double)b2[2 * F + f] * sh2) / sqrt((double)b2[3 * F + f] + (double)a.eps));
-  a.db1[f] = a.scale * g1[f] * a.C1[(size_t)f * N1 + 9 * ci];
+  a.dgamma2[f] = a.scale * (float)((t2 - (double)b2[2 * F + f] * sh2) / sqrt((double)b2[3 * F + f] + (double)a.eps));
+  a.db1[f] = a.scale * (a.scaled ? iact : g1[f]) * a.C1[(size_t)f * N1 + 9 * ci];
   a.dbeta1[f] = a.scale * (float)sh1;
-  a.dgamma1[f] = a.scale * (float)(((double)a.T1[f] - (double)b1[2 * F + f] * sh1) / sqrt((double)b1[3 * F + f] + (double)a.eps));
+  a.dgamma1[f] = a.scale * (float)((t1 - (double)b1[2 * F + f] * sh1) / sqrt((double)b1[3 * F + f] + (double)a.eps));
 }
 
 // ---- ActNorm + 1x1: the fused per-pixel affine v = u A + b.  part[block][c*c + c]: sum_q u_i g_j, sum_q g_j over the block's pixels

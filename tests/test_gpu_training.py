@@ -52,6 +52,7 @@ CASES = {
     "L2_K3_F256_notop": (GlowConfig(H=16, W=16, C=1, L=2, K=3, F=256, learntop=False), 4),
     "L4_K1_F128": (GlowConfig(H=16, W=16, C=1, L=4, K=1, F=128), 3),
     "configB_shape_K2": (GlowConfig(H=64, W=64, C=1, L=3, K=2, F=512), 3),
+    "L3_K2_F256": (GlowConfig(H=32, W=32, C=1, L=3, K=2, F=256), 6),
 }
 
 
@@ -97,6 +98,32 @@ def keras_update(opt, p, g, m, v, t, lr):
         v = b2 * v + (1 - b2) * g * g
         p = p - lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t) * m / (np.sqrt(v) + eps)
     return p, m, v
+
+
+@pytest.mark.parametrize("name", ["L2_K2_F128", "L2_K3_F256_notop", "configB_shape_K2", "L3_K2_F256"])
+def test_parameter_gradients_in_the_split_arithmetic(name):
+    """glowk_param_grad with the handle in f16x3: the sweep runs the fp16-split kernels (k_net_h3 with hidden stores, planar arrays
+    in scaled units, undone in the assembly) -- fp32-class, so the same bar against the fp64 autograd; and it is a different
+    code path from the exact one (not bitwise equal), with no range-guard fallback on a normalised flow."""
+    cfg, n = CASES[name]
+    eng, params = calibrated_engine(cfg, device=0, init_tiles=8)
+    x = synthetic_mel_tiles(n, cfg, seed=17)
+    scale = -1.0 / 32.0
+    lp_ref, ref = oracle_param_grads(x, params, cfg, scale)
+    _, _, flat32 = engine_grads(eng, params, x, scale)
+    eng.set_precision(_lib.PREC_F16X3)
+    eng.set_range_policy("error")
+    lp, got, flat = engine_grads(eng, params, x, scale)
+    np.testing.assert_allclose(lp, lp_ref, rtol=2e-6)
+    worst = 0.0
+    for k, r in ref.items():
+        denom = max(np.abs(r).max(), 1e-12)
+        worst = max(worst, float(np.abs(got[k] - r).max() / denom))
+        np.testing.assert_allclose(got[k], r, atol=2e-4 * denom, rtol=2e-3, err_msg=k)
+    print(name, "f16x3 sweep: worst |g - fp64| / max|g| over all tensors %.1e" % worst)
+    assert not np.array_equal(flat, flat32) and eng.range_status() == (False, 0)
+    _, _, flat2 = engine_grads(eng, params, x, scale)
+    assert np.array_equal(flat, flat2)                     # repeatable bit for bit
 
 
 @pytest.mark.parametrize("opt", ["adamax", "adam"])
