@@ -100,6 +100,11 @@ struct glowk_handle {
   size_t tr_prior_off = 0;
   std::vector<int*> tr_map;      // per level: packed-image position -> position in the step's parameter block (k_repack_f32)
   std::vector<size_t> tr_map_n;
+  std::vector<int*> tr_map16;    // per level: half position in [RHp, Afwd) -> source code | lo bit (k_repack_f16), or null
+  std::vector<size_t> tr_map16_n;
+  float* tr16_src = nullptr;     // [K][max cTot] scaled sources of one level's steps
+  int* tr16_S = nullptr;         // [K][6]
+  float* tr16_scales = nullptr;  // [K][8]
   int trN = 0;
   float *trR1 = nullptr, *trR2 = nullptr, *trM1 = nullptr, *trM2 = nullptr, *trXcol = nullptr, *trGcol = nullptr, *trCpart = nullptr;
   float *trC1 = nullptr, *trC2 = nullptr, *trC3 = nullptr, *trT = nullptr, *trGv = nullptr;
@@ -877,6 +882,32 @@ int train_begin(glowk_handle* h) {
       HIPCHK(hipMemcpy(h->tr_map[l], map.data(), map.size() * 4, hipMemcpyHostToDevice));
       h->tr_map_n[l] = map.size();
     }
+    // the same for the fp16-split images: the packer in map mode
+    h->tr_map16.assign(h->levels.size(), nullptr);
+    h->tr_map16_n.assign(h->levels.size(), 0);
+    size_t src_max = 0;
+    for (size_t l = 0; l < h->levels.size(); ++l) {
+      const Level& lv = h->levels[l];
+      const StepLayout SL = step_layout(lv.c, h->cfg.F);
+      if (!(SL.slotH || SL.slotS || SL.slotHB || SL.slotSB)) continue;
+      Level tmp;
+      tmp.h = lv.h; tmp.w = lv.w; tmp.c = lv.c; tmp.z_off = 0; tmp.z_width = 0; tmp.Cz = 0;
+      for (int id = 0; id < GLOWK_NUM_STEP_TENSORS; ++id) tmp.host[id].assign(1, lv.host[id][0]);   // any valid step: only the layout matters
+      std::vector<float> stage(SL.total, 0.0f);
+      std::vector<int> map16(SL.total * 2, -1);
+      double ldc; float sc[8]; std::string err;
+      if (!pack_step(h->cfg, tmp, 0, stage.data(), &ldc, sc, &err, map16.data())) return fail("f16 repack map: " + err);
+      const size_t lo = SL.RHp * 2, n = (SL.Afwd - SL.RHp) * 2;
+      HIPCHK(hipMalloc(&h->tr_map16[l], n * 4));
+      HIPCHK(hipMemcpy(h->tr_map16[l], map16.data() + lo, n * 4, hipMemcpyHostToDevice));
+      h->tr_map16_n[l] = n;
+      src_max = std::max(src_max, f16_code_bases(lv.c, h->cfg.F).total);
+    }
+    if (src_max) {
+      HIPCHK(hipMalloc(&h->tr16_src, (size_t)h->cfg.K * src_max * 4));
+      HIPCHK(hipMalloc(&h->tr16_S, (size_t)h->cfg.K * 6 * 4));
+      HIPCHK(hipMalloc(&h->tr16_scales, (size_t)h->cfg.K * 8 * 4));
+    }
   }
   std::vector<float> flat;
   params_to_flat(h, flat);
@@ -985,9 +1016,10 @@ int glowk_destroy(glowk_handle* h) {
   if (h->h_flag) hipHostFree(h->h_flag);
   {
     void* tr[] = {h->tr_params, h->tr_m, h->tr_v, h->trR1, h->trR2, h->trM1, h->trM2, h->trXcol, h->trGcol, h->trCpart, h->trC1, h->trC2, h->trC3,
-                  h->trT, h->trGv, h->trAffPart, h->trAffSum, h->trSmall, h->trKeep};
+                  h->trT, h->trGv, h->trAffPart, h->trAffSum, h->trSmall, h->trKeep, h->tr16_src, h->tr16_S, h->tr16_scales};
     for (void* p : tr) if (p) hipFree(p);
     for (int* m : h->tr_map) if (m) hipFree(m);
+    for (int* m : h->tr_map16) if (m) hipFree(m);
   }
   if (h->bufA) { hipFree(h->bufA); hipFree(h->bufB); hipFree(h->bufP); hipFree(h->bufZ); hipFree(h->bufLd); }
   if (h->bufC) hipFree(h->bufC);
@@ -1651,6 +1683,7 @@ int glowk_apply_gradients(glowk_handle* h, const float* grad_dev, int optimizer,
   const glowk_config& cfg = h->cfg;
   const int F = cfg.F;
   const double b1 = 0.9, b2 = 0.999;
+  bool stale16 = false;      // set when a level's fp16-split images are NOT refreshed below (handle in exact fp32)
   h->tr_t += 1;
   const double t = (double)h->tr_t;
   const float lr_t = optimizer == 1 ? (float)(lr / (1.0 - std::pow(b1, t))) : (float)(lr * std::sqrt(1.0 - std::pow(b2, t)) / (1.0 - std::pow(b1, t)));
@@ -1668,6 +1701,29 @@ int glowk_apply_gradients(glowk_handle* h, const float* grad_dev, int optimizer,
                        p0, t.total, img0 + SL.K1p, SL.total);
     hipLaunchKernelGGL(k_fold_bn, dim3((F + 255) / 256, cfg.K), dim3(256), 0, s, p0 + t.b1, p0 + t.b2, p0 + t.bn, t.total, F, cfg.bn_eps, img0 + SL.ep, SL.total);
     LAUNCHCHK("k_repack_f32");
+    // the fp16-split images, when the handle is in a split arithmetic (otherwise they are re-packed lazily by the host)
+    const bool refresh16 = h->precision != GLOWK_PREC_F32 && h->tr_map16[lvl];
+    std::vector<float> sc16;
+    if (refresh16) {
+      const F16Codes q = f16_code_bases(lv.c, F);
+      F16Prep fp;
+      fp.params = p0; fp.param_stride = t.total; fp.ep = img0 + SL.ep; fp.img_stride = SL.total;
+      fp.oK1 = t.K1; fp.oK2 = t.K2; fp.oK3 = t.K3; fp.ob1 = t.b1; fp.ob2 = t.b2; fp.c = lv.c; fp.F = F;
+      fp.cA = q.A; fp.cB = q.B; fp.cC = q.C; fp.cD = q.D; fp.cE = q.E; fp.cG = q.G; fp.cTot = q.total;
+      fp.src = h->tr16_src; fp.S = h->tr16_S; fp.scales = h->tr16_scales;
+      const int NMT = (9 * lv.c + 31) / 32;
+      hipLaunchKernelGGL(k_f16_sources, dim3((unsigned)((q.total + 255) / 256), cfg.K), dim3(256), 0, s, fp);
+      hipLaunchKernelGGL(k_f16_absmax, dim3(6, cfg.K), dim3(1024), 0, s, fp);
+      hipLaunchKernelGGL(k_f16_consts, dim3((F + 32 * NMT + 255) / 256, cfg.K), dim3(256), 0, s, fp, img0 + SL.epH, NMT);
+      hipLaunchKernelGGL(k_f16_limits, dim3(2, cfg.K), dim3(512), 0, s, fp);
+      hipLaunchKernelGGL(k_repack_f16, dim3((unsigned)((h->tr_map16_n[lvl] + 255) / 256), cfg.K), dim3(256), 0, s, (const int*)h->tr_map16[lvl],
+                         h->tr_map16_n[lvl], fp, reinterpret_cast<unsigned short*>(img0 + SL.RHp), SL.total * 2);
+      LAUNCHCHK("k_repack_f16");
+      sc16.resize((size_t)cfg.K * 8);
+      HIPCHK(hipMemcpyAsync(sc16.data(), h->tr16_scales, sc16.size() * 4, hipMemcpyDeviceToHost, s));
+    } else if (h->tr_map16[lvl]) {
+      stale16 = true;
+    }
     // small tensors: down to the host (they parameterise the fp64 fold of ActNorm + 1x1), folded, back up
     const size_t small = t.K1;
     std::vector<float> sm((size_t)cfg.K * small), b3v((size_t)cfg.K * lv.c);
@@ -1690,6 +1746,12 @@ int glowk_apply_gradients(glowk_handle* h, const float* grad_dev, int optimizer,
       if (!pack_affine(cfg, lv, k, tmp.data(), &ldc, &err)) return fail("level " + std::to_string(lvl) + " step " + std::to_string(k) + ": " + err);
       h->ld_step[(size_t)lvl * cfg.K + k] = ldc;
       std::memcpy(blocks.data() + (size_t)k * tail, tmp.data() + SL.Afwd, tail * 4);
+      if (refresh16) {      // the kernels' scale arguments and range-guard limits live in the host-side step descriptors
+        StepDev& d = lv.dev[k];
+        const float* q8 = sc16.data() + (size_t)k * 8;
+        if (SL.slotH || SL.slotS) { d.sc1 = q8[0]; d.sc2 = q8[1]; d.sc3 = q8[2]; d.xlim_f = q8[6]; }
+        if (SL.slotHB || SL.slotSB) { d.scb1 = q8[3]; d.scb2 = q8[4]; d.scb3 = q8[5]; d.xlim_b = q8[7]; }
+      }
     }
     HIPCHK(hipMemcpy2DAsync(img0 + SL.Afwd, SL.total * 4, blocks.data(), tail * 4, tail * 4, cfg.K, hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1702,7 +1764,7 @@ int glowk_apply_gradients(glowk_handle* h, const float* grad_dev, int optimizer,
     HIPCHK(hipMemcpyAsync(const_cast<float*>(h->d_log_scale), h->tr_params + h->tr_prior_off + pad4(E), E * 4, hipMemcpyDeviceToDevice, s));
   }
   h->host_stale = true;
-  h->split_stale = true;
+  h->split_stale = stale16;
   return 0;
 }
 

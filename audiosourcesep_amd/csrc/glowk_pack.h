@@ -265,7 +265,21 @@ bool pack_affine(const glowk_config& cfg, const Level& lv, int k, float* dst, do
 }
 
 // pack one step into dst (host staging of the arena)
-bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, double* ld_const_out, float* scales3 /* [8]: fwd, bwd scales; fwd, bwd input limits */, std::string* err) {
+// The f16 images as a MAP for the device-side re-pack of the training step (glowk_train.h: k_repack_f16): every half of every
+// image is one element of six scaled fp32 source arrays (or zero), scaled by its layer's power of two and split hi / lo.
+// pack_step(..., f16_map) runs the very loops that write the images, with the source arrays holding 1-based CODES instead of
+// values: code ranges [K1f | K2f | K3f | W3b | W2b | K1 raw], bit 30 = lo half; positions no image loop writes stay -1.
+struct F16Codes { size_t A, B, C, D, E, G, total; };
+inline F16Codes f16_code_bases(int c, int F) {
+  const size_t CI = c / 2;
+  F16Codes q;
+  q.A = 0; q.B = q.A + (9 * CI + 1) * F; q.C = q.B + (size_t)F * F; q.D = q.C + (size_t)9 * F * c; q.E = q.D + (size_t)9 * c * F;
+  q.G = q.E + (size_t)F * F; q.total = q.G + 9 * CI * F;
+  return q;
+}
+
+bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, double* ld_const_out, float* scales3 /* [8]: fwd, bwd scales; fwd, bwd input limits */,
+               std::string* err, int* f16_map = nullptr) {
   const int c = lv.c, F = cfg.F, CI = c / 2, CO = c, NF = F / 32, KS1 = (9 * CI) / 2, NMT = (9 * c + 31) / 32;
   const StepLayout L = step_layout(c, F);
   auto T = [&](int id) -> const float* { return lv.host[id][k].data(); };
@@ -340,7 +354,12 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
     return 14 - e;                                // |w| * 2^S < 2^14: hi well inside fp16, lo ~2^3 (normal)
   };
   // one A-operand element: scaled, split, stored as half j of this lane's 16 bytes in the hi row and in the lo row after it
-  auto put = [](float* row_lane, int j, int hl, float w, int S) {
+  const F16Codes QC = f16_code_bases(c, F);
+  auto put = [dst, f16_map](float* row_lane, int j, int hl, float w, int S) {
+    if (f16_map) {      // map mode: w is a code (0 = a zero element)
+      f16_map[(size_t)(row_lane - dst) * 2 + (size_t)hl * 512 + j] = (int)w | (hl << 30);
+      return;
+    }
     const float ws = std::ldexp(w, S);
     const uint16_t hi = f32_to_f16(ws);
     const uint16_t lo = f32_to_f16(ws - f16_to_f32(hi));
@@ -414,6 +433,11 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
       scales3[6] = (float)(xl * (double)GLOWK_ACT_SCALE * (1.0 - 1e-6));   // the kernel compares its scaled gathers
     }
     const int S1 = pow2_scale(K1f.data(), K1f.size()), S2 = pow2_scale(K2f.data(), K2f.size()), S3 = pow2_scale(K3f.data(), K3f.size());
+    if (f16_map) {      // from here on the arrays only steer the image loops: codes instead of values
+      for (size_t i = 0; i < K1f.size(); ++i) K1f[i] = (float)(QC.A + i + 1);
+      for (size_t i = 0; i < K2f.size(); ++i) K2f[i] = (float)(QC.B + i + 1);
+      for (size_t i = 0; i < K3f.size(); ++i) K3f[i] = (float)(QC.C + i + 1);
+    }
     const float act = GLOWK_ACT_SCALE;
     scales3[0] = std::ldexp(1.0f, -S1); scales3[1] = std::ldexp(1.0f, -S2); scales3[2] = std::ldexp(1.0f, -S3) / act;
     {
@@ -534,6 +558,15 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
       scales3[7] = (float)(RANGE_LIM / amax * (double)GLOWK_ACT_SCALE * (1.0 - 1e-6));
     }
     const int S1 = pow2_scale(W3b.data(), W3b.size()), S2 = pow2_scale(W2b.data(), W2b.size()), S3 = pow2_scale(K1, (size_t)9 * CI * F);
+    std::vector<float> K1codes;
+    const float* K1b = K1;             // conv1^T of the backward network reads the raw kernel
+    if (f16_map) {
+      for (size_t i = 0; i < W3b.size(); ++i) W3b[i] = (float)(QC.D + i + 1);
+      for (size_t i = 0; i < W2b.size(); ++i) W2b[i] = (float)(QC.E + i + 1);
+      K1codes.resize((size_t)9 * CI * F);
+      for (size_t i = 0; i < K1codes.size(); ++i) K1codes[i] = (float)(QC.G + i + 1);
+      K1b = K1codes.data();
+    }
     scales3[3] = std::ldexp(1.0f, -S1); scales3[4] = std::ldexp(1.0f, -S2); scales3[5] = std::ldexp(1.0f, -S3) / GLOWK_ACT_SCALE;
     const size_t k1blk = (size_t)KSB * 2 * 256, chunkf = (size_t)NFH * 1024;
     float* img = dst + L.RHBp;
@@ -567,7 +600,7 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
                   const int mt = t < NFH * G0N ? t % G0N : G0N + (t - NFH * G0N) % G1N;
                   const int m = mt * 32 + i, f = (ps * NFH + fo) * 32 + kloc;
                   S = S3;
-                  if (m < 9 * CI) w = K1[(size_t)m * F + f];          // conv1^T: row (tap, cin), contraction over the hidden channel
+                  if (m < 9 * CI) w = K1b[(size_t)m * F + f];         // conv1^T: row (tap, cin), contraction over the hidden channel
                 }
                 float* row_lane = chunk + ((size_t)((tp * 2 + s2) * 2) * 64 + l) * 4;
                 put(row_lane, j, 0, w, S);
@@ -609,7 +642,7 @@ bool pack_step(const glowk_config& cfg, const Level& lv, int k, float* dst, doub
                     const int fo = t < NFH * GS0 ? t / GS0 : (t - NFH * GS0) / GS1;
                     const int mt = t < NFH * GS0 ? t % GS0 : GS0 + (t - NFH * GS0) % GS1;
                     const int m = mt * 16 + i, f = (ps * NFH + fo) * 32 + kloc;
-                    if (m < 9 * CI) w = K1[(size_t)m * F + f];
+                    if (m < 9 * CI) w = K1b[(size_t)m * F + f];
                   }
                 }
                 float* row_lane = chunk + ((size_t)(tp * 2) * 64 + l) * 4;

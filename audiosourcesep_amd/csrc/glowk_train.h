@@ -378,3 +378,189 @@ __global__ __launch_bounds__(256) void k_fold_bn(const float* __restrict__ b1, c
   e[f] = b1[po + f]; e[F + f] = g1; e[2 * F + f] = d1;
   e[3 * F + f] = b2[po + f]; e[4 * F + f] = g2; e[5 * F + f] = d2;
 }
+
+// ---- device-side refresh of the fp16-split kernel images after an optimizer step -----------------------------------------
+// The host packer (glowk_pack.h: pack_step) folds BatchNorm into the weights, scales every layer by a power of two taken from
+// its largest element, splits into fp16 hi + lo and lays the halves out in MFMA fragment order.  Here the layout is a MAP made
+// by the packer itself in map mode (one int per half: source code | lo bit, see F16Codes), and the arithmetic is redone on the
+// device in the packer's own precision and order (fp64 where it uses fp64, separate multiply and add where the x86 build has
+// no fused ones), so that the refreshed images are bit for bit the host-packed ones -- which is what the test asserts.
+// All kernels take one grid row (blockIdx.y) per step of the level.
+struct F16Prep {
+  const float* params;     // first step's parameter block (TrainOff layout), param_stride floats between steps
+  size_t param_stride;
+  const float* ep;         // first step's folded block [b1 | g1 | d1 | b2 | g2 | d2] in the arena, img_stride floats between steps
+  size_t img_stride;
+  size_t oK1, oK2, oK3, ob1, ob2;   // TrainOff offsets
+  int c, F;
+  size_t cA, cB, cC, cD, cE, cG, cTot;   // F16Codes
+  float* src;              // [steps][cTot] scaled fp32 sources
+  int* S;                  // [steps][6] power-of-two scales of the six source arrays
+  float* scales;           // [steps][8]: sc1 sc2 sc3 scb1 scb2 scb3 xlim_f xlim_b (what the host packer hands back in scales3)
+};
+
+__device__ __forceinline__ int gain_exp(float g) { int e = 0; if (g != 0.0f) frexp((double)g, &e); return e; }
+__device__ __forceinline__ double gain_mant(float g) { int e; return frexp((double)g, &e); }
+
+__global__ __launch_bounds__(256) void k_f16_sources(F16Prep a) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.cTot) return;
+  const int F = a.F, c = a.c, ci = c / 2;
+  const float* p = a.params + (size_t)blockIdx.y * a.param_stride;
+  const float* ep = a.ep + (size_t)blockIdx.y * a.img_stride;
+  const float *K1 = p + a.oK1, *K2 = p + a.oK2, *K3 = p + a.oK3, *g1 = ep + F, *g2 = ep + 4 * (size_t)F;
+  float v;
+  if (i < a.cB) {                       // K1f[kk][f] = ldexp(K1[kk][f] | b1[f], e1[f])
+    const int kk = (int)(i / F), f = (int)(i % F);
+    v = ldexpf(kk < 9 * ci ? K1[(size_t)kk * F + f] : ep[f], gain_exp(g1[f]));
+  } else if (i < a.cC) {                // K2f[fi][fo] = (float) ldexp(K2 m1[fi], e2[fo])
+    const size_t j = i - a.cB;
+    const int fi = (int)(j / F), fo = (int)(j % F);
+    v = (float)ldexp(__dmul_rn((double)K2[j], gain_mant(g1[fi])), gain_exp(g2[fo]));
+  } else if (i < a.cD) {                // K3f[tap][f][co] = (float)(K3 m2[f])
+    const size_t j = i - a.cC;
+    const int f = (int)((j / c) % F);
+    v = (float)__dmul_rn((double)K3[j], gain_mant(g2[f]));
+  } else if (i < a.cE) {                // W3b[kk = (tap, co)][f] = K3[tap][f][co] g2[f]   (float product)
+    const size_t j = i - a.cD;
+    const int kk = (int)(j / F), f = (int)(j % F), tap = kk / c, co = kk % c;
+    v = __fmul_rn(K3[((size_t)tap * F + f) * c + co], g2[f]);
+  } else if (i < a.cG) {                // W2b[f2][f1] = K2[f1][f2] g1[f1]
+    const size_t j = i - a.cE;
+    const int f2 = (int)(j / F), f1 = (int)(j % F);
+    v = __fmul_rn(K2[(size_t)f1 * F + f2], g1[f1]);
+  } else {
+    v = K1[i - a.cG];
+  }
+  a.src[(size_t)blockIdx.y * a.cTot + i] = v;
+}
+
+// S = 14 - exponent(max |w|) of each of the six source arrays (grid: 6 x steps, 1024 threads)
+__global__ __launch_bounds__(1024) void k_f16_absmax(F16Prep a) {
+  __shared__ float red[16];
+  const size_t lo[6] = {a.cA, a.cB, a.cC, a.cD, a.cE, a.cG}, hi[6] = {a.cB, a.cC, a.cD, a.cE, a.cG, a.cTot};
+  const int r = blockIdx.x;
+  const float* s = a.src + (size_t)blockIdx.y * a.cTot;
+  float m = 0.0f;
+  for (size_t i = lo[r] + threadIdx.x; i < hi[r]; i += 1024) m = fmaxf(m, fabsf(s[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+    int e = 0;
+    if (m > 0.0f) frexpf(m, &e);
+    a.S[(size_t)blockIdx.y * 6 + r] = 14 - e;
+  }
+}
+
+// epH block of a step: [conv2 accumulator init (F) | per-row constants of P (32 NMT)], and the six kernel scales
+__global__ __launch_bounds__(256) void k_f16_consts(F16Prep a, float* __restrict__ eph0, int NMT) {
+  const int F = a.F, c = a.c, m = blockIdx.x * 256 + threadIdx.x;
+  const float* p = a.params + (size_t)blockIdx.y * a.param_stride;
+  const float* ep = a.ep + (size_t)blockIdx.y * a.img_stride;
+  float* eh = eph0 + (size_t)blockIdx.y * a.img_stride;
+  const int* S = a.S + (size_t)blockIdx.y * 6;
+  const float act = GLOWK_ACT_SCALE;
+  if (m < F) {            // b2f[fo] = b2 + sum_fi K2[fi][fo] d1[fi]  (fp64, fi ascending, multiply and add separately)
+    const float* K2 = p + a.oK2;
+    double b = (double)ep[3 * (size_t)F + m];
+    for (int fi = 0; fi < F; ++fi) b = __dadd_rn(b, __dmul_rn((double)K2[(size_t)fi * F + m], (double)ep[2 * (size_t)F + fi]));
+    eh[m] = (float)ldexp(__dmul_rn((double)act, b), gain_exp(ep[4 * (size_t)F + m]) + S[1]);
+  } else if (m < F + 32 * NMT) {
+    const int k = m - F;
+    double pb = 0.0;
+    if (k < 9 * c) {
+      const float* K3 = p + a.oK3;
+      const int tap = k / c, co = k % c;
+      for (int f = 0; f < F; ++f) pb = __dadd_rn(pb, __dmul_rn((double)K3[((size_t)tap * F + f) * c + co], (double)ep[5 * (size_t)F + f]));
+    }
+    eh[m] = (float)pb;
+  }
+  if (m == 0) {
+    float* sc = a.scales + (size_t)blockIdx.y * 8;
+    sc[0] = ldexpf(1.0f, -S[0]); sc[1] = ldexpf(1.0f, -S[1]); sc[2] = ldexpf(1.0f, -S[2]) / act;
+    sc[3] = ldexpf(1.0f, -S[3]); sc[4] = ldexpf(1.0f, -S[4]); sc[5] = ldexpf(1.0f, -S[5]) / act;
+  }
+}
+
+// the range-guard limits of a step (pack_step: "range guard, forward / backward network"), one workgroup of F threads per step
+// and direction (blockIdx.x = 0 forward, 1 backward)
+__global__ __launch_bounds__(512) void k_f16_limits(F16Prep a) {
+  __shared__ double sh[512];
+  __shared__ double red[512];
+  const int F = a.F, c = a.c, ci = c / 2, f = threadIdx.x;
+  const float* p = a.params + (size_t)blockIdx.y * a.param_stride;
+  const float* ep = a.ep + (size_t)blockIdx.y * a.img_stride;
+  const double LIM = 60000.0 / (double)GLOWK_ACT_SCALE;
+  float* sc = a.scales + (size_t)blockIdx.y * 8;
+  if (blockIdx.x == 0) {
+    const float *K1 = p + a.oK1, *K2 = p + a.oK2, *g1 = ep + F, *g2 = ep + 4 * (size_t)F;
+    double n1 = 0.0;
+    if (f < F)
+      for (int kk = 0; kk < 9 * ci; ++kk) n1 = __dadd_rn(n1, fabs((double)K1[(size_t)kk * F + f]));
+    if (f < F) sh[f] = n1;
+    __syncthreads();
+    double cand = LIM;
+    auto tighten = [&](double A, double B) {
+      const double room = LIM - B;
+      if (room <= 0.0) cand = 0.0;
+      else if (A > 0.0) cand = fmin(cand, room / A);
+    };
+    if (f < F) {
+      tighten(ldexp(n1, gain_exp(g1[f])), ldexp(fabs((double)ep[f]), gain_exp(g1[f])));
+      double A2 = 0.0, B2 = 0.0;
+      for (int fi = 0; fi < F; ++fi) {
+        const double ga = fabs((double)g1[fi]);
+        const double aa = __dmul_rn(ga, sh[fi]), bb = __dadd_rn(__dmul_rn(ga, fabs((double)ep[fi])), fabs((double)ep[2 * (size_t)F + fi]));
+        const double w = fabs((double)K2[(size_t)fi * F + f]);
+        A2 = __dadd_rn(A2, __dmul_rn(w, aa));
+        B2 = __dadd_rn(B2, __dmul_rn(w, bb));
+      }
+      tighten(ldexp(A2, gain_exp(g2[f])), ldexp(__dadd_rn(B2, fabs((double)ep[3 * (size_t)F + f])), gain_exp(g2[f])));
+    }
+    red[f] = f < F ? cand : LIM;
+    __syncthreads();
+    for (int o = 256; o > 0; o >>= 1) { if (f < o) red[f] = fmin(red[f], red[f + o]); __syncthreads(); }
+    if (f == 0) sc[6] = (float)(red[0] * (double)GLOWK_ACT_SCALE * (1.0 - 1e-6));
+  } else {
+    const float* s = a.src + (size_t)blockIdx.y * a.cTot;
+    const float *W3b = s + a.cD, *W2b = s + a.cE;
+    double a1 = 0.0;
+    if (f < F)
+      for (int kk = 0; kk < 9 * c; ++kk) a1 = __dadd_rn(a1, fabs((double)W3b[(size_t)kk * F + f]));
+    sh[f] = f < F ? a1 : 0.0;
+    __syncthreads();
+    double a2 = 0.0;
+    if (f < F)
+      for (int f2 = 0; f2 < F; ++f2) a2 = __dadd_rn(a2, __dmul_rn(fabs((double)W2b[(size_t)f2 * F + f]), sh[f2]));
+    red[f] = f < F ? fmax(a1, a2) : 0.0;
+    __syncthreads();
+    for (int o = 256; o > 0; o >>= 1) { if (f < o) red[f] = fmax(red[f], red[f + o]); __syncthreads(); }
+    if (f == 0) sc[7] = (float)(LIM / fmax(1.0, red[0]) * (double)GLOWK_ACT_SCALE * (1.0 - 1e-6));
+  }
+}
+
+// IEEE binary32 -> binary16, round to nearest even, and back (bit-for-bit glowk_pack.h: f32_to_f16 / f16_to_f32)
+__device__ __forceinline__ unsigned short dev_f32_to_f16(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+__device__ __forceinline__ float dev_f16_to_f32(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+
+// img16[pos] = hi or lo half of ldexp(src[code - 1], S[range of code]); map[pos] = code | lo << 30, or -1: leave alone
+__global__ __launch_bounds__(256) void k_repack_f16(const int* __restrict__ map, size_t n, F16Prep a, unsigned short* __restrict__ img16, size_t img_stride_halves) {
+  const size_t pos = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (pos >= n) return;
+  const int mv = map[pos];
+  if (mv < 0) return;
+  const int lo = (mv >> 30) & 1;
+  const size_t code = (size_t)(mv & 0x3FFFFFFF);
+  unsigned short out = 0;
+  if (code) {
+    const size_t i = code - 1;
+    const int r = i < a.cB ? 0 : i < a.cC ? 1 : i < a.cD ? 2 : i < a.cE ? 3 : i < a.cG ? 4 : 5;
+    const float ws = ldexpf(a.src[(size_t)blockIdx.y * a.cTot + i], a.S[(size_t)blockIdx.y * 6 + r]);
+    const unsigned short hi = dev_f32_to_f16(ws);
+    out = lo ? dev_f32_to_f16(ws - dev_f16_to_f32(hi)) : hi;
+  }
+  img16[(size_t)blockIdx.y * img_stride_halves + pos] = out;
+}

@@ -204,8 +204,12 @@ int glowk_coupling_net(glowk_handle* h, int level, int step, const float* xb_dev
  * all-reduce).  Here: glowk_param_grad fills ONE flat fp32 vector with  scale * d sum_n log_prob(x_n) / d theta  for this rank's
  * tiles (scale = -1 / global batch), the caller all-reduces that vector across ranks (RCCL; torch.distributed in the mirror),
  * glowk_apply_gradients takes the optimizer step on the engine's device-resident master copy of the parameters and refreshes
- * the packed kernel images on the device.  The training sweep always runs the exact fp32 kernels, whatever glowk_set_precision
- * says (the split kernels' images are re-packed lazily, by the host, at the next split-precision call).
+ * the packed kernel images on the device.  The sweep runs in the handle's arithmetic: with GLOWK_PREC_F16X3 / F16X2 on the split
+ * kernels (hidden tensors stored in their scaled units, undone in the gradient assembly; fp32-class gradients, ~2x the exact
+ * sweep) wherever every level has training instances, under the range guard (a tripped sweep is repeated on the exact kernels
+ * unless the policy is GLOWK_RANGE_ERROR); otherwise, and with GLOWK_PREC_F32, on the exact fp32 kernels.  glowk_apply_gradients
+ * refreshes the exact images always and the fp16 hi/lo images (BatchNorm folds, power-of-two scales, epilogue constants,
+ * range-guard limits; bit for bit the host packer's) when the handle is in a split arithmetic.
  * Layout of the vector: glowk_param_offset.  It holds every tf.Variable of the flow except the frozen P, P_inv, sign_S; the
  * BatchNorm moving mean / variance (non-trainable, never updated by the reference: the layers are called without training=)
  * are carried with zero gradient. */

@@ -17,8 +17,8 @@ for p in f16x3 f32; do
   python bench.py --workload basis --batch 30 --steps 20 --warmup 3 --precision $p --no-cpu-baseline > $O/r02_basis_$p.json 2>> $O/r02_bench.err
   echo "$p done"
 done
-for b in 32 256; do python bench.py --workload train --batch $b --no-cpu-baseline > $O/r02_train_b$b.json 2>> $O/r02_bench.err; done
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/r02_prof_train -- python3 bench.py --workload train --batch 32 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>> $O/r02_prof.err
+for p in f16x3 f32; do for b in 32 256; do python bench.py --workload train --precision $p --batch $b --no-cpu-baseline > $O/r02_train_${p}_b$b.json 2>> $O/r02_bench.err; done; done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/r02_prof_train -- python3 bench.py --workload train --precision f16x3 --batch 32 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>> $O/r02_prof.err
 cp $(find $O/r02_prof_train -name "*kernel_stats.csv" | head -1) $O/r02_train_kernel_stats.csv
 echo "train done"
 GLOWK_BENCH_REHEARSAL=1 python bench.py --gpus 2 --steps 3 --warmup 1 --batch 256 > $O/r02_bench_gpus2_rehearsal.json 2>> $O/r02_bench.err

@@ -197,3 +197,46 @@ def test_short_training_loop_lowers_the_loss():
     v.assign(v.numpy() + 0.25)
     lp2, _ = eng.param_grad(x, -1.0 / 32.0)
     assert torch.equal(lp2, flow.log_prob(x)) and not torch.equal(lp2, lp_after)
+
+
+@pytest.mark.parametrize("cfg", [GlowConfig(H=16, W=32, C=1, L=3, K=2, F=256), GlowConfig(H=32, W=32, C=1, L=2, K=3, F=512),
+                                 GlowConfig(H=32, W=32, C=1, L=4, K=2, F=128)], ids=["L3_F256", "L2_F512", "L4_F128"])
+def test_split_training_steps_refresh_the_f16_images_on_the_device(cfg):
+    """Training with the handle in f16x3: sweep on the split kernels, Adamax, and the fp16 hi/lo images (BatchNorm folds,
+    per-layer power-of-two scales, epilogue constants, range-guard limits) rebuilt ON THE DEVICE after every step.  The rebuilt
+    images must be the host packer's, bit for bit: a fresh engine that loads the trained variables (host packing) gives
+    bitwise the same log_prob / gradient in f16x3 and f16x2, and both match the fp64 oracle on those variables."""
+    eng, params = calibrated_engine(cfg, device=0, init_tiles=16)
+    flow = GlowFlow(eng)
+    eng.set_precision(_lib.PREC_F16X3)
+    eng.set_range_policy("error")
+    x = dev(synthetic_mel_tiles(24, cfg, seed=41))
+    losses = []
+    for it in range(4):
+        lp, g = eng.param_grad(x, -1.0 / 24.0)
+        losses.append(float(-lp.mean()))
+        eng.apply_gradients(g, optimizer="adamax", lr=5e-4)
+    assert np.isfinite(losses).all() and losses[-1] != losses[0]
+    lp_dev, z_dev = eng.log_prob(x, return_latent=True)          # images refreshed by the device
+    lpg_dev, gx_dev = eng.log_prob_grad(x)
+    sd = flow.state_dict()
+    other, _ = calibrated_engine(cfg, device=0, init_tiles=16)
+    oflow = GlowFlow(other)
+    oflow.load_state_dict(sd)                                      # images packed by the host
+    other.set_precision(_lib.PREC_F16X3)
+    other.set_range_policy("error")
+    lp_host, z_host = other.log_prob(x, return_latent=True)
+    lpg_host, gx_host = other.log_prob_grad(x)
+    assert torch.equal(lp_dev, lp_host) and torch.equal(z_dev, z_host) and torch.equal(gx_dev, gx_host) and torch.equal(lpg_dev, lpg_host)
+    for e in (eng, other):
+        e.set_precision(_lib.PREC_F16X2)
+    assert torch.equal(eng.log_prob(x), other.log_prob(x))
+    lp_ref = RT.log_prob(torch.from_numpy(x.cpu().numpy().astype(np.float64)), RT.to_torch(sd, torch.float64), cfg.as_dict())[0].numpy()
+    np.testing.assert_allclose(lp_dev.cpu().numpy(), lp_ref, rtol=2e-6)
+    assert eng.range_status() == (False, 0) and other.range_status() == (False, 0)
+    # one more step from the device-refreshed images equals one more step from the host-packed ones
+    eng.set_precision(_lib.PREC_F16X3)
+    other.set_precision(_lib.PREC_F16X3)
+    _, g1 = eng.param_grad(x, -1.0 / 24.0)
+    _, g2 = other.param_grad(x, -1.0 / 24.0)
+    assert torch.equal(g1, g2)
