@@ -542,19 +542,26 @@ int ensure_train(glowk_handle* h, int N) {
   return 0;
 }
 
-// C[Mp][N] = [A; 1?] . B^T over K pixels: split-K MFMA GEMM + fixed-order sum of the partials
-int launch_wgrad(glowk_handle* h, const float* A, int M, int a_ones, const float* B, int N, int K, float* C, hipStream_t s) {
-  const int Mp = M + a_ones, tm = (Mp + 63) / 64, tn = (N + 63) / 64, tiles = tm * tn;
-  int S = std::max(1, std::min((2 * num_cus() + tiles - 1) / tiles, (K + 255) / 256));
+// C[M (+1)][N] = A . B^T over K pixels: split-K MFMA GEMM + fixed-order sum of the partials; ones_row: row M of C = the row sums of B
+// (what an appended row of ones in A would give, without a ninth row tile for one row)
+int launch_wgrad(glowk_handle* h, const float* A, int M, int ones_row, const float* B, int N, int K, float* C, hipStream_t s) {
+  const bool big = M >= 256 && N >= 256 && getenv("GLOWK_WGRAD_128");   // 128 x 128 tiles for the square conv2 gradient: measured 5 % SLOWER
+                                                                          // than 64 x 64 (two workgroups per CU instead of four), kept behind a switch
+  const int TS = big ? 128 : 64, tm = (M + TS - 1) / TS, tn = (N + TS - 1) / TS, tiles = tm * tn;
+  static const int wg_per_cu = getenv("GLOWK_WGRAD_WGS") ? atoi(getenv("GLOWK_WGRAD_WGS")) : 2;   // workgroups per CU the split aims at
+  int S = std::max(1, std::min((wg_per_cu * num_cus() + tiles - 1) / tiles, (K + 255) / 256));
+  S = (int)std::max<size_t>(1, std::min<size_t>((size_t)S, CPART_FLOATS / ((size_t)M * N)));   // (the partial buffer bounds the split)
   int kslice = (((K + S - 1) / S) + 31) / 32 * 32;
   S = (K + kslice - 1) / kslice;
-  if ((size_t)S * Mp * N > CPART_FLOATS) return fail("wgrad: partial buffer too small");
+  if ((size_t)S * M * N > CPART_FLOATS) return fail("wgrad: partial buffer too small");
   WgradArgs a;
-  a.A = A; a.B = B; a.M = M; a.N = N; a.a_ones = a_ones; a.K = K; a.kslice = kslice; a.Cpart = h->trCpart;
-  hipLaunchKernelGGL(k_wgrad_nt, dim3(tm, tn, S), dim3(256), 0, s, a);
+  a.A = A; a.B = B; a.M = M; a.N = N; a.a_ones = 0; a.K = K; a.kslice = kslice; a.Cpart = h->trCpart;
+  if (big) hipLaunchKernelGGL((k_wgrad_nt<2>), dim3(tm, tn, S), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_wgrad_nt<1>), dim3(tm, tn, S), dim3(256), 0, s, a);
   LAUNCHCHK("k_wgrad_nt");
-  const size_t n = (size_t)Mp * N;
+  const size_t n = (size_t)M * N;
   hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)h->trCpart, S, n, C);
+  if (ones_row) hipLaunchKernelGGL(k_rowsum, dim3(N), dim3(256), 0, s, B, K, C + n);
   LAUNCHCHK("k_sum_parts");
   return 0;
 }
@@ -588,10 +595,10 @@ int train_network_grads(glowk_handle* h, TrainCtx* tc, int lvl, int k, const flo
   LAUNCHCHK("k_im2col_planar");
   // (3) the three GEMMs over the pixel dimension
   if (int rc = launch_wgrad(h, R2, F, 1, h->trGcol, 9 * c, Q, h->trC3, s)) return rc;
-  if (int rc = launch_wgrad(h, R1, F, 1, h->trM2, F, Q, h->trC2, s)) return rc;
+  if (int rc = launch_wgrad(h, R1, F, 0, h->trM2, F, Q, h->trC2, s)) return rc;      // (row F of C2 = sum_q M2: from k_rowdot below)
   if (int rc = launch_wgrad(h, h->trM1, F, 0, h->trXcol, 9 * ci + 1, Q, h->trC1, s)) return rc;
-  hipLaunchKernelGGL(k_rowdot, dim3(F), dim3(256), 0, s, (const float*)h->trM1, R1, Q, h->trT);
-  hipLaunchKernelGGL(k_rowdot, dim3(F), dim3(256), 0, s, (const float*)h->trM2, R2, Q, h->trT + F);
+  hipLaunchKernelGGL(k_rowdot, dim3(F), dim3(256), 0, s, (const float*)h->trM1, R1, Q, h->trT, (float*)nullptr);
+  hipLaunchKernelGGL(k_rowdot, dim3(F), dim3(256), 0, s, (const float*)h->trM2, R2, Q, h->trT + F, h->trC2 + (size_t)F * F);
   LAUNCHCHK("k_rowdot");
   // (4) assemble into the flat gradient vector
   const TrainOff t = train_off(c, F);

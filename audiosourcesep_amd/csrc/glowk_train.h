@@ -52,25 +52,36 @@ struct WgradArgs {
   float* Cpart;      // [S][Mp][Np], Mp = M + a_ones, Np = N
 };
 
+// WT = 32 x 32 accumulator tiles per wave in each direction: workgroup tile (64 WT) x (64 WT).  WT = 2 (128 x 128, 64 accumulator
+// registers per lane, every LDS operand read feeds two MFMAs) for the square conv2 gradient, WT = 1 for the skinny ones.
+template <int WT>
 __global__ __launch_bounds__(256) void k_wgrad_nt(WgradArgs a) {
-  __shared__ float As[2][32][65];
-  __shared__ float Bs[2][32][65];
+  constexpr int TS = 64 * WT;          // tile side
+  constexpr int LD = TS + 2;           // k-major LDS rows, padded: the transposing writes of a wave hit 64 distinct banks
+  constexpr int RPT = TS / 32;         // rows per thread and operand in one 32-deep stage
+  __shared__ float As[2][32][LD];
+  __shared__ float Bs[2][32][LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64, s = blockIdx.z;
+  const int m0 = blockIdx.x * TS, n0 = blockIdx.y * TS, s = blockIdx.z;
   const int Mp = a.M + a.a_ones;
   const long k_begin = (long)s * a.kslice;
   const long k_end = k_begin + a.kslice < a.K ? k_begin + a.kslice : a.K;
-  f32x16 acc;
+  f32x16 acc[WT][WT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  // loader: thread t brings rows (t >> 3) and (t >> 3) + 32 of both tiles, 4 consecutive k each
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  // loader: thread t brings rows (t >> 3) + 32 e of both tiles, 4 consecutive k each
   const int lr = tid >> 3, lk = (tid & 7) * 4;
-  float4 ra[2], rb[2];
+  // two register sets: the loads of stage c + 2 are issued before the MFMAs of stage c, so a load has two stages to land
+  float4 ra[2][RPT], rb[2][RPT];
   const bool vec = (a.K & 3) == 0;
-  auto fetch = [&](long k0) {
+  auto fetch = [&](long k0, int set) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < RPT; ++e) {
       const int m = m0 + lr + 32 * e, n = n0 + lr + 32 * e;
       const long k = k0 + lk;
       float4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
@@ -91,40 +102,73 @@ __global__ __launch_bounds__(256) void k_wgrad_nt(WgradArgs a) {
         va = float4{ta[0], ta[1], ta[2], ta[3]};
         vb = float4{tb[0], tb[1], tb[2], tb[3]};
       }
-      ra[e] = va; rb[e] = vb;
+      ra[set][e] = va; rb[set][e] = vb;
     }
   };
-  auto stage = [&](int buf) {
+  auto stage = [&](int buf, int set) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < RPT; ++e) {
       const int r = lr + 32 * e;
-      As[buf][lk + 0][r] = ra[e].x; As[buf][lk + 1][r] = ra[e].y; As[buf][lk + 2][r] = ra[e].z; As[buf][lk + 3][r] = ra[e].w;
-      Bs[buf][lk + 0][r] = rb[e].x; Bs[buf][lk + 1][r] = rb[e].y; Bs[buf][lk + 2][r] = rb[e].z; Bs[buf][lk + 3][r] = rb[e].w;
+      As[buf][lk + 0][r] = ra[set][e].x; As[buf][lk + 1][r] = ra[set][e].y; As[buf][lk + 2][r] = ra[set][e].z; As[buf][lk + 3][r] = ra[set][e].w;
+      Bs[buf][lk + 0][r] = rb[set][e].x; Bs[buf][lk + 1][r] = rb[set][e].y; Bs[buf][lk + 2][r] = rb[set][e].z; Bs[buf][lk + 3][r] = rb[set][e].w;
     }
   };
   const int i32 = lane & 31, kh = lane >> 5;
-  if (k_begin < k_end) {
-    fetch(k_begin);
-    stage(0);
-    __syncthreads();
-    int buf = 0;
-    for (long k0 = k_begin; k0 < k_end; k0 += 32) {
-      const bool more = k0 + 32 < k_end;
-      if (more) fetch(k0 + 32);
+  auto compute = [&](int buf) {
 #pragma unroll
-      for (int kk = 0; kk < 32; kk += 2)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][kk + kh][wm * 32 + i32], Bs[buf][kk + kh][wn * 32 + i32], acc, 0, 0, 0);
-      if (more) stage(buf ^ 1);
+    for (int kk = 0; kk < 32; kk += 2) {
+      float av[WT], bv[WT];
+#pragma unroll
+      for (int i = 0; i < WT; ++i) av[i] = As[buf][kk + kh][(wm * WT + i) * 32 + i32];
+#pragma unroll
+      for (int j = 0; j < WT; ++j) bv[j] = Bs[buf][kk + kh][(wn * WT + j) * 32 + i32];
+#pragma unroll
+      for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  if (k_begin < k_end) {
+    fetch(k_begin, 0);
+    stage(0, 0);
+    if (k_begin + 32 < k_end) fetch(k_begin + 32, 1);
+    __syncthreads();
+    // stages come in pairs so that the register set of every fetch / stage is a compile-time constant
+    for (long k0 = k_begin; k0 < k_end; k0 += 64) {
+      if (k0 + 64 < k_end) fetch(k0 + 64, 0);
+      compute(0);
+      if (k0 + 32 < k_end) stage(1, 1);
       __syncthreads();
-      buf ^= 1;
+      if (k0 + 32 >= k_end) break;
+      if (k0 + 96 < k_end) fetch(k0 + 96, 1);
+      compute(1);
+      if (k0 + 64 < k_end) stage(0, 0);
+      __syncthreads();
     }
   }
   float* C = a.Cpart + (size_t)s * Mp * a.N;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wm * 32 + mfma_row(r, kh), n = n0 + wn * 32 + i32;
-    if (m < Mp && n < a.N) C[(size_t)m * a.N + n] = acc[r];
-  }
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * WT + i) * 32 + mfma_row(r, kh), n = n0 + (wn * WT + j) * 32 + i32;
+        if (m < Mp && n < a.N) C[(size_t)m * a.N + n] = acc[i][j][r];
+      }
+}
+
+// out[n] = sum_k B[n][k]  (fp64 accumulation, one workgroup per row): the sums the appended row of ones used to deliver
+__global__ __launch_bounds__(256) void k_rowsum(const float* __restrict__ B, int K, float* __restrict__ out) {
+  __shared__ double red[4];
+  const float* b = B + (size_t)blockIdx.x * K;
+  double t = 0.0;
+  for (int k = threadIdx.x; k < K; k += 256) t += (double)b[k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = (float)(red[0] + red[1] + red[2] + red[3]);
 }
 
 // sum of the split-K partials: C[e] = sum_s Cpart[s][e]  (fixed order)
@@ -145,19 +189,28 @@ __global__ __launch_bounds__(256) void k_sum_parts_f64(const double* __restrict_
   out[e] = t;
 }
 
-// out[f] = sum_q X[f][q] * Y[f][q]   (one workgroup per channel row; fp64 accumulation, fixed order)
-__global__ __launch_bounds__(256) void k_rowdot(const float* __restrict__ X, const float* __restrict__ Y, int Q, float* __restrict__ out) {
-  __shared__ double red[4];
+// out[f] = sum_q X[f][q] * Y[f][q]  and, if sum_x != null, sum_x[f] = sum_q X[f][q]   (one workgroup per channel row; fp64
+// accumulation, fixed order; the row sums ride along for free: the rows are being read anyway)
+__global__ __launch_bounds__(256) void k_rowdot(const float* __restrict__ X, const float* __restrict__ Y, int Q, float* __restrict__ out,
+                                               float* __restrict__ sum_x) {
+  __shared__ double red[2][4];
   const int f = blockIdx.x;
   const float* x = X + (size_t)f * Q;
   const float* y = Y + (size_t)f * Q;
-  double t = 0.0;
-  for (int q = threadIdx.x; q < Q; q += 256) t += (double)x[q] * (double)y[q];
+  double t = 0.0, u = 0.0;
+  for (int q = threadIdx.x; q < Q; q += 256) {
+    const double xv = (double)x[q];
+    t += xv * (double)y[q];
+    u += xv;
+  }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  for (int o = 32; o > 0; o >>= 1) { t += __shfl_down(t, o, 64); u += __shfl_down(u, o, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = t; red[1][threadIdx.x >> 6] = u; }
   __syncthreads();
-  if (threadIdx.x == 0) out[f] = (float)(red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    out[f] = (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    if (sum_x) sum_x[f] = (float)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
 }
 
 // ---- gradients of one step's coupling network from the GEMM results ------------------------------------------------
