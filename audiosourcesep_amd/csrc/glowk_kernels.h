@@ -969,6 +969,9 @@ struct RingS {
   static constexpr int IMG_PASS4 = (NF + IMG_NCH) * IMG_MAIN4;
   static constexpr int SUBS = NP / 2;
   __device__ static const float4* main_chunk(const float4* img, int pass, int ch) {
+#ifdef GLOWK_EXP_SAMECHUNK   // (diagnostic build, wrong results: every weight DMA reads the same 32 KiB -- is the weight stream's L2 / HBM latency on the critical path?)
+    ch = 0;
+#endif
     return img + K1TOT4 + (size_t)(pass / SUBS) * IMG_PASS4 + (size_t)ch * IMG_MAIN4 + (size_t)(pass % SUBS) * MAIN4;
   }
   __device__ static const float4* out_chunk(const float4* img, int pass, int s) {   // conv3 chunk s of a pass (TPC tiles)
@@ -979,6 +982,15 @@ struct RingS {
   }
   static constexpr int tile_fo(int t) { return (t - GT * (t / GT)) / grp_n(t / GT); }
   static constexpr int tile_mt(int t) { return 6 * (t / GT) + (t - GT * (t / GT)) % grp_n(t / GT); }
+  // P written ONCE: with two passes in one workgroup and at most three row blocks of P (c = 4: the level that is 3/4 of the
+  // time) pass 0 keeps its partial sums in 24 registers and pass 1 adds them before the only store.  (Diagnostic builds: the P
+  // stores are ~10 % of the kernel's time -- skipping two thirds of them made a pass 7 % faster -- so half of them is worth having;
+  // the consumer reads one partial buffer instead of two.)  Plain forward modes only: the saving pass keeps its two buffers.
+#ifdef GLOWK_NO_MERGE   // (A/B builds only, scripts/ab.py)
+  static constexpr bool MERGE = false;
+#else
+  static constexpr bool MERGE = NP == 2 && NGRP == 1 && NMT <= 3 && (MODE == NET_FWD || MODE == NET_FWD2);
+#endif
 };
 
 template <bool TWO = false>
@@ -1116,9 +1128,10 @@ __device__ __forceinline__ void h3s_Y(const float4* slot, const h8 (&bh)[2], con
 template <int KIN, int MOUT, int NF, int MODE, int NP, int P0, int PASS, bool SOLO, int Z>
 __device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const float* epl, f32x4 (&acc2)[(RingS<KIN, MOUT, NF, MODE, NP>::NRB)][2],
                                       f32x4 (&acc3)[(RingS<KIN, MOUT, NF, MODE, NP>::G0N)][2], h8 (&bh)[2], h8 (&bl)[2], int g, const int (&q)[2],
-                                      const bool (&qok)[2], int lane, int kq) {
+                                      const bool (&qok)[2], int lane, int kq, f32x4 (&keep)[(RingS<KIN, MOUT, NF, MODE, NP>::G0N)][2]) {
   using G = RingS<KIN, MOUT, NF, MODE, NP>;
   constexpr int NFH = G::NFH, M3 = G::M3, TPC = G::TPC;
+  constexpr bool MERGE = G::MERGE && !SOLO;
   constexpr int S = Z >> 1;
   constexpr int P0N = (G::NCH + 1 + P0) & 1;
   if (!g) {
@@ -1132,7 +1145,7 @@ __device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const fl
   }
   const float4* slot = S == 0 ? c.sD : (((NF + S - 1 + P0) & 1) ? c.sB : c.sA);
   const h8* buf = reinterpret_cast<const h8*>(slot) + lane;
-  float* Pp = a.P + (size_t)PASS * a.pstride;
+  float* Pp = a.P + (MERGE ? (size_t)0 : (size_t)PASS * a.pstride);
   const float* pb = epl + NF * 32;
 #pragma unroll
   for (int i = 0; i < TPC / 2; ++i) {
@@ -1162,7 +1175,12 @@ __device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const fl
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = mt * 16 + 4 * kq + r;
-            if (m < M3 && qok[hf]) Pp[(size_t)m * a.Q + q[hf]] = (PASS == 0 && MODE != NET_BWD) ? fmaf(acc3[ml][hf][r], a.sc3, pb[m]) : acc3[ml][hf][r] * a.sc3;
+            const float val = (PASS == 0 && MODE != NET_BWD) ? fmaf(acc3[ml][hf][r], a.sc3, pb[m]) : acc3[ml][hf][r] * a.sc3;
+            if (MERGE && PASS == 0) { keep[ml][hf][r] = val; continue; }     // pass 1 adds it and stores once
+#ifdef GLOWK_EXP_NOSTORE   // (diagnostic build, wrong results: only one row tile of P is written -- what do the P stores cost?)
+            if (mt == 0)
+#endif
+            if (m < M3 && qok[hf]) Pp[(size_t)m * a.Q + q[hf]] = MERGE ? val + keep[ml][hf][r] : val;
           }
       }
     }
@@ -1173,13 +1191,15 @@ __device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const fl
 template <int KIN, int MOUT, int NF, int MODE, int NP, int P0, int PASS, bool SOLO, int... Z>
 __device__ __forceinline__ void h3s_tail(const NetArgs& a, const H3Ctx& c, const float* epl, f32x4 (&acc2)[(RingS<KIN, MOUT, NF, MODE, NP>::NRB)][2],
                                          f32x4 (&acc3)[(RingS<KIN, MOUT, NF, MODE, NP>::G0N)][2], h8 (&bh)[2], h8 (&bl)[2], int g, const int (&q)[2],
-                                         const bool (&qok)[2], int lane, int kq, std::integer_sequence<int, Z...>) {
-  (h3s_Z<KIN, MOUT, NF, MODE, NP, P0, PASS, SOLO, Z>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, kq), ...);
+                                         const bool (&qok)[2], int lane, int kq, f32x4 (&keep)[(RingS<KIN, MOUT, NF, MODE, NP>::G0N)][2],
+                                         std::integer_sequence<int, Z...>) {
+  (h3s_Z<KIN, MOUT, NF, MODE, NP, P0, PASS, SOLO, Z>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, kq, keep), ...);
 }
 
 template <int KIN, int MOUT, int NF, int MODE, int NP, int P0, int PASS, bool SOLO>
 __device__ __forceinline__ void h3s_pass(const NetArgs& a, const H3Ctx& c, const float* epl, const h8 (&xh)[(RingS<KIN, MOUT, NF, MODE, NP>::KS)][2],
-                                         const h8 (&xl)[(RingS<KIN, MOUT, NF, MODE, NP>::KS)][2], int g, const int (&q)[2], const bool (&qok)[2], int lane, int kq) {
+                                         const h8 (&xl)[(RingS<KIN, MOUT, NF, MODE, NP>::KS)][2], int g, const int (&q)[2], const bool (&qok)[2], int lane, int kq,
+                                         f32x4 (&keep)[(RingS<KIN, MOUT, NF, MODE, NP>::G0N)][2]) {
   using G = RingS<KIN, MOUT, NF, MODE, NP>;
   constexpr int NRB = G::NRB;
   constexpr int f2base = PASS * G::NFH * 32;
@@ -1210,14 +1230,15 @@ __device__ __forceinline__ void h3s_pass(const NetArgs& a, const H3Ctx& c, const
     h3_barrier();
   }
   f32x4 acc3[G::G0N][2];
-  h3s_tail<KIN, MOUT, NF, MODE, NP, P0, PASS, SOLO>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, kq, std::make_integer_sequence<int, 2 * G::NCH>());
+  h3s_tail<KIN, MOUT, NF, MODE, NP, P0, PASS, SOLO>(a, c, epl, acc2, acc3, bh, bl, g, q, qok, lane, kq, keep, std::make_integer_sequence<int, 2 * G::NCH>());
 }
 
 template <int KIN, int MOUT, int NF, int MODE, int NP, int PASS, int P0>
 __device__ __forceinline__ void h3s_passes(const NetArgs& a, const H3Ctx& c, const float* epl, const h8 (&xh)[(RingS<KIN, MOUT, NF, MODE, NP>::KS)][2],
-                                           const h8 (&xl)[(RingS<KIN, MOUT, NF, MODE, NP>::KS)][2], int g, const int (&q)[2], const bool (&qok)[2], int lane, int kq) {
-  h3s_pass<KIN, MOUT, NF, MODE, NP, P0, PASS, false>(a, c, epl, xh, xl, g, q, qok, lane, kq);
-  if constexpr (PASS + 1 < NP) h3s_passes<KIN, MOUT, NF, MODE, NP, PASS + 1, (RingS<KIN, MOUT, NF, MODE, NP>::NCH + 1 + P0) & 1>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+                                           const h8 (&xl)[(RingS<KIN, MOUT, NF, MODE, NP>::KS)][2], int g, const int (&q)[2], const bool (&qok)[2], int lane, int kq,
+                                           f32x4 (&keep)[(RingS<KIN, MOUT, NF, MODE, NP>::G0N)][2]) {
+  h3s_pass<KIN, MOUT, NF, MODE, NP, P0, PASS, false>(a, c, epl, xh, xl, g, q, qok, lane, kq, keep);
+  if constexpr (PASS + 1 < NP) h3s_passes<KIN, MOUT, NF, MODE, NP, PASS + 1, (RingS<KIN, MOUT, NF, MODE, NP>::NCH + 1 + P0) & 1>(a, c, epl, xh, xl, g, q, qok, lane, kq, keep);
 }
 
 template <int KIN, int MOUT, int NF, int MODE, int NP, bool SPLIT>
@@ -1293,16 +1314,17 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  f32x4 keep[G::G0N][2];     // pass 0's partial sums of P (RingS::MERGE; otherwise never touched and compiled away)
   if (g) h3_barrier();
   if constexpr (SPLIT) {
-    if (solo_pass == 0) h3s_pass<KIN, MOUT, NF, MODE, NP, 0, 0, true>(a, c, epl, xh, xl, g, q, qok, lane, kq);
-    else if (solo_pass == 1) h3s_pass<KIN, MOUT, NF, MODE, NP, 0, 1, true>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+    if (solo_pass == 0) h3s_pass<KIN, MOUT, NF, MODE, NP, 0, 0, true>(a, c, epl, xh, xl, g, q, qok, lane, kq, keep);
+    else if (solo_pass == 1) h3s_pass<KIN, MOUT, NF, MODE, NP, 0, 1, true>(a, c, epl, xh, xl, g, q, qok, lane, kq, keep);
     else if constexpr (NP > 2) {
-      if (solo_pass == 2) h3s_pass<KIN, MOUT, NF, MODE, NP, 0, 2, true>(a, c, epl, xh, xl, g, q, qok, lane, kq);
-      else h3s_pass<KIN, MOUT, NF, MODE, NP, 0, 3, true>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+      if (solo_pass == 2) h3s_pass<KIN, MOUT, NF, MODE, NP, 0, 2, true>(a, c, epl, xh, xl, g, q, qok, lane, kq, keep);
+      else h3s_pass<KIN, MOUT, NF, MODE, NP, 0, 3, true>(a, c, epl, xh, xl, g, q, qok, lane, kq, keep);
     }
   } else {
-    h3s_passes<KIN, MOUT, NF, MODE, NP, 0, 0>(a, c, epl, xh, xl, g, q, qok, lane, kq);
+    h3s_passes<KIN, MOUT, NF, MODE, NP, 0, 0>(a, c, epl, xh, xl, g, q, qok, lane, kq, keep);
   }
   if (!g) h3_barrier();
 }

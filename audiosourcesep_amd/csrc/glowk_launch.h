@@ -56,11 +56,12 @@ int launch_h3s(const NetArgs& a, hipStream_t s, bool dry) {
     }
   }
   if constexpr (F2) {
+    const bool split = 2 * wgs <= cus;
     if (!dry) {
-      if (2 * wgs <= cus) hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE, 2, true>), dim3(wgs, 2), dim3(512), 0, s, a);
+      if (split) hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE, 2, true>), dim3(wgs, 2), dim3(512), 0, s, a);
       else hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE, 2, false>), dim3(wgs), dim3(512), 0, s, a);
     }
-    return 2;
+    return (!split && RingS<KIN, MOUT, NF, MODE, 2>::MERGE) ? 1 : 2;     // (merged: the two passes' sums leave the kernel as one buffer)
   }
   return 0;
 }
