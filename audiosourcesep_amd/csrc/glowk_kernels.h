@@ -587,7 +587,9 @@ __device__ __forceinline__ void gather8(const float* base, int i, int j0, int h,
 // The waits are builtins so that the compiler's own wait-count bookkeeping sees them.
 __device__ __forceinline__ void h3_barrier() {
   asm volatile("" ::: "memory");
+#ifndef GLOWK_EXP_NOBARRIER   // (diagnostic build, racy on purpose: what do the phase barriers cost?)
   __builtin_amdgcn_s_barrier();
+#endif
   asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void h3_wait_barrier() {
