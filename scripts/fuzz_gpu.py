@@ -1,4 +1,4 @@
-"""Randomised cross-check on the GPU (not part of the test suite): for random shapes and batch sizes -- i.e. random mixes of
+"""Randomised cross-check on the GPU (not part of the test suite; training checks per shape at the end of the loop): for random shapes and batch sizes -- i.e. random mixes of
 launch forms (2/4 passes, split or not, 16x16x32 or 32x32x16 tiling, one lane or four lanes per pixel) -- the fp16x3 kernels
 against the exact-fp32 kernels: log_prob, latent, inverse round trip, input gradient; plus batch independence (a tile's result
 does not depend on what else is in the batch)."""
@@ -9,6 +9,19 @@ from audiosourcesep_amd import _lib
 from audiosourcesep_amd.config import GlowConfig
 from audiosourcesep_amd.synthetic import calibrated_engine, synthetic_mel_tiles
 
+def tile_by_tile(cfg, eseed, x):
+    eng, _ = calibrated_engine(cfg, device=0, init_tiles=16, seed=eseed)
+    out = []
+    for j in range(x.shape[0]):
+        eng.set_precision(_lib.PREC_F32)
+        a = eng.param_grad(x[j:j + 1], -1.0)[1].clone()
+        eng.set_precision(_lib.PREC_F16X3)
+        b = eng.param_grad(x[j:j + 1], -1.0)[1]
+        out.append(float((a - b).norm() / a.norm()))
+    eng.close()
+    return out
+
+
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "0")))
 budget = float(os.environ.get("FUZZ_SECONDS", "240"))
 t_end = time.time() + budget
@@ -18,7 +31,7 @@ while time.time() < t_end:
     L = int(rng.choice([2, 3, 3, 4]))
     unit = 2 ** L
     H, W = unit * int(rng.integers(1, 5)), unit * int(rng.integers(1, 5))
-    F = int(rng.choice([128, 128, 512]))
+    F = int(rng.choice([128, 128, 256, 384, 512]))
     K = int(rng.integers(1, 4))
     if os.environ.get("FUZZ_ONLY"):   # e.g. FUZZ_ONLY=64,64,4,3,512: hammer one shape (random weights, batch sizes, call order)
         H, W, L, K, F = [int(v) for v in os.environ["FUZZ_ONLY"].split(",")]
@@ -26,7 +39,7 @@ while time.time() < t_end:
     eseed = int(rng.integers(1, 10 ** 6))
     eng, params = calibrated_engine(cfg, device=0, init_tiles=16, seed=eseed)
     for _ in range(3):
-        n = int(rng.choice([1, 2, 3, 7, 30, 64, 129, 300, 700])) if F == 128 else int(rng.choice([1, 3, 30, 65, 200]))
+        n = int(rng.choice([1, 2, 3, 7, 30, 64, 129, 300, 700])) if F == 128 else int(rng.choice([1, 3, 30, 65, 200, 520]))
         xseed = int(rng.integers(1, 10 ** 6))
         x = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=xseed)).cuda()
         eng.set_precision(_lib.PREC_F32)
@@ -76,4 +89,37 @@ while time.time() < t_end:
             if not (verdict and lp_ok):
                 sys.exit(1)
             print("   -> isolated ReLU flips, tolerated", flush=True)
+    # ---- training (round 2): the parameter-gradient sweep in both arithmetics, one optimizer step in f16x3, and the kernel images
+    #      refreshed on the device against the host packer's (a fresh engine loading the trained variables): bitwise
+    from audiosourcesep_amd.flow_models.flow_glow import GlowFlow
+    n = int(rng.choice([3, 17, 40]))
+    x = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=int(rng.integers(1, 10 ** 6)))).cuda()
+    eng.set_precision(_lib.PREC_F32)
+    _, ga = eng.param_grad(x, -1.0 / n)
+    ga = ga.clone()
+    eng.set_precision(_lib.PREC_F16X3)
+    lpb, gb = eng.param_grad(x, -1.0 / n)
+    e_pg = float((ga - gb).norm() / ga.norm())
+    worst["param_grad"] = max(worst.get("param_grad", 0.0), e_pg)
+    eng.apply_gradients(gb, "adamax", 1e-4)
+    lp_dev = eng.log_prob(x)
+    other, _ = calibrated_engine(cfg, device=0, init_tiles=16, seed=eseed)
+    GlowFlow(other).load_state_dict(GlowFlow(eng).state_dict())
+    other.set_precision(_lib.PREC_F16X3)
+    same = bool(torch.equal(other.log_prob(x), lp_dev))
+    fb = eng.range_status(sync=False)[1] + other.range_status(sync=False)[1]
+    ok = e_pg < 2e-5 and same and bool(torch.isfinite(lp_dev).all())
+    note = ""
+    if same and not e_pg < 2e-5:   # a systematic difference shows in every tile; a ReLU decided differently by the two arithmetics (see
+        # above) shows in the one tile it happened in: tile by tile, before the optimizer step (a fresh engine, same variables)
+        per = tile_by_tile(cfg, eseed, x)
+        bad = [j for j, e in enumerate(per) if e > 2e-5]
+        note = "; per tile: %d of %d above 2e-5 (max %.1e, median %.1e)" % (len(bad), n, max(per), float(np.median(per)))
+        ok = len(bad) <= 3 and max(per) < 5e-2 and float(np.median(per)) < 2e-6
+    print("%s train: H%d W%d L%d K%d F%d N%d  |g16 - g32| / |g32| %.1e, device-refreshed images == host-packed: %s, fp32 fallbacks %d%s"
+          % ("ok  " if ok else "FAIL", H, W, L, K, F, n, e_pg, same, fb, note), flush=True)
+    if not ok:
+        print("   replay: H=%d W=%d L=%d K=%d F=%d engine seed %d" % (H, W, L, K, F, eseed), flush=True)
+        sys.exit(1)
+    eng.close(); other.close()
 print("fuzz: %d cases, worst %s" % (case, worst))
