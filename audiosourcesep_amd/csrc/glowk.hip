@@ -556,12 +556,39 @@ int launch_wgrad(glowk_handle* h, const float* A, int M, int ones_row, const flo
   if ((size_t)S * M * N > CPART_FLOATS) return fail("wgrad: partial buffer too small");
   WgradArgs a;
   a.A = A; a.B = B; a.M = M; a.N = N; a.a_ones = 0; a.K = K; a.kslice = kslice; a.Cpart = h->trCpart;
-  if (big) hipLaunchKernelGGL((k_wgrad_nt<2>), dim3(tm, tn, S), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k_wgrad_nt<1>), dim3(tm, tn, S), dim3(256), 0, s, a);
+  const bool vec = (K & 3) == 0;
+  if (big && vec) hipLaunchKernelGGL((k_wgrad_nt<2, true>), dim3(tm, tn, S), dim3(256), 0, s, a);
+  else if (big) hipLaunchKernelGGL((k_wgrad_nt<2, false>), dim3(tm, tn, S), dim3(256), 0, s, a);
+  else if (vec) hipLaunchKernelGGL((k_wgrad_nt<1, true>), dim3(tm, tn, S), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_wgrad_nt<1, false>), dim3(tm, tn, S), dim3(256), 0, s, a);
   LAUNCHCHK("k_wgrad_nt");
   const size_t n = (size_t)M * N;
   hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)h->trCpart, S, n, C);
   if (ones_row) hipLaunchKernelGGL(k_rowsum, dim3(N), dim3(256), 0, s, B, K, C + n);
+  LAUNCHCHK("k_sum_parts");
+  return 0;
+}
+
+// the same in the split arithmetic (k_wgrad_h3): sa / sb = the scales the operands are split at
+int launch_wgrad_split(glowk_handle* h, const float* A, int M, const float* B, int N, int K, float sa, float sb, float* C, hipStream_t s) {
+  const bool big = N >= 256;   // the square conv2 gradient; everything else (N = 9 ci + 1, 9 c) is skinny and bound by streaming A
+  const int TM = 128, TN = big ? 128 : 32, tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN, tiles = tm * tn;
+  static const int wg_per_cu = getenv("GLOWK_WGRAD_WGS") ? atoi(getenv("GLOWK_WGRAD_WGS")) : 2;
+  int S = std::max(1, std::min((wg_per_cu * num_cus() + tiles - 1) / tiles, (K + 255) / 256));
+  S = (int)std::max<size_t>(1, std::min<size_t>((size_t)S, CPART_FLOATS / ((size_t)M * N)));
+  const int kslice = (((K + S - 1) / S) + 31) / 32 * 32;
+  S = (K + kslice - 1) / kslice;
+  if ((size_t)S * M * N > CPART_FLOATS) return fail("wgrad: partial buffer too small");
+  WgradSplitArgs a;
+  a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.kslice = kslice; a.S = S; a.tm = tm; a.tn = tn; a.bsA = 0; a.bsB = 0; a.sa = sa; a.sb = sb; a.Cpart = h->trCpart;
+  const bool vec = (K & 3) == 0;
+  if (big && vec) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, true>), dim3(tiles * S), dim3(256), 0, s, a);
+  else if (big) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, false>), dim3(tiles * S), dim3(256), 0, s, a);
+  else if (vec) hipLaunchKernelGGL((k_wgrad_h3<1, 1, 4, 1, true>), dim3(tiles * S), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_wgrad_h3<1, 1, 4, 1, false>), dim3(tiles * S), dim3(256), 0, s, a);
+  LAUNCHCHK("k_wgrad_h3");
+  const size_t n = (size_t)M * N;
+  hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)h->trCpart, S, n, C);
   LAUNCHCHK("k_sum_parts");
   return 0;
 }
@@ -594,9 +621,18 @@ int train_network_grads(glowk_handle* h, TrainCtx* tc, int lvl, int k, const flo
   hipLaunchKernelGGL(k_im2col_planar, dim3((Q + 255) / 256), dim3(256), 0, s, g_o, c, 0, c, Q, lv.h, lv.w, -1, 0, h->trGcol);
   LAUNCHCHK("k_im2col_planar");
   // (3) the three GEMMs over the pixel dimension
-  if (int rc = launch_wgrad(h, R2, F, 1, h->trGcol, 9 * c, Q, h->trC3, s)) return rc;
-  if (int rc = launch_wgrad(h, R1, F, 0, h->trM2, F, Q, h->trC2, s)) return rc;      // (row F of C2 = sum_q M2: from k_rowdot below)
-  if (int rc = launch_wgrad(h, h->trM1, F, 0, h->trXcol, 9 * ci + 1, Q, h->trC1, s)) return rc;
+  static const bool gemm_f32 = getenv("GLOWK_WGRAD_F32") != nullptr;   // (A/B: the exact GEMMs under a split sweep)
+  if (tc->split && !gemm_f32) {
+    // the sweep ran the split kernels: R / M are in the units those kernels split them in, the im2col arrays take the gathers' scale
+    if (int rc = launch_wgrad_split(h, R2, F, h->trGcol, 9 * c, Q, 1.0f, GLOWK_ACT_SCALE, h->trC3, s)) return rc;
+    hipLaunchKernelGGL(k_rowsum, dim3(9 * c), dim3(256), 0, s, (const float*)h->trGcol, Q, h->trC3 + (size_t)F * 9 * c);
+    if (int rc = launch_wgrad_split(h, R1, F, h->trM2, F, Q, 1.0f, 1.0f, h->trC2, s)) return rc;
+    if (int rc = launch_wgrad_split(h, h->trM1, F, h->trXcol, 9 * ci + 1, Q, 1.0f, GLOWK_ACT_SCALE, h->trC1, s)) return rc;
+  } else {
+    if (int rc = launch_wgrad(h, R2, F, 1, h->trGcol, 9 * c, Q, h->trC3, s)) return rc;
+    if (int rc = launch_wgrad(h, R1, F, 0, h->trM2, F, Q, h->trC2, s)) return rc;      // (row F of C2 = sum_q M2: from k_rowdot below)
+    if (int rc = launch_wgrad(h, h->trM1, F, 0, h->trXcol, 9 * ci + 1, Q, h->trC1, s)) return rc;
+  }
   hipLaunchKernelGGL(k_rowdot, dim3(F), dim3(256), 0, s, (const float*)h->trM1, R1, Q, h->trT, (float*)nullptr);
   hipLaunchKernelGGL(k_rowdot, dim3(F), dim3(256), 0, s, (const float*)h->trM2, R2, Q, h->trT + F, h->trC2 + (size_t)F * F);
   LAUNCHCHK("k_rowdot");

@@ -35,6 +35,16 @@ __global__ __launch_bounds__(256) void k_im2col_planar(const float* __restrict__
   if (ones) out[(size_t)(9 * CH) * Q + q] = 1.0f;
 }
 
+// workgroup barrier of the GEMM main loops: this wave's LDS writes are complete (lgkmcnt(0)), but its global loads stay in flight --
+// __syncthreads() makes hipcc drain vmcnt(0) as well, which exposes the full HBM latency of the prefetch in every round (measured:
+// 4.4 us per 32-deep round of k_wgrad_h3 against 0.3 us of MFMA work)
+__device__ __forceinline__ void gemm_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // ---- weight-gradient GEMM:  Cpart[s][m][n] = sum_{k in slice s} A[m][k] * B[n][k] ---------------------------------------
 // A: [M][ldk], B: [N][ldk] row-major, K = the pixel dimension (contiguous).  a_ones: row M of A is an implicit row of ones
 // (so that C[M][n] = sum_k B[n][k]: the bias / BatchNorm-offset sums come out of the same GEMM).
@@ -54,7 +64,7 @@ struct WgradArgs {
 
 // WT = 32 x 32 accumulator tiles per wave in each direction: workgroup tile (64 WT) x (64 WT).  WT = 2 (128 x 128, 64 accumulator
 // registers per lane, every LDS operand read feeds two MFMAs) for the square conv2 gradient, WT = 1 for the skinny ones.
-template <int WT>
+template <int WT, bool VEC>
 __global__ __launch_bounds__(256) void k_wgrad_nt(WgradArgs a) {
   constexpr int TS = 64 * WT;          // tile side
   constexpr int LD = TS + 2;           // k-major LDS rows, padded: the transposing writes of a wave hit 64 distinct banks
@@ -78,19 +88,20 @@ __global__ __launch_bounds__(256) void k_wgrad_nt(WgradArgs a) {
   const int lr = tid >> 3, lk = (tid & 7) * 4;
   // two register sets: the loads of stage c + 2 are issued before the MFMAs of stage c, so a load has two stages to land
   float4 ra[2][RPT], rb[2][RPT];
-  const bool vec = (a.K & 3) == 0;
   auto fetch = [&](long k0, int set) {
 #pragma unroll
     for (int e = 0; e < RPT; ++e) {
       const int m = m0 + lr + 32 * e, n = n0 + lr + 32 * e;
       const long k = k0 + lk;
       float4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-      if (vec) {            // K a multiple of 4: rows are 16-byte aligned and a float4 never straddles the end of a slice
-        if (k < k_end) {
-          if (m < a.M) va = *reinterpret_cast<const float4*>(a.A + (size_t)m * a.K + k);
-          else if (m == a.M && a.a_ones) va = float4{1.f, 1.f, 1.f, 1.f};
-          if (n < a.N) vb = *reinterpret_cast<const float4*>(a.B + (size_t)n * a.K + k);
-        }
+      if constexpr (VEC) {  // K a multiple of 4: rows are 16-byte aligned and a float4 never straddles the end of a slice.
+        // Unconditional loads from clamped addresses, then selects: a branch around a load makes hipcc wait for each one in turn.
+        const long kc = k < (long)a.K - 4 ? k : (long)a.K - 4;
+        const float4 ta = *reinterpret_cast<const float4*>(a.A + (size_t)(m < a.M ? m : a.M - 1) * a.K + kc);
+        const float4 tb = *reinterpret_cast<const float4*>(a.B + (size_t)(n < a.N ? n : a.N - 1) * a.K + kc);
+        const bool in = k < k_end, oka = in && m < a.M, one = in && m == a.M && a.a_ones, okb = in && n < a.N;
+        va.x = oka ? ta.x : one ? 1.f : 0.f; va.y = oka ? ta.y : one ? 1.f : 0.f; va.z = oka ? ta.z : one ? 1.f : 0.f; va.w = oka ? ta.w : one ? 1.f : 0.f;
+        vb.x = okb ? tb.x : 0.f; vb.y = okb ? tb.y : 0.f; vb.z = okb ? tb.z : 0.f; vb.w = okb ? tb.w : 0.f;
       } else {              // odd pixel counts (1 x 1 or 3 x 1 images at the last level): element by element
         float ta[4], tb[4];
 #pragma unroll
@@ -138,12 +149,12 @@ __global__ __launch_bounds__(256) void k_wgrad_nt(WgradArgs a) {
       if (k0 + 64 < k_end) fetch(k0 + 64, 0);
       compute(0);
       if (k0 + 32 < k_end) stage(1, 1);
-      __syncthreads();
+      gemm_barrier();
       if (k0 + 32 >= k_end) break;
       if (k0 + 96 < k_end) fetch(k0 + 96, 1);
       compute(1);
       if (k0 + 64 < k_end) stage(0, 0);
-      __syncthreads();
+      gemm_barrier();
     }
   }
   float* C = a.Cpart + (size_t)s * Mp * a.N;
@@ -155,6 +166,164 @@ __global__ __launch_bounds__(256) void k_wgrad_nt(WgradArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + (wm * WT + i) * 32 + mfma_row(r, kh), n = n0 + (wn * WT + j) * 32 + i32;
         if (m < Mp && n < a.N) C[(size_t)m * a.N + n] = acc[i][j][r];
+      }
+}
+
+// ---- the same GEMM in the split arithmetic (sweeps that ran the fp16-split kernels) ------------------------------------------
+// Cpart[b][s][m][n] = 1 / (sa sb) * sum_{k in slice s} split(sa A_b[m][k]) . split(sb B_b[n][k]),  x = hi + lo in fp16, the three products
+// hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation (fp32-class, section 5 of DESIGN.md; 8/3 of the fp32 MFMA rate).
+// The operands are the fp32 planar arrays the split kernels stored -- the very values those kernels were about to split, in the
+// units they split them in, so the range guard of the sweep covers them (sa = 1) -- and the planar im2col arrays (raw units:
+// sb = GLOWK_ACT_SCALE, what the kernels' own gathers apply).  A workgroup converts every element ONCE while staging it (global ->
+// registers -> hi / lo planes in LDS, double buffered; rows of 32 k padded to 80 bytes: a wave's 16-byte fragment reads are
+// conflict free); a wave owns WTM x WTN accumulator tiles of 32 x 32.  Two shapes: 128 x 128 (2 x 2 waves of 64 x 64) for the square
+// conv2 gradient, 128 x 32 (4 x 1 waves of 32 x 32) for the skinny conv1 / conv3 ones, which are bound by streaming A.
+// A launch covers `batch` independent GEMMs (the steps of a level) of S slices each.
+struct WgradSplitArgs {
+  const float* A;
+  const float* B;
+  int M, N, K;
+  int kslice;        // pixels per slice (multiple of 32)
+  int S;             // slices per batch entry
+  int tm, tn;        // tiles in each direction
+  size_t bsA, bsB;   // floats between the batch entries of A / B
+  float sa, sb;      // powers of two
+  float* Cpart;      // [batch][S][M][N]
+};
+
+// VEC: K is a multiple of 4 (float4 loads; a template parameter because a run-time branch around every load makes hipcc wait for
+// each load in turn)
+template <int WTM, int WTN, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(256, 2) void k_wgrad_h3(WgradSplitArgs a) {
+  static_assert(WM * WN == 4, "four waves");
+  constexpr int TM = 32 * WTM * WM, TN = 32 * WTN * WN;
+  constexpr int LDH = 40;              // halves per LDS row: 32 k + 8 of padding
+  constexpr int EA = TM / 32, EB = TN / 32;
+  __shared__ __attribute__((aligned(16))) _Float16 Ah[2][TM * LDH];
+  __shared__ __attribute__((aligned(16))) _Float16 Al[2][TM * LDH];
+  __shared__ __attribute__((aligned(16))) _Float16 Bh[2][TN * LDH];
+  __shared__ __attribute__((aligned(16))) _Float16 Bl[2][TN * LDH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  // 1-D grid of tm * tn * batch * S workgroups.  Hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own
+  // L2); the tiles of one (batch entry, slice) share their operand panels, so they are made to share an XCD: ids are remapped so that
+  // every XCD owns a contiguous run of logical ids (bijective for any grid size), and a logical id is (slice-major) tile-minor.
+  // Without this the 128 x 128 form is bound by HBM at its own arithmetic intensity (fp32 operands: 32 flop / byte = 126 TFLOP/s measured).
+  int wg;
+  {
+    const int nwg = (int)gridDim.x, orig = (int)blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int tiles = a.tm * a.tn, tile = wg % tiles, zz = wg / tiles;
+  const int m0 = (tile % a.tm) * TM, n0 = (tile / a.tm) * TN;
+  const int b = zz / a.S, s = zz % a.S;
+  const float* __restrict__ Ab = a.A + (size_t)b * a.bsA;
+  const float* __restrict__ Bb = a.B + (size_t)b * a.bsB;
+  const long k_begin = (long)s * a.kslice;
+  const long k_end = k_begin + a.kslice < a.K ? k_begin + a.kslice : a.K;
+  f32x16 acc[WTM][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  const int lr = tid >> 3, lk = (tid & 7) * 4;       // loader: rows lr + 32 e, 4 consecutive k
+  float4 ra[EA], rb[EB];
+  auto load4 = [&](const float* base, int row, int rows, long k) -> float4 {
+    float4 v = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (VEC) {   // unconditional load from a clamped address, then select (no branch around the load)
+      const int rc = row < rows ? row : rows - 1;
+      const long kc = k < (long)a.K - 4 ? k : (long)a.K - 4;
+      const float4 t = *reinterpret_cast<const float4*>(base + (size_t)rc * a.K + kc);
+      const bool ok = row < rows && k < k_end;
+      v.x = ok ? t.x : 0.0f; v.y = ok ? t.y : 0.0f; v.z = ok ? t.z : 0.0f; v.w = ok ? t.w : 0.0f;
+    } else if (row < rows) {   // odd pixel counts (1 x 1 or 3 x 1 images at the last level): element by element
+      const float* p = base + (size_t)row * a.K + k;
+      if (k + 0 < k_end) v.x = p[0];
+      if (k + 1 < k_end) v.y = p[1];
+      if (k + 2 < k_end) v.z = p[2];
+      if (k + 3 < k_end) v.w = p[3];
+    }
+    return v;
+  };
+  auto fetch = [&](long k0) {
+#pragma unroll
+    for (int e = 0; e < EA; ++e) ra[e] = load4(Ab, m0 + lr + 32 * e, a.M, k0 + lk);
+#pragma unroll
+    for (int e = 0; e < EB; ++e) rb[e] = load4(Bb, n0 + lr + 32 * e, a.N, k0 + lk);
+  };
+  typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+  auto put = [&](const float4& v, float sc, _Float16* hi, _Float16* lo, int row) {
+    const f32x2 p0 = {v.x * sc, v.y * sc}, p1 = {v.z * sc, v.w * sc};
+    const h2v h0 = __builtin_convertvector(p0, h2v), h1 = __builtin_convertvector(p1, h2v);
+    const f32x2 d0 = p0 - __builtin_convertvector(h0, f32x2), d1 = p1 - __builtin_convertvector(h1, f32x2);
+    const h2v l0 = __builtin_convertvector(d0, h2v), l1 = __builtin_convertvector(d1, h2v);
+    *reinterpret_cast<h4v*>(hi + row * LDH + lk) = h4v{h0[0], h0[1], h1[0], h1[1]};
+    *reinterpret_cast<h4v*>(lo + row * LDH + lk) = h4v{l0[0], l0[1], l1[0], l1[1]};
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < EA; ++e) put(ra[e], a.sa, Ah[buf], Al[buf], lr + 32 * e);
+#pragma unroll
+    for (int e = 0; e < EB; ++e) put(rb[e], a.sb, Bh[buf], Bl[buf], lr + 32 * e);
+  };
+  const int i32 = lane & 31, kh = lane >> 5;
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      h8 fah[WTM], fal[WTM], fbh[WTN], fbl[WTN];
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) {
+        const int off = ((wm * WTM + i) * 32 + i32) * LDH + ks * 16 + 8 * kh;
+        fah[i] = *reinterpret_cast<const h8*>(Ah[buf] + off);
+        fal[i] = *reinterpret_cast<const h8*>(Al[buf] + off);
+      }
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) {
+        const int off = ((wn * WTN + j) * 32 + i32) * LDH + ks * 16 + 8 * kh;
+        fbh[j] = *reinterpret_cast<const h8*>(Bh[buf] + off);
+        fbl[j] = *reinterpret_cast<const h8*>(Bl[buf] + off);
+      }
+      // product by product over the wave's tiles: consecutive MFMAs write different accumulators
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  if (k_begin < k_end) {
+    fetch(k_begin);
+    stage(0);
+    if (k_begin + 32 < k_end) fetch(k_begin + 32);
+    __syncthreads();
+    int buf = 0;
+    for (long k0 = k_begin; k0 < k_end; k0 += 32, buf ^= 1) {
+      const bool more = k0 + 32 < k_end;
+      if (more) stage(buf ^ 1);                   // (buffer buf ^ 1 was last read before the barrier that ended the previous round)
+      if (k0 + 64 < k_end) fetch(k0 + 64);
+      compute(buf);
+      gemm_barrier();
+    }
+  }
+  const float inv = 1.0f / (a.sa * a.sb);
+  float* C = a.Cpart + (size_t)zz * a.M * a.N;
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * WTM + i) * 32 + mfma_row(r, kh), n = n0 + (wn * WTN + j) * 32 + i32;
+        if (m < a.M && n < a.N) C[(size_t)m * a.N + n] = acc[i][j][r] * inv;
       }
 }
 
