@@ -107,7 +107,10 @@ struct glowk_handle {
   float* tr16_scales = nullptr;  // [K][8]
   int trN = 0;
   float *trR1 = nullptr, *trR2 = nullptr, *trM1 = nullptr, *trM2 = nullptr, *trXcol = nullptr, *trGcol = nullptr, *trCpart = nullptr;
-  float *trC1 = nullptr, *trC2 = nullptr, *trC3 = nullptr, *trT = nullptr, *trGv = nullptr;
+  float *trC1 = nullptr, *trC2 = nullptr, *trC3 = nullptr, *trT = nullptr, *trGv = nullptr, *trGo = nullptr;
+  int trNB = 1;                  // steps whose weight-gradient work runs as one batch: K (a level at a time: the planar arrays of all its
+                                 // steps are kept until its sweep is over) when the memory is there and the per-step device blocks are
+                                 // evenly spaced, else 1 (step by step)
   double *trAffPart = nullptr, *trAffSum = nullptr;
   float* trSmall = nullptr;      // staging of the small (ActNorm / 1x1 / conv3-bias) parameters, device side
   float* trKeep = nullptr;       // R1 | R2 of EVERY step, written by the saving forward pass itself when the memory is there (else recomputed per step)
@@ -492,15 +495,29 @@ size_t train_step_pos(const glowk_handle* h, int lvl, int k) { return h->tr_leve
 
 constexpr int AFF_BLOCKS = 32;
 constexpr size_t AFF_NOUT_MAX = 32 * 32 + 32;
-constexpr size_t CPART_FLOATS = (size_t)6 << 20;
+constexpr size_t CPART_FLOATS = (size_t)32 << 20;
+
+// per-step device blocks of a level evenly spaced?  (they are: one image per step inside one allocation per level; checked, not assumed)
+bool level_uniform(const Level& lv) {
+  const size_t K = lv.dev.size();
+  if (K < 2) return true;
+  const ptrdiff_t se = lv.dev[1].ep - lv.dev[0].ep, sa = lv.dev[1].Ainv - lv.dev[0].Ainv, sb = lv.dev[1].binv - lv.dev[0].binv;
+  for (size_t k = 2; k < K; ++k)
+    if (lv.dev[k].ep - lv.dev[0].ep != se * (ptrdiff_t)k || lv.dev[k].Ainv - lv.dev[0].Ainv != sa * (ptrdiff_t)k ||
+        lv.dev[k].binv - lv.dev[0].binv != sb * (ptrdiff_t)k)
+      return false;
+  return true;
+}
 
 int ensure_train(glowk_handle* h, int N) {
   if (N <= h->trN) return 0;
   HIPCHK(hipDeviceSynchronize());
-  float** bufs[] = {&h->trR1, &h->trR2, &h->trM1, &h->trM2, &h->trXcol, &h->trGcol, &h->trGv};
+  float** bufs[] = {&h->trR1, &h->trR2, &h->trM1, &h->trM2, &h->trXcol, &h->trGcol, &h->trGv, &h->trGo, &h->trC1, &h->trC2, &h->trC3, &h->trT};
   for (float** b : bufs) { if (*b) hipFree(*b); *b = nullptr; }
+  if (h->trAffPart) { hipFree(h->trAffPart); h->trAffPart = nullptr; }
+  if (h->trKeep) { hipFree(h->trKeep); h->trKeep = nullptr; h->trKeepN = 0; }
   h->trN = 0;
-  const size_t F = h->cfg.F;
+  const size_t F = h->cfg.F, K = h->cfg.K;
   size_t qmax = 0, xcol = 0, gcol = 0, gv = 0;
   for (const Level& lv : h->levels) {
     const size_t Q = (size_t)N * lv.h * lv.w;
@@ -509,22 +526,9 @@ int ensure_train(glowk_handle* h, int N) {
     gcol = std::max(gcol, (size_t)9 * lv.c * Q);
     gv = std::max(gv, Q * lv.c);
   }
-  HIPCHK(hipMalloc(&h->trR1, F * qmax * 4)); HIPCHK(hipMalloc(&h->trR2, F * qmax * 4));
-  HIPCHK(hipMalloc(&h->trM1, F * qmax * 4)); HIPCHK(hipMalloc(&h->trM2, F * qmax * 4));
-  HIPCHK(hipMalloc(&h->trXcol, xcol * 4)); HIPCHK(hipMalloc(&h->trGcol, gcol * 4)); HIPCHK(hipMalloc(&h->trGv, gv * 4));
-  if (!h->trCpart) {
-    HIPCHK(hipMalloc(&h->trCpart, CPART_FLOATS * 4));
-    HIPCHK(hipMalloc(&h->trC1, (size_t)F * (9 * 16 + 1) * 4));
-    HIPCHK(hipMalloc(&h->trC2, (size_t)(F + 1) * F * 4));
-    HIPCHK(hipMalloc(&h->trC3, (size_t)(F + 1) * 9 * 32 * 4));
-    HIPCHK(hipMalloc(&h->trT, ((size_t)2 * F + 64) * 4));   // T1 | T2 | 64 floats where ragged column blocks dump their stores
-    HIPCHK(hipMalloc(&h->trAffPart, (size_t)AFF_BLOCKS * AFF_NOUT_MAX * 8));
-    HIPCHK(hipMalloc(&h->trAffSum, (size_t)h->cfg.L * h->cfg.K * AFF_NOUT_MAX * 8));
-  }
   // R1 / R2 of all steps at once (4 KB per pixel and step at n_filters 512: 5.6 GB for 32 tiles of 64x64, K = 32, L = 3): kept
   // by the saving forward pass when they fit a quarter of the free memory, otherwise every step re-runs its forward network
   {
-    if (h->trKeep) { hipFree(h->trKeep); h->trKeep = nullptr; h->trKeepN = 0; }
     size_t per_tile = 0;
     h->trKeepOff.assign((size_t)h->cfg.L * h->cfg.K, 0);
     for (int lvl = 0; lvl < h->cfg.L; ++lvl)
@@ -538,58 +542,77 @@ int ensure_train(glowk_handle* h, int N) {
       h->trKeepN = N;
     }
   }
+  // a level at a time (trNB = K): M1 / M2, g_o, g_v and the im2col arrays of all K steps of the largest level -- with R1 / R2 kept and
+  // a third of what is then free; GLOWK_TRAIN_PERSTEP=1 forces the step-by-step path (both are tested)
+  h->trNB = 1;
+  if (h->trKeep && K > 1 && !getenv("GLOWK_TRAIN_PERSTEP")) {
+    bool uniform = true;
+    for (const Level& lv : h->levels) uniform = uniform && level_uniform(lv);
+    const size_t extra = (K * (2 * F * qmax + xcol + gcol + 2 * gv)) * 4;
+    size_t free_b = 0, tot_b = 0;
+    if (uniform && hipMemGetInfo(&free_b, &tot_b) == hipSuccess && extra <= free_b / 3) h->trNB = (int)K;
+  }
+  const size_t nb = (size_t)h->trNB;
+  if (!h->trKeep) HIPCHK(hipMalloc(&h->trR1, 2 * F * qmax * 4));   // R1 | R2 of the step at hand (recomputed)
+  HIPCHK(hipMalloc(&h->trM1, nb * F * qmax * 4)); HIPCHK(hipMalloc(&h->trM2, nb * F * qmax * 4));
+  HIPCHK(hipMalloc(&h->trXcol, nb * xcol * 4)); HIPCHK(hipMalloc(&h->trGcol, nb * gcol * 4));
+  HIPCHK(hipMalloc(&h->trGv, nb * gv * 4)); HIPCHK(hipMalloc(&h->trGo, nb * gv * 4));
+  HIPCHK(hipMalloc(&h->trC1, nb * F * (9 * 16 + 1) * 4));
+  HIPCHK(hipMalloc(&h->trC2, nb * (F + 1) * F * 4));
+  HIPCHK(hipMalloc(&h->trC3, nb * (F + 1) * 9 * 32 * 4));
+  HIPCHK(hipMalloc(&h->trT, (nb * 2 * F + 64) * 4));
+  HIPCHK(hipMalloc(&h->trAffPart, nb * AFF_BLOCKS * AFF_NOUT_MAX * 8));
+  if (!h->trCpart) {
+    HIPCHK(hipMalloc(&h->trCpart, CPART_FLOATS * 4));
+    HIPCHK(hipMalloc(&h->trAffSum, (size_t)h->cfg.L * h->cfg.K * AFF_NOUT_MAX * 8));
+  }
   h->trN = N;
   return 0;
 }
 
-// C[M (+1)][N] = A . B^T over K pixels: split-K MFMA GEMM + fixed-order sum of the partials; ones_row: row M of C = the row sums of B
-// (what an appended row of ones in A would give, without a ninth row tile for one row)
-int launch_wgrad(glowk_handle* h, const float* A, int M, int ones_row, const float* B, int N, int K, float* C, hipStream_t s) {
-  const bool big = M >= 256 && N >= 256 && getenv("GLOWK_WGRAD_128");   // 128 x 128 tiles for the square conv2 gradient: measured 5 % SLOWER
-                                                                          // than 64 x 64 (two workgroups per CU instead of four), kept behind a switch
-  const int TS = big ? 128 : 64, tm = (M + TS - 1) / TS, tn = (N + TS - 1) / TS, tiles = tm * tn;
+// nb GEMMs C_b[M][N] = A_b . B_b^T over K pixels (A_b = A + b bsA, B_b = B + b bsB, C_b = C + b csC): MFMA tiles, split over the pixel
+// dimension into S slices where nb * tiles alone would not fill the chip, partials summed in a fixed order (bitwise repeatable, no
+// atomics); S = 1 writes C directly.  split: the three-product fp16 form (k_wgrad_h3; sa / sb = the scales the operands are split at),
+// else exact fp32 (k_wgrad_nt).
+int launch_wgrad(glowk_handle* h, bool split, const float* A, ptrdiff_t bsA, int M, const float* B, ptrdiff_t bsB, int N, int K, int nb, float sa, float sb,
+                 float* C, size_t csC, hipStream_t s) {
+  const bool big = split ? N >= 256 : (M >= 256 && N >= 256 && getenv("GLOWK_WGRAD_128"));   // (fp32: 128 x 128 tiles measured 5 % slower than 64 x 64)
+  const int TM = split ? 128 : big ? 128 : 64, TN = split ? (big ? 128 : 32) : TM;
+  const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN, tiles = tm * tn;
   static const int wg_per_cu = getenv("GLOWK_WGRAD_WGS") ? atoi(getenv("GLOWK_WGRAD_WGS")) : 2;   // workgroups per CU the split aims at
-  int S = std::max(1, std::min((wg_per_cu * num_cus() + tiles - 1) / tiles, (K + 255) / 256));
-  S = (int)std::max<size_t>(1, std::min<size_t>((size_t)S, CPART_FLOATS / ((size_t)M * N)));   // (the partial buffer bounds the split)
-  int kslice = (((K + S - 1) / S) + 31) / 32 * 32;
-  S = (K + kslice - 1) / kslice;
-  if ((size_t)S * M * N > CPART_FLOATS) return fail("wgrad: partial buffer too small");
-  WgradArgs a;
-  a.A = A; a.B = B; a.M = M; a.N = N; a.a_ones = 0; a.K = K; a.kslice = kslice; a.Cpart = h->trCpart;
-  const bool vec = (K & 3) == 0;
-  if (big && vec) hipLaunchKernelGGL((k_wgrad_nt<2, true>), dim3(tm, tn, S), dim3(256), 0, s, a);
-  else if (big) hipLaunchKernelGGL((k_wgrad_nt<2, false>), dim3(tm, tn, S), dim3(256), 0, s, a);
-  else if (vec) hipLaunchKernelGGL((k_wgrad_nt<1, true>), dim3(tm, tn, S), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k_wgrad_nt<1, false>), dim3(tm, tn, S), dim3(256), 0, s, a);
-  LAUNCHCHK("k_wgrad_nt");
-  const size_t n = (size_t)M * N;
-  hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)h->trCpart, S, n, C);
-  if (ones_row) hipLaunchKernelGGL(k_rowsum, dim3(N), dim3(256), 0, s, B, K, C + n);
-  LAUNCHCHK("k_sum_parts");
-  return 0;
-}
-
-// the same in the split arithmetic (k_wgrad_h3): sa / sb = the scales the operands are split at
-int launch_wgrad_split(glowk_handle* h, const float* A, int M, const float* B, int N, int K, float sa, float sb, float* C, hipStream_t s) {
-  const bool big = N >= 256;   // the square conv2 gradient; everything else (N = 9 ci + 1, 9 c) is skinny and bound by streaming A
-  const int TM = 128, TN = big ? 128 : 32, tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN, tiles = tm * tn;
-  static const int wg_per_cu = getenv("GLOWK_WGRAD_WGS") ? atoi(getenv("GLOWK_WGRAD_WGS")) : 2;
-  int S = std::max(1, std::min((wg_per_cu * num_cus() + tiles - 1) / tiles, (K + 255) / 256));
-  S = (int)std::max<size_t>(1, std::min<size_t>((size_t)S, CPART_FLOATS / ((size_t)M * N)));
+  int S = std::max(1, std::min((wg_per_cu * num_cus() + tiles * nb - 1) / (tiles * nb), (K + 255) / 256));
+  S = (int)std::max<size_t>(1, std::min<size_t>((size_t)S, CPART_FLOATS / ((size_t)M * N * nb)));   // (the partial buffer bounds the split)
   const int kslice = (((K + S - 1) / S) + 31) / 32 * 32;
   S = (K + kslice - 1) / kslice;
-  if ((size_t)S * M * N > CPART_FLOATS) return fail("wgrad: partial buffer too small");
-  WgradSplitArgs a;
-  a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.kslice = kslice; a.S = S; a.tm = tm; a.tn = tn; a.bsA = 0; a.bsB = 0; a.sa = sa; a.sb = sb; a.Cpart = h->trCpart;
-  const bool vec = (K & 3) == 0;
-  if (big && vec) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, true>), dim3(tiles * S), dim3(256), 0, s, a);
-  else if (big) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, false>), dim3(tiles * S), dim3(256), 0, s, a);
-  else if (vec) hipLaunchKernelGGL((k_wgrad_h3<1, 1, 4, 1, true>), dim3(tiles * S), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k_wgrad_h3<1, 1, 4, 1, false>), dim3(tiles * S), dim3(256), 0, s, a);
-  LAUNCHCHK("k_wgrad_h3");
   const size_t n = (size_t)M * N;
-  hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)h->trCpart, S, n, C);
-  LAUNCHCHK("k_sum_parts");
+  if (S > 1 && (size_t)S * nb * n > CPART_FLOATS) return fail("wgrad: partial buffer too small");
+  float* out = S == 1 ? C : h->trCpart;
+  const size_t csz = S == 1 ? csC : n;
+  const bool vec = (K & 3) == 0;
+  if (split) {
+    WgradSplitArgs a;
+    a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.kslice = kslice; a.S = S; a.tm = tm; a.tn = tn; a.bsA = bsA; a.bsB = bsB; a.sa = sa; a.sb = sb;
+    a.Cpart = out; a.csz = csz;
+    const dim3 grid((unsigned)(tiles * S * nb));
+    if (big && vec) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, true>), grid, dim3(256), 0, s, a);
+    else if (big) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, false>), grid, dim3(256), 0, s, a);
+    else if (vec) hipLaunchKernelGGL((k_wgrad_h3<1, 1, 4, 1, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_wgrad_h3<1, 1, 4, 1, false>), grid, dim3(256), 0, s, a);
+    LAUNCHCHK("k_wgrad_h3");
+  } else {
+    WgradArgs a;
+    a.A = A; a.B = B; a.M = M; a.N = N; a.a_ones = 0; a.K = K; a.kslice = kslice; a.Cpart = out; a.S = S; a.bsA = bsA; a.bsB = bsB; a.csz = csz;
+    const dim3 grid(tm, tn, (unsigned)(S * nb));
+    if (big && vec) hipLaunchKernelGGL((k_wgrad_nt<2, true>), grid, dim3(256), 0, s, a);
+    else if (big) hipLaunchKernelGGL((k_wgrad_nt<2, false>), grid, dim3(256), 0, s, a);
+    else if (vec) hipLaunchKernelGGL((k_wgrad_nt<1, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_wgrad_nt<1, false>), grid, dim3(256), 0, s, a);
+    LAUNCHCHK("k_wgrad_nt");
+  }
+  if (S > 1) {
+    hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((n + 255) / 256), nb), dim3(256), 0, s, (const float*)h->trCpart, S, n, C, csC);
+    LAUNCHCHK("k_sum_parts");
+  }
   return 0;
 }
 
@@ -599,69 +622,60 @@ struct TrainCtx {
   bool split;      // the sweep runs the fp16-split kernels (k_net_h3, MODE | 8): planar arrays in scaled units (StepGradArgs::scaled)
 };
 
-// weight gradients of one step's coupling network.  v: the step's saved coupling input [Q][c]; g_o: gradient wrt the network output
-// [Q][c]; the backward launch (mode 8) has just left M2 / M1 in trM2 / trM1.
-int train_network_grads(glowk_handle* h, TrainCtx* tc, int lvl, int k, const float* v, const float* g_o, int N, hipStream_t s) {
+// Weight gradients of the coupling networks of steps k0 .. k0 + nb - 1 of a level (k = backward order), as ONE batch of launches.
+// Entry b reads the saved coupling input v + b v_bs [Q][c], the gradient wrt the network output g_o + b go_bs [Q][c], R1 + b r_bs
+// (R2 follows at + F Q) and M1 / M2 + b m_bs, all planar [F][Q].
+int train_network_grads(glowk_handle* h, TrainCtx* tc, int lvl, int k0, int nb, const float* v, ptrdiff_t v_bs, const float* g_o, ptrdiff_t go_bs,
+                        const float* R1, ptrdiff_t r_bs, const float* M1, const float* M2, ptrdiff_t m_bs, int N, hipStream_t s) {
   const Level& lv = h->levels[lvl];
-  const StepDev& sd = lv.dev[k];
   const int F = h->cfg.F, c = lv.c, ci = c / 2, Q = N * lv.h * lv.w;
-  // (1) R1 / R2: kept by the saving forward pass, or recomputed now from the saved input (the P output of that launch goes to a
-  //     scratch partial of bufP)
-  const float *R1 = h->trR1, *R2 = h->trR2;
-  if (h->trKeep && N <= h->trKeepN) {
-    R1 = h->trKeep + h->trKeepOff[(size_t)lvl * h->cfg.K + (h->cfg.K - 1 - k)] * (size_t)N;   // (blocks are per tile: they scale with the batch)
-    R2 = R1 + (size_t)F * Q;
-  } else {
-    NetArgs nf = net_args(h, lv, sd, v, c, ci, N);
-    nf.P = h->bufP + 2 * h->pstride; nf.st1 = h->trR1; nf.st2 = h->trR2;
-    if (launch_net_raw(c, F, nf, 7, s) < 0) return 1;
-  }
-  // (2) planar im2col operands
-  hipLaunchKernelGGL(k_im2col_planar, dim3((Q + 255) / 256), dim3(256), 0, s, v, c, ci, ci, Q, lv.h, lv.w, 1, 1, h->trXcol);
-  hipLaunchKernelGGL(k_im2col_planar, dim3((Q + 255) / 256), dim3(256), 0, s, g_o, c, 0, c, Q, lv.h, lv.w, -1, 0, h->trGcol);
+  const int N1 = 9 * ci + 1, N3 = 9 * c;
+  const float* R2 = R1 + (size_t)F * Q;
+  const size_t xs = (size_t)N1 * Q, gs = (size_t)N3 * Q, c1s = (size_t)F * N1, c2s = (size_t)(F + 1) * F, c3s = (size_t)(F + 1) * N3, ts = 2 * (size_t)F;
+  // (1) planar im2col operands
+  hipLaunchKernelGGL(k_im2col_planar, dim3((Q + 255) / 256, nb), dim3(256), 0, s, v, c, ci, ci, Q, lv.h, lv.w, 1, 1, h->trXcol, v_bs, (ptrdiff_t)xs);
+  hipLaunchKernelGGL(k_im2col_planar, dim3((Q + 255) / 256, nb), dim3(256), 0, s, g_o, c, 0, c, Q, lv.h, lv.w, -1, 0, h->trGcol, go_bs, (ptrdiff_t)gs);
   LAUNCHCHK("k_im2col_planar");
-  // (3) the three GEMMs over the pixel dimension
+  // (2) the three GEMMs over the pixel dimension.  A split sweep left R / M in the units its kernels split them in; the im2col
+  //     arrays take the scale of those kernels' own gathers.  Row F of C3 = the row sums of Gcol, row F of C2 = sum_q M2 (k_rowdot).
   static const bool gemm_f32 = getenv("GLOWK_WGRAD_F32") != nullptr;   // (A/B: the exact GEMMs under a split sweep)
-  if (tc->split && !gemm_f32) {
-    // the sweep ran the split kernels: R / M are in the units those kernels split them in, the im2col arrays take the gathers' scale
-    if (int rc = launch_wgrad_split(h, R2, F, h->trGcol, 9 * c, Q, 1.0f, GLOWK_ACT_SCALE, h->trC3, s)) return rc;
-    hipLaunchKernelGGL(k_rowsum, dim3(9 * c), dim3(256), 0, s, (const float*)h->trGcol, Q, h->trC3 + (size_t)F * 9 * c);
-    if (int rc = launch_wgrad_split(h, R1, F, h->trM2, F, Q, 1.0f, 1.0f, h->trC2, s)) return rc;
-    if (int rc = launch_wgrad_split(h, h->trM1, F, h->trXcol, 9 * ci + 1, Q, 1.0f, GLOWK_ACT_SCALE, h->trC1, s)) return rc;
-  } else {
-    if (int rc = launch_wgrad(h, R2, F, 1, h->trGcol, 9 * c, Q, h->trC3, s)) return rc;
-    if (int rc = launch_wgrad(h, R1, F, 0, h->trM2, F, Q, h->trC2, s)) return rc;      // (row F of C2 = sum_q M2: from k_rowdot below)
-    if (int rc = launch_wgrad(h, h->trM1, F, 0, h->trXcol, 9 * ci + 1, Q, h->trC1, s)) return rc;
-  }
-  hipLaunchKernelGGL(k_rowdot, dim3(F), dim3(256), 0, s, (const float*)h->trM1, R1, Q, h->trT, (float*)nullptr);
-  hipLaunchKernelGGL(k_rowdot, dim3(F), dim3(256), 0, s, (const float*)h->trM2, R2, Q, h->trT + F, h->trC2 + (size_t)F * F);
+  const bool sg = tc->split && !gemm_f32;
+  const float act = sg ? GLOWK_ACT_SCALE : 1.0f;
+  if (int rc = launch_wgrad(h, sg, R2, r_bs, F, h->trGcol, (ptrdiff_t)gs, N3, Q, nb, 1.0f, act, h->trC3, c3s, s)) return rc;
+  hipLaunchKernelGGL(k_rowsum, dim3(N3, nb), dim3(256), 0, s, (const float*)h->trGcol, Q, h->trC3 + (size_t)F * N3, (ptrdiff_t)gs, c3s);
+  if (int rc = launch_wgrad(h, sg, R1, r_bs, F, M2, m_bs, F, Q, nb, 1.0f, 1.0f, h->trC2, c2s, s)) return rc;
+  if (int rc = launch_wgrad(h, sg, M1, m_bs, F, h->trXcol, (ptrdiff_t)xs, N1, Q, nb, 1.0f, act, h->trC1, c1s, s)) return rc;
+  hipLaunchKernelGGL(k_rowdot, dim3(F, nb), dim3(256), 0, s, M1, R1, Q, h->trT, (float*)nullptr, m_bs, r_bs, ts, (size_t)0);
+  hipLaunchKernelGGL(k_rowdot, dim3(F, nb), dim3(256), 0, s, M2, R2, Q, h->trT + F, h->trC2 + (size_t)F * F, m_bs, r_bs, ts, c2s);
   LAUNCHCHK("k_rowdot");
-  // (4) assemble into the flat gradient vector
+  // (3) assemble into the flat gradient vector
   const TrainOff t = train_off(c, F);
-  const float* p = h->tr_params + train_step_pos(h, lvl, k);
-  float* g = tc->grad + train_step_pos(h, lvl, k);
+  const float* p = h->tr_params + train_step_pos(h, lvl, k0);
+  float* g = tc->grad + train_step_pos(h, lvl, k0);
   StepGradArgs a;
-  a.F = F; a.c = c; a.K2 = p + t.K2; a.K3 = p + t.K3; a.bn = p + t.bn; a.ep = sd.ep; a.eps = h->cfg.bn_eps; a.scaled = tc->split ? 1 : 0;
+  a.F = F; a.c = c; a.K2 = p + t.K2; a.K3 = p + t.K3; a.bn = p + t.bn; a.ep = lv.dev[k0].ep; a.eps = h->cfg.bn_eps; a.scaled = tc->split ? 1 : 0;
   a.C1 = h->trC1; a.C2 = h->trC2; a.C3 = h->trC3; a.T1 = h->trT; a.T2 = h->trT + F; a.scale = tc->scale;
   a.dK1 = g + t.K1; a.dK2 = g + t.K2; a.dK3 = g + t.K3; a.db1 = g + t.b1; a.db2 = g + t.b2; a.db3 = g + t.b3;
   a.dgamma1 = g + t.bn; a.dbeta1 = g + t.bn + F; a.dgamma2 = g + t.bn + 4 * (size_t)F; a.dbeta2 = g + t.bn + 5 * (size_t)F;
+  a.ps = t.total; a.es = nb > 1 ? (size_t)(lv.dev[k0 + 1].ep - lv.dev[k0].ep) : 0; a.c1s = c1s; a.c2s = c2s; a.c3s = c3s; a.ts = ts;
   const size_t work = std::max({(size_t)F * F, (size_t)9 * F * c, (size_t)9 * ci * F});
-  hipLaunchKernelGGL(k_assemble_step_grads, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_assemble_channel_grads, dim3(F), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_assemble_step_grads, dim3((unsigned)((work + 255) / 256), nb), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_assemble_channel_grads, dim3(F, nb), dim3(256), 0, s, a);
   LAUNCHCHK("k_assemble_step_grads");
   return 0;
 }
 
-// sums for the ActNorm / 1x1 gradients of step k: dA = sum_q u^T g_v, db = sum_q g_v  ->  trAffSum[(lvl K + k)]
-int train_affine_sums(glowk_handle* h, int lvl, int k, const float* v, const float* gv, int N, hipStream_t s) {
+// sums for the ActNorm / 1x1 gradients of steps k0 .. k0 + nb - 1: dA = sum_q u^T g_v, db = sum_q g_v  ->  trAffSum[(lvl K + k)]
+int train_affine_sums(glowk_handle* h, int lvl, int k0, int nb, const float* v, ptrdiff_t v_bs, const float* gv, ptrdiff_t gv_bs, int N, hipStream_t s) {
   const Level& lv = h->levels[lvl];
-  const StepDev& sd = lv.dev[k];
+  const StepDev& sd = lv.dev[k0];
   const int Q = N * lv.h * lv.w, c = lv.c;
   const size_t nout = (size_t)c * c + c;
-  CDISPATCH(c, hipLaunchKernelGGL((k_affine_wgrad<CC>), dim3(AFF_BLOCKS), dim3(256), 0, s, v, gv, Q, sd.Ainv, sd.binv, h->trAffPart));
+  const ptrdiff_t a_bs = nb > 1 ? lv.dev[k0 + 1].Ainv - sd.Ainv : 0, b_bs = nb > 1 ? lv.dev[k0 + 1].binv - sd.binv : 0;
+  CDISPATCH(c, hipLaunchKernelGGL((k_affine_wgrad<CC>), dim3(AFF_BLOCKS, nb), dim3(256), 0, s, v, gv, Q, sd.Ainv, sd.binv, h->trAffPart, v_bs, gv_bs, a_bs, b_bs));
   LAUNCHCHK("k_affine_wgrad");
-  hipLaunchKernelGGL(k_sum_parts_f64, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, s, (const double*)h->trAffPart, AFF_BLOCKS, nout,
-                     h->trAffSum + ((size_t)lvl * h->cfg.K + k) * AFF_NOUT_MAX);
+  hipLaunchKernelGGL(k_sum_parts_f64, dim3((unsigned)((nout + 255) / 256), nb), dim3(256), 0, s, (const double*)h->trAffPart, AFF_BLOCKS, nout,
+                     h->trAffSum + ((size_t)lvl * h->cfg.K + k0) * AFF_NOUT_MAX, AFF_NOUT_MAX);
   LAUNCHCHK("k_sum_parts_f64");
   return 0;
 }
@@ -688,13 +702,18 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
     const int Q = N * lv.h * lv.w;
     const size_t blocks = (((size_t)Q + 255) / 256) * 8;
     int npg = 1;                    // partials of Pg the previous network launch of this level left in bufP
+    // training sweep: per-step slots of g_o, g_v, M1 / M2 when the level's weight-gradient work runs as one batch after its sweep
+    const bool level_batch = tc && h->trNB == K && K > 1;
+    const size_t go_slot = level_batch ? (size_t)Q * lv.c : 0, m_slot = level_batch ? (size_t)cfg.F * Q : 0;
+    const ptrdiff_t v_bs = K > 1 ? (ptrdiff_t)h->offV[(size_t)lvl * K] - (ptrdiff_t)h->offV[(size_t)lvl * K + 1] : 0;   // saved inputs: forward order
     for (int k = 0; k < K; ++k) {   // reverse of the forward order K-1 .. 0
       const StepDev& sd = lv.dev[k];
       const size_t sidx = (size_t)lvl * K + (K - 1 - k);
       BwdArgs ba;
       ba.Q = Q; ba.h = lv.h; ba.w = lv.w; ba.flag = flagp(h);
       ba.v = h->saveV + h->offV[sidx]; ba.P = h->saveP + h->offP[sidx]; ba.np = h->save_parts[sidx]; ba.pstride = h->save_pstride; ba.b3 = sd.b3;
-      ba.g_o = g_o; ba.ghalf_out = gh_b; ba.gu_out = nullptr;
+      float* go_k = tc ? h->trGo + (size_t)k * go_slot : g_o;
+      ba.g_o = go_k; ba.ghalf_out = gh_b; ba.gu_out = nullptr;
       if (k == 0) {
         // gradient wrt the block output: the latent slice itself (last block) or what k_bwd_split assembled
         ba.ghalf_in = nullptr; ba.Pg = nullptr; ba.npg = 1; ba.pgstride = 0; ba.A = nullptr;
@@ -705,22 +724,32 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
         ba.ghalf_in = gh_a; ba.Pg = Pg; ba.npg = npg; ba.pgstride = h->pstride; ba.gv_direct = nullptr; ba.gvd_stride = 0; ba.gvd_off = 0;
         ba.A = lv.dev[k - 1].Afwd;
       }
-      ba.gv_out = (tc && k > 0) ? h->trGv : nullptr;
+      ba.gv_out = (tc && k > 0) ? h->trGv + (size_t)(k - 1) * go_slot : nullptr;
       CDISPATCH(lv.c, hipLaunchKernelGGL((k_bwd_light<CC>), dim3((Q + 63) / 64), dim3(256), 0, s, ba));
       LAUNCHCHK("k_bwd_light");
-      if (tc && k > 0)   // g_v of step k-1 is complete: its ActNorm + 1x1 gradient sums
-        if (int rc = train_affine_sums(h, lvl, k - 1, h->saveV + h->offV[sidx + 1], h->trGv, N, s)) return rc;
+      if (tc && k > 0 && !level_batch)   // g_v of step k-1 is complete: its ActNorm + 1x1 gradient sums
+        if (int rc = train_affine_sums(h, lvl, k - 1, 1, h->saveV + h->offV[sidx + 1], 0, h->trGv, 0, N, s)) return rc;
       std::swap(gh_a, gh_b);   // gh_a now holds this step's [g_va, g_yb]
-      NetArgs na = net_args(h, lv, sd, g_o, lv.c, 0, N);
+      NetArgs na = net_args(h, lv, sd, go_k, lv.c, 0, N);
       na.K1p = sd.K3bp; na.R0p = sd.RBp; na.P = Pg;
       na.mask1 = h->saveM + h->offM[sidx];
       na.mask2 = na.mask1 + blocks * NF * 64;
       const bool h3b = (tc ? tc->split : h->precision != GLOWK_PREC_F32) && sd.RHBp;
       if (h3b) { na.RHp = sd.RHBp; na.RSp = sd.RSBp; na.eph = nullptr; na.sc1 = sd.scb1; na.sc2 = sd.scb2; na.sc3 = sd.scb3; na.xlim = sd.xlim_b; }
-      if (tc) { na.st1 = h->trM2; na.st2 = h->trM1; }
+      if (tc) { na.st1 = h->trM2 + (size_t)k * m_slot; na.st2 = h->trM1 + (size_t)k * m_slot; }
       if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, tc ? (tc->split ? 11 : 8) : h3b ? 5 : NET_BWD, &npg)) return rc;
-      if (tc)
-        if (int rc = train_network_grads(h, tc, lvl, k, h->saveV + h->offV[sidx], g_o, N, s)) return rc;
+      if (tc && !level_batch) {
+        // R1 / R2: kept by the saving forward pass, or recomputed now from the saved input (the P output of that launch goes to a
+        // scratch partial of bufP)
+        const float* R1 = h->trR1;
+        if (h->trKeep && N <= h->trKeepN) R1 = h->trKeep + h->trKeepOff[sidx] * (size_t)N;   // (blocks are per tile: they scale with the batch)
+        else {
+          NetArgs nf = net_args(h, lv, sd, h->saveV + h->offV[sidx], lv.c, lv.c / 2, N);
+          nf.P = h->bufP + 2 * h->pstride; nf.st1 = h->trR1; nf.st2 = h->trR1 + (size_t)cfg.F * Q;
+          if (launch_net_raw(lv.c, cfg.F, nf, 7, s) < 0) return 1;
+        }
+        if (int rc = train_network_grads(h, tc, lvl, k, 1, h->saveV + h->offV[sidx], 0, go_k, 0, R1, 0, h->trM1, h->trM2, 0, N, s)) return rc;
+      }
     }
     // first forward step of the block (k = K-1): merge, then through its ActNorm + 1x1 -> g_u of the squeezed block input
     {
@@ -729,11 +758,20 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       ba.ghalf_in = gh_a; ba.Pg = Pg; ba.npg = npg; ba.pgstride = h->pstride; ba.gv_direct = nullptr; ba.gvd_stride = 0; ba.gvd_off = 0;
       ba.A = lv.dev[K - 1].Afwd;
       ba.v = nullptr; ba.P = nullptr; ba.np = 1; ba.pstride = 0; ba.b3 = nullptr; ba.g_o = nullptr; ba.ghalf_out = nullptr; ba.gu_out = g_o;   // reuse g_o as g_u
-      ba.gv_out = tc ? h->trGv : nullptr;
+      ba.gv_out = tc ? h->trGv + (size_t)(K - 1) * go_slot : nullptr;
       CDISPATCH(lv.c, hipLaunchKernelGGL((k_bwd_light<CC>), dim3((Q + 63) / 64), dim3(256), 0, s, ba));
       LAUNCHCHK("k_bwd_light");
-      if (tc)
-        if (int rc = train_affine_sums(h, lvl, K - 1, h->saveV + h->offV[(size_t)lvl * K], h->trGv, N, s)) return rc;
+      if (tc && !level_batch)
+        if (int rc = train_affine_sums(h, lvl, K - 1, 1, h->saveV + h->offV[(size_t)lvl * K], 0, h->trGv, 0, N, s)) return rc;
+    }
+    if (level_batch) {
+      // the level's sweep is over: weight gradients of its K steps in one batch of launches.  Step k (backward order) saved its input at
+      // forward position K-1-k (v_bs < 0) and kept R1 / R2 there; M1 / M2, g_o, g_v sit in slot k.
+      const float* v0 = h->saveV + h->offV[(size_t)lvl * K + (K - 1)];
+      const float* R10 = h->trKeep + h->trKeepOff[(size_t)lvl * K + (K - 1)] * (size_t)N;
+      const ptrdiff_t r_bs = -(ptrdiff_t)(2 * (size_t)cfg.F * Q);
+      if (int rc = train_network_grads(h, tc, lvl, 0, K, v0, v_bs, h->trGo, (ptrdiff_t)go_slot, R10, r_bs, h->trM1, h->trM2, (ptrdiff_t)m_slot, N, s)) return rc;
+      if (int rc = train_affine_sums(h, lvl, 0, K, v0, v_bs, h->trGv, (ptrdiff_t)go_slot, N, s)) return rc;
     }
     if (lvl > 0) {
       const Level& pv = h->levels[lvl - 1];
@@ -1059,7 +1097,7 @@ int glowk_destroy(glowk_handle* h) {
   if (h->h_flag) hipHostFree(h->h_flag);
   {
     void* tr[] = {h->tr_params, h->tr_m, h->tr_v, h->trR1, h->trR2, h->trM1, h->trM2, h->trXcol, h->trGcol, h->trCpart, h->trC1, h->trC2, h->trC3,
-                  h->trT, h->trGv, h->trAffPart, h->trAffSum, h->trSmall, h->trKeep, h->tr16_src, h->tr16_S, h->tr16_scales};
+                  h->trT, h->trGv, h->trGo, h->trAffPart, h->trAffSum, h->trSmall, h->trKeep, h->tr16_src, h->tr16_S, h->tr16_scales};
     for (void* p : tr) if (p) hipFree(p);
     for (int* m : h->tr_map) if (m) hipFree(m);
     for (int* m : h->tr_map16) if (m) hipFree(m);

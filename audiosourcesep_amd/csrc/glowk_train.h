@@ -20,10 +20,13 @@
 
 // ---- im2col in planar form -------------------------------------------------------------------------------------------
 // out[(tap * CH + ch)][q] = in[q + sgn * d(tap)][in_off + ch] inside the image, 0 outside; row 9 * CH (if ones) = 1
+// blockIdx.y = batch entry (a step of the level): in / out advance by in_bs / out_bs floats (in_bs may be negative)
 __global__ __launch_bounds__(256) void k_im2col_planar(const float* __restrict__ in, int in_stride, int in_off, int CH, int Q, int h, int w,
-                                                      int sgn, int ones, float* __restrict__ out) {
+                                                      int sgn, int ones, float* __restrict__ out, ptrdiff_t in_bs, ptrdiff_t out_bs) {
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= Q) return;
+  in += (ptrdiff_t)blockIdx.y * in_bs;
+  out += (ptrdiff_t)blockIdx.y * out_bs;
   const int hw = h * w, rem = q % hw, i = rem / w, j = rem % w;
   for (int tap = 0; tap < 9; ++tap) {
     const int dy = sgn * (tap / 3 - 1), dx = sgn * (tap % 3 - 1);
@@ -59,7 +62,10 @@ struct WgradArgs {
   int a_ones;        // 1: an extra row M of ones
   int K;             // pixels
   int kslice;        // pixels per split (multiple of 32)
-  float* Cpart;      // [S][Mp][Np], Mp = M + a_ones, Np = N
+  float* Cpart;      // [batch][S][Mp][Np], Mp = M + a_ones, Np = N; output z = b * S + s starts at Cpart + z * csz
+  int S;             // slices per batch entry (blockIdx.z = b * S + s)
+  ptrdiff_t bsA, bsB;   // floats between the batch entries of A / B (may be negative)
+  size_t csz;        // floats between consecutive outputs (>= Mp * Np)
 };
 
 // WT = 32 x 32 accumulator tiles per wave in each direction: workgroup tile (64 WT) x (64 WT).  WT = 2 (128 x 128, 64 accumulator
@@ -73,8 +79,10 @@ __global__ __launch_bounds__(256) void k_wgrad_nt(WgradArgs a) {
   __shared__ float Bs[2][32][LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * TS, n0 = blockIdx.y * TS, s = blockIdx.z;
+  const int m0 = blockIdx.x * TS, n0 = blockIdx.y * TS, s = blockIdx.z % a.S;
   const int Mp = a.M + a.a_ones;
+  a.A += (ptrdiff_t)(blockIdx.z / a.S) * a.bsA;
+  a.B += (ptrdiff_t)(blockIdx.z / a.S) * a.bsB;
   const long k_begin = (long)s * a.kslice;
   const long k_end = k_begin + a.kslice < a.K ? k_begin + a.kslice : a.K;
   f32x16 acc[WT][WT];
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(256) void k_wgrad_nt(WgradArgs a) {
       gemm_barrier();
     }
   }
-  float* C = a.Cpart + (size_t)s * Mp * a.N;
+  float* C = a.Cpart + (size_t)blockIdx.z * a.csz;
 #pragma unroll
   for (int i = 0; i < WT; ++i)
 #pragma unroll
@@ -186,9 +194,10 @@ struct WgradSplitArgs {
   int kslice;        // pixels per slice (multiple of 32)
   int S;             // slices per batch entry
   int tm, tn;        // tiles in each direction
-  size_t bsA, bsB;   // floats between the batch entries of A / B
+  ptrdiff_t bsA, bsB;   // floats between the batch entries of A / B (may be negative)
   float sa, sb;      // powers of two
-  float* Cpart;      // [batch][S][M][N]
+  float* Cpart;      // output z = b * S + s starts at Cpart + z * csz
+  size_t csz;        // floats between consecutive outputs (>= M * N)
 };
 
 // VEC: K is a multiple of 4 (float4 loads; a template parameter because a run-time branch around every load makes hipcc wait for
@@ -217,8 +226,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h3(WgradSplitArgs a) {
   const int tiles = a.tm * a.tn, tile = wg % tiles, zz = wg / tiles;
   const int m0 = (tile % a.tm) * TM, n0 = (tile / a.tm) * TN;
   const int b = zz / a.S, s = zz % a.S;
-  const float* __restrict__ Ab = a.A + (size_t)b * a.bsA;
-  const float* __restrict__ Bb = a.B + (size_t)b * a.bsB;
+  const float* __restrict__ Ab = a.A + (ptrdiff_t)b * a.bsA;
+  const float* __restrict__ Bb = a.B + (ptrdiff_t)b * a.bsB;
   const long k_begin = (long)s * a.kslice;
   const long k_end = k_begin + a.kslice < a.K ? k_begin + a.kslice : a.K;
   f32x16 acc[WTM][WTN];
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h3(WgradSplitArgs a) {
     }
   }
   const float inv = 1.0f / (a.sa * a.sb);
-  float* C = a.Cpart + (size_t)zz * a.M * a.N;
+  float* C = a.Cpart + (size_t)zz * a.csz;
 #pragma unroll
   for (int i = 0; i < WTM; ++i)
 #pragma unroll
@@ -328,9 +337,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h3(WgradSplitArgs a) {
 }
 
 // out[n] = sum_k B[n][k]  (fp64 accumulation, one workgroup per row): the sums the appended row of ones used to deliver
-__global__ __launch_bounds__(256) void k_rowsum(const float* __restrict__ B, int K, float* __restrict__ out) {
+// blockIdx.y = batch entry: B advances by b_bs floats, out by out_bs
+__global__ __launch_bounds__(256) void k_rowsum(const float* __restrict__ B, int K, float* __restrict__ out, ptrdiff_t b_bs, size_t out_bs) {
   __shared__ double red[4];
-  const float* b = B + (size_t)blockIdx.x * K;
+  const float* b = B + (ptrdiff_t)blockIdx.y * b_bs + (size_t)blockIdx.x * K;
+  out += (size_t)blockIdx.y * out_bs;
   double t = 0.0;
   for (int k = threadIdx.x; k < K; k += 256) t += (double)b[k];
 #pragma unroll
@@ -340,19 +351,23 @@ __global__ __launch_bounds__(256) void k_rowsum(const float* __restrict__ B, int
   if (threadIdx.x == 0) out[blockIdx.x] = (float)(red[0] + red[1] + red[2] + red[3]);
 }
 
-// sum of the split-K partials: C[e] = sum_s Cpart[s][e]  (fixed order)
-__global__ __launch_bounds__(256) void k_sum_parts(const float* __restrict__ part, int S, size_t n, float* __restrict__ out) {
+// sum of the split-K partials: C[e] = sum_s Cpart[s][e]  (fixed order); blockIdx.y = batch entry: S * n partials each, out_bs floats apart
+__global__ __launch_bounds__(256) void k_sum_parts(const float* __restrict__ part, int S, size_t n, float* __restrict__ out, size_t out_bs) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
+  part += (size_t)blockIdx.y * S * n;
+  out += (size_t)blockIdx.y * out_bs;
   float t = 0.0f;
   for (int s = 0; s < S; ++s) t += part[(size_t)s * n + e];
   out[e] = t;
 }
 
 // the same for fp64 partials (k_affine_wgrad)
-__global__ __launch_bounds__(256) void k_sum_parts_f64(const double* __restrict__ part, int S, size_t n, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_sum_parts_f64(const double* __restrict__ part, int S, size_t n, double* __restrict__ out, size_t out_bs) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
+  part += (size_t)blockIdx.y * S * n;
+  out += (size_t)blockIdx.y * out_bs;
   double t = 0.0;
   for (int s = 0; s < S; ++s) t += part[(size_t)s * n + e];
   out[e] = t;
@@ -360,10 +375,13 @@ __global__ __launch_bounds__(256) void k_sum_parts_f64(const double* __restrict_
 
 // out[f] = sum_q X[f][q] * Y[f][q]  and, if sum_x != null, sum_x[f] = sum_q X[f][q]   (one workgroup per channel row; fp64
 // accumulation, fixed order; the row sums ride along for free: the rows are being read anyway)
+// blockIdx.y = batch entry: X / Y advance by x_bs / y_bs floats (may be negative), out by out_bs, sum_x by sum_bs
 __global__ __launch_bounds__(256) void k_rowdot(const float* __restrict__ X, const float* __restrict__ Y, int Q, float* __restrict__ out,
-                                               float* __restrict__ sum_x) {
+                                               float* __restrict__ sum_x, ptrdiff_t x_bs, ptrdiff_t y_bs, size_t out_bs, size_t sum_bs) {
   __shared__ double red[2][4];
   const int f = blockIdx.x;
+  X += (ptrdiff_t)blockIdx.y * x_bs; Y += (ptrdiff_t)blockIdx.y * y_bs; out += (size_t)blockIdx.y * out_bs;
+  if (sum_x) sum_x += (size_t)blockIdx.y * sum_bs;
   const float* x = X + (size_t)f * Q;
   const float* y = Y + (size_t)f * Q;
   double t = 0.0, u = 0.0;
@@ -409,7 +427,15 @@ struct StepGradArgs {
   const float *C1, *C2, *C3, *T1, *T2;
   float scale;
   float *dK1, *db1, *dgamma1, *dbeta1, *dK2, *db2, *dgamma2, *dbeta2, *dK3, *db3;
+  // batch entry b (blockIdx.y: a step of the level): parameters and gradients advance by ps floats, ep by es, C1 / C2 / C3 / T by their strides
+  size_t ps, es, c1s, c2s, c3s, ts;
 };
+__device__ __forceinline__ void step_grad_batch(StepGradArgs& a, size_t b) {
+  a.K2 += b * a.ps; a.K3 += b * a.ps; a.bn += b * a.ps; a.ep += b * a.es;
+  a.C1 += b * a.c1s; a.C2 += b * a.c2s; a.C3 += b * a.c3s; a.T1 += b * a.ts; a.T2 += b * a.ts;
+  a.dK1 += b * a.ps; a.db1 += b * a.ps; a.dgamma1 += b * a.ps; a.dbeta1 += b * a.ps; a.dK2 += b * a.ps; a.db2 += b * a.ps;
+  a.dgamma2 += b * a.ps; a.dbeta2 += b * a.ps; a.dK3 += b * a.ps; a.db3 += b * a.ps;
+}
 
 __device__ __forceinline__ void bn_fold(const float* bn, int F, int layer, int f, float eps, float& g, float& d) {
   const float* b = bn + (size_t)layer * 4 * F;
@@ -426,6 +452,7 @@ __device__ __forceinline__ float pow2_of_gain_inv(float g) {   // 2^-e with g = 
 
 // grid: enough blocks of 256 threads to cover max(F * F, 9 * F * c, 9 * ci * F)
 __global__ __launch_bounds__(256) void k_assemble_step_grads(StepGradArgs a) {
+  step_grad_batch(a, blockIdx.y);
   const int F = a.F, c = a.c, ci = c / 2, N1 = 9 * ci + 1, N3 = 9 * c;
   const float *g1 = a.ep + F, *d1 = a.ep + 2 * (size_t)F, *g2 = a.ep + 4 * (size_t)F, *d2 = a.ep + 5 * (size_t)F;
   const float iact = a.scaled ? 1.0f / GLOWK_ACT_SCALE : 1.0f;
@@ -453,6 +480,7 @@ __global__ __launch_bounds__(256) void k_assemble_step_grads(StepGradArgs a) {
 // SH2[f] = sum_k K3[k][f] SG[k] and SH1[f] = sum_f2 K2[f][f2] (sum_q g_a2[f2]) reduced across its threads (fp64, fixed order)
 __global__ __launch_bounds__(256) void k_assemble_channel_grads(StepGradArgs a) {
   __shared__ double red[2][4];
+  step_grad_batch(a, blockIdx.y);
   const int F = a.F, c = a.c, ci = c / 2, N1 = 9 * ci + 1, N3 = 9 * c, f = blockIdx.x;
   const float *g1 = a.ep + F, *g2 = a.ep + 4 * (size_t)F;
   const float iact = a.scaled ? 1.0f / GLOWK_ACT_SCALE : 1.0f;
@@ -485,12 +513,16 @@ __global__ __launch_bounds__(256) void k_assemble_channel_grads(StepGradArgs a) 
 
 // ---- ActNorm + 1x1: the fused per-pixel affine v = u A + b.  part[block][c*c + c]: sum_q u_i g_j, sum_q g_j over the block's pixels
 // (u is not kept by the forward pass: u = v Ainv + binv)
+// blockIdx.y = batch entry (a step of the level): v / gv / Ainv / binv advance by their strides, part by gridDim.x * NOUT
 template <int C>
 __global__ __launch_bounds__(256) void k_affine_wgrad(const float* __restrict__ v, const float* __restrict__ gv, int Q, const float* __restrict__ Ainv,
-                                                     const float* __restrict__ binv, double* __restrict__ part) {
+                                                     const float* __restrict__ binv, double* __restrict__ part, ptrdiff_t v_bs, ptrdiff_t gv_bs,
+                                                     ptrdiff_t a_bs, ptrdiff_t b_bs) {
   __shared__ float us[64][C + 1];
   __shared__ float gs[64][C + 1];
   constexpr int NOUT = C * C + C;
+  v += (ptrdiff_t)blockIdx.y * v_bs; gv += (ptrdiff_t)blockIdx.y * gv_bs; Ainv += (ptrdiff_t)blockIdx.y * a_bs; binv += (ptrdiff_t)blockIdx.y * b_bs;
+  part += (size_t)blockIdx.y * gridDim.x * NOUT;
   constexpr int PER = (NOUT + 255) / 256;
   double acc[PER];
 #pragma unroll

@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
   const double flop = 2.0 * M * N * (double)K * batch;
   auto report = [&](const char* name, float ms, int reps) { printf("%-28s %8.1f us  %7.1f TFLOP/s (fp32-equivalent)\n", name, ms / reps * 1e3, flop / (ms / reps * 1e-3) / 1e12); };
   {
-    WgradSplitArgs a; a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.kslice = kslice; a.S = S; a.bsA = hA.size(); a.bsB = hB.size(); a.sa = 1.0f; a.sb = 4.0f; a.Cpart = Cp;
+    WgradSplitArgs a; a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.kslice = kslice; a.S = S; a.bsA = hA.size(); a.bsB = hB.size(); a.sa = 1.0f; a.sb = 4.0f; a.Cpart = Cp; a.csz = (size_t)M * N;
     a.tm = (M + 127) / 128; a.tn = (N + (N >= 256 ? 127 : 31)) / (N >= 256 ? 128 : 32);
     const bool big = N >= 256;
     const int TM = 128, TN = big ? 128 : 32;
@@ -45,7 +45,7 @@ int main(int argc, char** argv) {
     printf("M %d N %d K %d S %d batch %d grid %d x %d x %d\n", M, N, K, S, batch, grid.x, grid.y, grid.z);
     report("k_wgrad_h3 (fp16 split)", ms, 20);
     // spot check against fp64 on the host (batch entry 0)
-    hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, 0, (const float*)Cp, S, (size_t)M * N, C);
+    hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, 0, (const float*)Cp, S, (size_t)M * N, C, (size_t)0);
     std::vector<float> hC((size_t)M * N);
     CK(hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost));
     double worst = 0, scale = 0;
@@ -58,7 +58,7 @@ int main(int argc, char** argv) {
     printf("   max |C - fp64| / max |C| over 64 entries: %.2e\n", worst / scale);
   }
   if (batch == 1) {
-    WgradArgs a; a.A = A; a.B = B; a.M = M; a.N = N; a.a_ones = 0; a.K = K; a.kslice = kslice; a.Cpart = Cp;
+    WgradArgs a; a.A = A; a.B = B; a.M = M; a.N = N; a.a_ones = 0; a.K = K; a.kslice = kslice; a.Cpart = Cp; a.S = S; a.bsA = 0; a.bsB = 0; a.csz = (size_t)M * N;
     dim3 grid((M + 63) / 64, (N + 63) / 64, S);
     for (int it = 0; it < 3; ++it) hipLaunchKernelGGL((k_wgrad_nt<1, true>), grid, dim3(256), 0, 0, a);
     CK(hipDeviceSynchronize());
