@@ -577,7 +577,7 @@ int ensure_train(glowk_handle* h, int N) {
 int launch_wgrad(glowk_handle* h, bool split, const float* A, ptrdiff_t bsA, int M, const float* B, ptrdiff_t bsB, int N, int K, int nb, float sa, float sb,
                  float* C, size_t csC, hipStream_t s) {
   const bool big = split ? N >= 256 : (M >= 256 && N >= 256 && getenv("GLOWK_WGRAD_128"));   // (fp32: 128 x 128 tiles measured 5 % slower than 64 x 64)
-  const int TM = split ? 128 : big ? 128 : 64, TN = split ? (big ? 128 : 32) : TM;
+  const int TM = split ? 128 : big ? 128 : 64, TN = split ? (big ? 128 : 64) : TM;
   const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN, tiles = tm * tn;
   static const int wg_per_cu = getenv("GLOWK_WGRAD_WGS") ? atoi(getenv("GLOWK_WGRAD_WGS")) : 2;   // workgroups per CU the split aims at
   int S = std::max(1, std::min((wg_per_cu * num_cus() + tiles * nb - 1) / (tiles * nb), (K + 255) / 256));
@@ -596,8 +596,8 @@ int launch_wgrad(glowk_handle* h, bool split, const float* A, ptrdiff_t bsA, int
     const dim3 grid((unsigned)(tiles * S * nb));
     if (big && vec) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, true>), grid, dim3(256), 0, s, a);
     else if (big) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, false>), grid, dim3(256), 0, s, a);
-    else if (vec) hipLaunchKernelGGL((k_wgrad_h3<1, 1, 4, 1, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_wgrad_h3<1, 1, 4, 1, false>), grid, dim3(256), 0, s, a);
+    else if (vec) hipLaunchKernelGGL((k_wgrad_h3<1, 2, 4, 1, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_wgrad_h3<1, 2, 4, 1, false>), grid, dim3(256), 0, s, a);
     LAUNCHCHK("k_wgrad_h3");
   } else {
     WgradArgs a;

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_wgrad_nt(WgradArgs a) {
 // sb = GLOWK_ACT_SCALE, what the kernels' own gathers apply).  A workgroup converts every element ONCE while staging it (global ->
 // registers -> hi / lo planes in LDS, double buffered; rows of 32 k padded to 80 bytes: a wave's 16-byte fragment reads are
 // conflict free); a wave owns WTM x WTN accumulator tiles of 32 x 32.  Two shapes: 128 x 128 (2 x 2 waves of 64 x 64) for the square
-// conv2 gradient, 128 x 32 (4 x 1 waves of 32 x 32) for the skinny conv1 / conv3 ones, which are bound by streaming A.
+// conv2 gradient, 128 x 64 (4 x 1 waves of 32 x 64) for the skinny conv1 / conv3 ones, which are bound by streaming (and converting) A.
 // A launch covers `batch` independent GEMMs (the steps of a level) of S slices each.
 struct WgradSplitArgs {
   const float* A;
@@ -195,7 +195,7 @@ struct WgradSplitArgs {
   int S;             // slices per batch entry
   int tm, tn;        // tiles in each direction
   ptrdiff_t bsA, bsB;   // floats between the batch entries of A / B (may be negative)
-  float sa, sb;      // powers of two
+  float sa, sb;      // powers of two; sa must be 1
   float* Cpart;      // output z = b * S + s starts at Cpart + z * csz
   size_t csz;        // floats between consecutive outputs (>= M * N)
 };
@@ -239,9 +239,13 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h3(WgradSplitArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   const int lr = tid >> 3, lk = (tid & 7) * 4;       // loader: rows lr + 32 e, 4 consecutive k
   float4 ra[EA], rb[EB];
-  auto load4 = [&](const float* base, int row, int rows, long k) -> float4 {
+  // full: the tile lies inside the matrices and the slice is whole 32-deep rounds -- no clamps, no selects (wave-uniform, decided once)
+  const bool full = VEC && m0 + TM <= a.M && n0 + TN <= a.N && ((k_end - k_begin) & 31) == 0;
+  auto load4 = [&](auto full_tag, const float* base, int row, int rows, long k) -> float4 {
     float4 v = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (VEC) {   // unconditional load from a clamped address, then select (no branch around the load)
+    if constexpr (decltype(full_tag)::value) {
+      v = *reinterpret_cast<const float4*>(base + (size_t)row * a.K + k);
+    } else if constexpr (VEC) {   // unconditional load from a clamped address, then select (no branch around the load)
       const int rc = row < rows ? row : rows - 1;
       const long kc = k < (long)a.K - 4 ? k : (long)a.K - 4;
       const float4 t = *reinterpret_cast<const float4*>(base + (size_t)rc * a.K + kc);
@@ -256,26 +260,27 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h3(WgradSplitArgs a) {
     }
     return v;
   };
-  auto fetch = [&](long k0) {
+  auto fetch = [&](auto full_tag, long k0) {
 #pragma unroll
-    for (int e = 0; e < EA; ++e) ra[e] = load4(Ab, m0 + lr + 32 * e, a.M, k0 + lk);
+    for (int e = 0; e < EA; ++e) ra[e] = load4(full_tag, Ab, m0 + lr + 32 * e, a.M, k0 + lk);
 #pragma unroll
-    for (int e = 0; e < EB; ++e) rb[e] = load4(Bb, n0 + lr + 32 * e, a.N, k0 + lk);
+    for (int e = 0; e < EB; ++e) rb[e] = load4(full_tag, Bb, n0 + lr + 32 * e, a.N, k0 + lk);
   };
   typedef _Float16 h4v __attribute__((ext_vector_type(4)));
-  auto put = [&](const float4& v, float sc, _Float16* hi, _Float16* lo, int row) {
-    const f32x2 p0 = {v.x * sc, v.y * sc}, p1 = {v.z * sc, v.w * sc};
+  auto put = [&](auto unit_tag, const float4& v, float sc, _Float16* hi, _Float16* lo, int row) {
+    constexpr bool UNIT = decltype(unit_tag)::value;    // scale 1: no multiply
+    const f32x2 p0 = {UNIT ? v.x : v.x * sc, UNIT ? v.y : v.y * sc}, p1 = {UNIT ? v.z : v.z * sc, UNIT ? v.w : v.w * sc};
     const h2v h0 = __builtin_convertvector(p0, h2v), h1 = __builtin_convertvector(p1, h2v);
     const f32x2 d0 = p0 - __builtin_convertvector(h0, f32x2), d1 = p1 - __builtin_convertvector(h1, f32x2);
     const h2v l0 = __builtin_convertvector(d0, h2v), l1 = __builtin_convertvector(d1, h2v);
     *reinterpret_cast<h4v*>(hi + row * LDH + lk) = h4v{h0[0], h0[1], h1[0], h1[1]};
     *reinterpret_cast<h4v*>(lo + row * LDH + lk) = h4v{l0[0], l0[1], l1[0], l1[1]};
   };
-  auto stage = [&](int buf) {
+  auto stage = [&](auto ub_tag, int buf) {        // (sa = 1 always: the A operands are the split kernels' own stores)
 #pragma unroll
-    for (int e = 0; e < EA; ++e) put(ra[e], a.sa, Ah[buf], Al[buf], lr + 32 * e);
+    for (int e = 0; e < EA; ++e) put(std::true_type{}, ra[e], 1.0f, Ah[buf], Al[buf], lr + 32 * e);
 #pragma unroll
-    for (int e = 0; e < EB; ++e) put(rb[e], a.sb, Bh[buf], Bl[buf], lr + 32 * e);
+    for (int e = 0; e < EB; ++e) put(ub_tag, rb[e], a.sb, Bh[buf], Bl[buf], lr + 32 * e);
   };
   const int i32 = lane & 31, kh = lane >> 5;
   auto compute = [&](int buf) {
@@ -309,21 +314,26 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h3(WgradSplitArgs a) {
         for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
     }
   };
-  if (k_begin < k_end) {
-    fetch(k_begin);
-    stage(0);
-    if (k_begin + 32 < k_end) fetch(k_begin + 32);
+  auto run = [&](auto full_tag, auto ub_tag) {
+    fetch(full_tag, k_begin);
+    stage(ub_tag, 0);
+    if (k_begin + 32 < k_end) fetch(full_tag, k_begin + 32);
     __syncthreads();
     int buf = 0;
     for (long k0 = k_begin; k0 < k_end; k0 += 32, buf ^= 1) {
       const bool more = k0 + 32 < k_end;
-      if (more) stage(buf ^ 1);                   // (buffer buf ^ 1 was last read before the barrier that ended the previous round)
-      if (k0 + 64 < k_end) fetch(k0 + 64);
+      if (more) stage(ub_tag, buf ^ 1);           // (buffer buf ^ 1 was last read before the barrier that ended the previous round)
+      if (k0 + 64 < k_end) fetch(full_tag, k0 + 64);
       compute(buf);
       gemm_barrier();
     }
+  };
+  if (k_begin < k_end) {
+    if (full && a.sb == 1.0f) run(std::true_type{}, std::true_type{});
+    else if (full) run(std::true_type{}, std::false_type{});
+    else run(std::false_type{}, std::false_type{});
   }
-  const float inv = 1.0f / (a.sa * a.sb);
+  const float inv = 1.0f / a.sb;
   float* C = a.Cpart + (size_t)zz * a.csz;
 #pragma unroll
   for (int i = 0; i < WTM; ++i)

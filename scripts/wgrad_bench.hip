@@ -13,6 +13,7 @@ int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 512, N = argc > 2 ? atoi(argv[2]) : 512, K = argc > 3 ? atoi(argv[3]) : 32768;
   int S = argc > 4 ? atoi(argv[4]) : 24;
   const int batch = argc > 5 ? atoi(argv[5]) : 1;
+  const float sb = argc > 6 ? (float)atof(argv[6]) : 4.0f;
   std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
   unsigned st = 12345;
   auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f - 0.5f; };
@@ -31,15 +32,15 @@ int main(int argc, char** argv) {
   const double flop = 2.0 * M * N * (double)K * batch;
   auto report = [&](const char* name, float ms, int reps) { printf("%-28s %8.1f us  %7.1f TFLOP/s (fp32-equivalent)\n", name, ms / reps * 1e3, flop / (ms / reps * 1e-3) / 1e12); };
   {
-    WgradSplitArgs a; a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.kslice = kslice; a.S = S; a.bsA = hA.size(); a.bsB = hB.size(); a.sa = 1.0f; a.sb = 4.0f; a.Cpart = Cp; a.csz = (size_t)M * N;
-    a.tm = (M + 127) / 128; a.tn = (N + (N >= 256 ? 127 : 31)) / (N >= 256 ? 128 : 32);
+    WgradSplitArgs a; a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.kslice = kslice; a.S = S; a.bsA = hA.size(); a.bsB = hB.size(); a.sa = 1.0f; a.sb = sb; a.Cpart = Cp; a.csz = (size_t)M * N;
+    a.tm = (M + 127) / 128; a.tn = (N + (N >= 256 ? 127 : 63)) / (N >= 256 ? 128 : 64);
     const bool big = N >= 256;
-    const int TM = 128, TN = big ? 128 : 32;
+    const int TM = 128, TN = big ? 128 : 64;
     dim3 grid(((M + TM - 1) / TM) * ((N + TN - 1) / TN) * S * batch);
-    for (int it = 0; it < 3; ++it) { if (big) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, true>), grid, dim3(256), 0, 0, a); else hipLaunchKernelGGL((k_wgrad_h3<1, 1, 4, 1, true>), grid, dim3(256), 0, 0, a); }
+    for (int it = 0; it < 3; ++it) { if (big) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, true>), grid, dim3(256), 0, 0, a); else hipLaunchKernelGGL((k_wgrad_h3<1, 2, 4, 1, true>), grid, dim3(256), 0, 0, a); }
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int it = 0; it < 20; ++it) { if (big) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, true>), grid, dim3(256), 0, 0, a); else hipLaunchKernelGGL((k_wgrad_h3<1, 1, 4, 1, true>), grid, dim3(256), 0, 0, a); }
+    for (int it = 0; it < 20; ++it) { if (big) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, true>), grid, dim3(256), 0, 0, a); else hipLaunchKernelGGL((k_wgrad_h3<1, 2, 4, 1, true>), grid, dim3(256), 0, 0, a); }
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("M %d N %d K %d S %d batch %d grid %d x %d x %d\n", M, N, K, S, batch, grid.x, grid.y, grid.z);
