@@ -107,7 +107,7 @@ struct glowk_handle {
   float* tr16_scales = nullptr;  // [K][8]
   int trN = 0;
   float *trR1 = nullptr, *trR2 = nullptr, *trM1 = nullptr, *trM2 = nullptr, *trXcol = nullptr, *trGcol = nullptr, *trCpart = nullptr;
-  float *trC1 = nullptr, *trC2 = nullptr, *trC3 = nullptr, *trT = nullptr, *trGv = nullptr, *trGo = nullptr;
+  float *trC1 = nullptr, *trC2 = nullptr, *trC3 = nullptr, *trGv = nullptr, *trGo = nullptr;
   int trNB = 1;                  // steps whose weight-gradient work runs as one batch: K (a level at a time: the planar arrays of all its
                                  // steps are kept until its sweep is over) when the memory is there and the per-step device blocks are
                                  // evenly spaced, else 1 (step by step)
@@ -512,7 +512,7 @@ bool level_uniform(const Level& lv) {
 int ensure_train(glowk_handle* h, int N) {
   if (N <= h->trN) return 0;
   HIPCHK(hipDeviceSynchronize());
-  float** bufs[] = {&h->trR1, &h->trR2, &h->trM1, &h->trM2, &h->trXcol, &h->trGcol, &h->trGv, &h->trGo, &h->trC1, &h->trC2, &h->trC3, &h->trT};
+  float** bufs[] = {&h->trR1, &h->trR2, &h->trM1, &h->trM2, &h->trXcol, &h->trGcol, &h->trGv, &h->trGo, &h->trC1, &h->trC2, &h->trC3};
   for (float** b : bufs) { if (*b) hipFree(*b); *b = nullptr; }
   if (h->trAffPart) { hipFree(h->trAffPart); h->trAffPart = nullptr; }
   if (h->trKeep) { hipFree(h->trKeep); h->trKeep = nullptr; h->trKeepN = 0; }
@@ -560,7 +560,6 @@ int ensure_train(glowk_handle* h, int N) {
   HIPCHK(hipMalloc(&h->trC1, nb * F * (9 * 16 + 1) * 4));
   HIPCHK(hipMalloc(&h->trC2, nb * (F + 1) * F * 4));
   HIPCHK(hipMalloc(&h->trC3, nb * (F + 1) * 9 * 32 * 4));
-  HIPCHK(hipMalloc(&h->trT, (nb * 2 * F + 64) * 4));
   HIPCHK(hipMalloc(&h->trAffPart, nb * AFF_BLOCKS * AFF_NOUT_MAX * 8));
   if (!h->trCpart) {
     HIPCHK(hipMalloc(&h->trCpart, CPART_FLOATS * 4));
@@ -631,13 +630,13 @@ int train_network_grads(glowk_handle* h, TrainCtx* tc, int lvl, int k0, int nb, 
   const int F = h->cfg.F, c = lv.c, ci = c / 2, Q = N * lv.h * lv.w;
   const int N1 = 9 * ci + 1, N3 = 9 * c;
   const float* R2 = R1 + (size_t)F * Q;
-  const size_t xs = (size_t)N1 * Q, gs = (size_t)N3 * Q, c1s = (size_t)F * N1, c2s = (size_t)(F + 1) * F, c3s = (size_t)(F + 1) * N3, ts = 2 * (size_t)F;
+  const size_t xs = (size_t)N1 * Q, gs = (size_t)N3 * Q, c1s = (size_t)F * N1, c2s = (size_t)(F + 1) * F, c3s = (size_t)(F + 1) * N3;
   // (1) planar im2col operands
   hipLaunchKernelGGL(k_im2col_planar, dim3((Q + 255) / 256, nb), dim3(256), 0, s, v, c, ci, ci, Q, lv.h, lv.w, 1, 1, h->trXcol, v_bs, (ptrdiff_t)xs);
   hipLaunchKernelGGL(k_im2col_planar, dim3((Q + 255) / 256, nb), dim3(256), 0, s, g_o, c, 0, c, Q, lv.h, lv.w, -1, 0, h->trGcol, go_bs, (ptrdiff_t)gs);
   LAUNCHCHK("k_im2col_planar");
   // (2) the three GEMMs over the pixel dimension.  A split sweep left R / M in the units its kernels split them in; the im2col
-  //     arrays take the scale of those kernels' own gathers.  Row F of C3 = the row sums of Gcol, row F of C2 = sum_q M2 (k_rowdot).
+  //     arrays take the scale of those kernels' own gathers.  Row F of C3 = the row sums of Gcol, row F of C2 = sum_q M2.
   static const bool gemm_f32 = getenv("GLOWK_WGRAD_F32") != nullptr;   // (A/B: the exact GEMMs under a split sweep)
   const bool sg = tc->split && !gemm_f32;
   const float act = sg ? GLOWK_ACT_SCALE : 1.0f;
@@ -645,19 +644,18 @@ int train_network_grads(glowk_handle* h, TrainCtx* tc, int lvl, int k0, int nb, 
   hipLaunchKernelGGL(k_rowsum, dim3(N3, nb), dim3(256), 0, s, (const float*)h->trGcol, Q, h->trC3 + (size_t)F * N3, (ptrdiff_t)gs, c3s);
   if (int rc = launch_wgrad(h, sg, R1, r_bs, F, M2, m_bs, F, Q, nb, 1.0f, 1.0f, h->trC2, c2s, s)) return rc;
   if (int rc = launch_wgrad(h, sg, M1, m_bs, F, h->trXcol, (ptrdiff_t)xs, N1, Q, nb, 1.0f, act, h->trC1, c1s, s)) return rc;
-  hipLaunchKernelGGL(k_rowdot, dim3(F, nb), dim3(256), 0, s, M1, R1, Q, h->trT, (float*)nullptr, m_bs, r_bs, ts, (size_t)0);
-  hipLaunchKernelGGL(k_rowdot, dim3(F, nb), dim3(256), 0, s, M2, R2, Q, h->trT + F, h->trC2 + (size_t)F * F, m_bs, r_bs, ts, c2s);
-  LAUNCHCHK("k_rowdot");
+  hipLaunchKernelGGL(k_rowsum, dim3(F, nb), dim3(256), 0, s, M2, Q, h->trC2 + (size_t)F * F, m_bs, c2s);
+  LAUNCHCHK("k_rowsum");
   // (3) assemble into the flat gradient vector
   const TrainOff t = train_off(c, F);
   const float* p = h->tr_params + train_step_pos(h, lvl, k0);
   float* g = tc->grad + train_step_pos(h, lvl, k0);
   StepGradArgs a;
   a.F = F; a.c = c; a.K2 = p + t.K2; a.K3 = p + t.K3; a.bn = p + t.bn; a.ep = lv.dev[k0].ep; a.eps = h->cfg.bn_eps; a.scaled = tc->split ? 1 : 0;
-  a.C1 = h->trC1; a.C2 = h->trC2; a.C3 = h->trC3; a.T1 = h->trT; a.T2 = h->trT + F; a.scale = tc->scale;
+  a.C1 = h->trC1; a.C2 = h->trC2; a.C3 = h->trC3; a.scale = tc->scale;
   a.dK1 = g + t.K1; a.dK2 = g + t.K2; a.dK3 = g + t.K3; a.db1 = g + t.b1; a.db2 = g + t.b2; a.db3 = g + t.b3;
   a.dgamma1 = g + t.bn; a.dbeta1 = g + t.bn + F; a.dgamma2 = g + t.bn + 4 * (size_t)F; a.dbeta2 = g + t.bn + 5 * (size_t)F;
-  a.ps = t.total; a.es = nb > 1 ? (size_t)(lv.dev[k0 + 1].ep - lv.dev[k0].ep) : 0; a.c1s = c1s; a.c2s = c2s; a.c3s = c3s; a.ts = ts;
+  a.ps = t.total; a.es = nb > 1 ? (size_t)(lv.dev[k0 + 1].ep - lv.dev[k0].ep) : 0; a.c1s = c1s; a.c2s = c2s; a.c3s = c3s;
   const size_t work = std::max({(size_t)F * F, (size_t)9 * F * c, (size_t)9 * ci * F});
   hipLaunchKernelGGL(k_assemble_step_grads, dim3((unsigned)((work + 255) / 256), nb), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_assemble_channel_grads, dim3(F, nb), dim3(256), 0, s, a);
@@ -1097,7 +1095,7 @@ int glowk_destroy(glowk_handle* h) {
   if (h->h_flag) hipHostFree(h->h_flag);
   {
     void* tr[] = {h->tr_params, h->tr_m, h->tr_v, h->trR1, h->trR2, h->trM1, h->trM2, h->trXcol, h->trGcol, h->trCpart, h->trC1, h->trC2, h->trC3,
-                  h->trT, h->trGv, h->trGo, h->trAffPart, h->trAffSum, h->trSmall, h->trKeep, h->tr16_src, h->tr16_S, h->tr16_scales};
+                  h->trGv, h->trGo, h->trAffPart, h->trAffSum, h->trSmall, h->trKeep, h->tr16_src, h->tr16_S, h->tr16_scales};
     for (void* p : tr) if (p) hipFree(p);
     for (int* m : h->tr_map) if (m) hipFree(m);
     for (int* m : h->tr_map16) if (m) hipFree(m);

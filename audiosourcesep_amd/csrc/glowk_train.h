@@ -383,37 +383,12 @@ __global__ __launch_bounds__(256) void k_sum_parts_f64(const double* __restrict_
   out[e] = t;
 }
 
-// out[f] = sum_q X[f][q] * Y[f][q]  and, if sum_x != null, sum_x[f] = sum_q X[f][q]   (one workgroup per channel row; fp64
-// accumulation, fixed order; the row sums ride along for free: the rows are being read anyway)
-// blockIdx.y = batch entry: X / Y advance by x_bs / y_bs floats (may be negative), out by out_bs, sum_x by sum_bs
-__global__ __launch_bounds__(256) void k_rowdot(const float* __restrict__ X, const float* __restrict__ Y, int Q, float* __restrict__ out,
-                                               float* __restrict__ sum_x, ptrdiff_t x_bs, ptrdiff_t y_bs, size_t out_bs, size_t sum_bs) {
-  __shared__ double red[2][4];
-  const int f = blockIdx.x;
-  X += (ptrdiff_t)blockIdx.y * x_bs; Y += (ptrdiff_t)blockIdx.y * y_bs; out += (size_t)blockIdx.y * out_bs;
-  if (sum_x) sum_x += (size_t)blockIdx.y * sum_bs;
-  const float* x = X + (size_t)f * Q;
-  const float* y = Y + (size_t)f * Q;
-  double t = 0.0, u = 0.0;
-  for (int q = threadIdx.x; q < Q; q += 256) {
-    const double xv = (double)x[q];
-    t += xv * (double)y[q];
-    u += xv;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { t += __shfl_down(t, o, 64); u += __shfl_down(u, o, 64); }
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = t; red[1][threadIdx.x >> 6] = u; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    out[f] = (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-    if (sum_x) sum_x[f] = (float)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
-  }
-}
-
 // ---- gradients of one step's coupling network from the GEMM results ------------------------------------------------
 // Notation (flow_tfk_layers.py:73-84): r = relu(conv + b), h = g r + d with g = gamma / sqrt(var + eps), d = beta - mean g.
 //   C3 [F+1][9c]   = [R2; 1] Gcol^T        C2 [F+1][F] = [R1; 1] M2^T        C1 [F][9ci+1] = M1 [Xcol; 1]^T
-//   T1[f] = sum_q M1 R1,  T2[f] = sum_q M2 R2
+//   T1[f] = sum_q M1 R1,  T2[f] = sum_q M2 R2  -- not reduced over the pixels (two more passes over four planar arrays) but taken from the
+//   GEMM results: M1 = mask1 . (K2 g_a2) and R1 vanishes where mask1 does, so T1[f1] = sum_f2 K2[f1][f2] g2[f2] C2[f1][f2]; likewise
+//   T2[f] = sum_{tap,co} K3[tap][f][co] C3[f][tap c + co]
 // and with  SM2[f] = C2[F][f] = sum_q M2,  SM1[f] = C1[f][9ci] = sum_q M1,  SG[k] = C3[F][k] = sum_q Gcol[k]:
 //   dK3[tap][f][co] = g2[f] C3[f][tap c + co] + d2[f] SG[tap c + co]        db3[co] = SG[4 c + co]   (centre tap: no border)
 //   SH2[f] = sum_q g_h2 = sum_{tap,co} K3[tap][f][co] SG[tap c + co]         dbeta2 = SH2    dgamma2 = (T2 - mean2 SH2) / sqrt(var2 + eps)
@@ -434,15 +409,15 @@ struct StepGradArgs {
   // The GEMMs ran on those; the per-row factors are undone here (powers of two and the gains themselves; a gain of exactly zero
   // -- a dead channel -- gets a zero gamma gradient).
   int scaled;
-  const float *C1, *C2, *C3, *T1, *T2;
+  const float *C1, *C2, *C3;
   float scale;
   float *dK1, *db1, *dgamma1, *dbeta1, *dK2, *db2, *dgamma2, *dbeta2, *dK3, *db3;
-  // batch entry b (blockIdx.y: a step of the level): parameters and gradients advance by ps floats, ep by es, C1 / C2 / C3 / T by their strides
-  size_t ps, es, c1s, c2s, c3s, ts;
+  // batch entry b (blockIdx.y: a step of the level): parameters and gradients advance by ps floats, ep by es, C1 / C2 / C3 by their strides
+  size_t ps, es, c1s, c2s, c3s;
 };
 __device__ __forceinline__ void step_grad_batch(StepGradArgs& a, size_t b) {
   a.K2 += b * a.ps; a.K3 += b * a.ps; a.bn += b * a.ps; a.ep += b * a.es;
-  a.C1 += b * a.c1s; a.C2 += b * a.c2s; a.C3 += b * a.c3s; a.T1 += b * a.ts; a.T2 += b * a.ts;
+  a.C1 += b * a.c1s; a.C2 += b * a.c2s; a.C3 += b * a.c3s;
   a.dK1 += b * a.ps; a.db1 += b * a.ps; a.dgamma1 += b * a.ps; a.dbeta1 += b * a.ps; a.dK2 += b * a.ps; a.db2 += b * a.ps;
   a.dgamma2 += b * a.ps; a.dbeta2 += b * a.ps; a.dK3 += b * a.ps; a.db3 += b * a.ps;
 }
@@ -489,29 +464,40 @@ __global__ __launch_bounds__(256) void k_assemble_step_grads(StepGradArgs a) {
 // the per-channel part (biases, BatchNorm gamma / beta): one workgroup per hidden channel f, the two matrix-vector products
 // SH2[f] = sum_k K3[k][f] SG[k] and SH1[f] = sum_f2 K2[f][f2] (sum_q g_a2[f2]) reduced across its threads (fp64, fixed order)
 __global__ __launch_bounds__(256) void k_assemble_channel_grads(StepGradArgs a) {
-  __shared__ double red[2][4];
+  __shared__ double red[4][4];
   step_grad_batch(a, blockIdx.y);
   const int F = a.F, c = a.c, ci = c / 2, N1 = 9 * ci + 1, N3 = 9 * c, f = blockIdx.x;
   const float *g1 = a.ep + F, *g2 = a.ep + 4 * (size_t)F;
   const float iact = a.scaled ? 1.0f / GLOWK_ACT_SCALE : 1.0f;
-  double sh2 = 0.0, sh1 = 0.0;
-  for (int k = threadIdx.x; k < N3; k += 256) sh2 += (double)a.K3[((size_t)(k / c) * F + f) * c + (k % c)] * (double)a.C3[(size_t)F * N3 + k];
-  for (int f2 = threadIdx.x; f2 < F; f2 += 256)      // sum_q g_a2[f2] = g2 sum M2 (exact) = sum G2 / ACT (scaled)
-    sh1 += (double)a.K2[(size_t)f * F + f2] * (double)((a.scaled ? iact : g2[f2]) * a.C2[(size_t)F * F + f2]);
+  double sh2 = 0.0, sh1 = 0.0, t2 = 0.0, t1 = 0.0;
+  for (int k = threadIdx.x; k < N3; k += 256) {
+    const double k3 = (double)a.K3[((size_t)(k / c) * F + f) * c + (k % c)];
+    sh2 += k3 * (double)a.C3[(size_t)F * N3 + k];
+    t2 += k3 * (double)a.C3[(size_t)f * N3 + k];
+  }
+  for (int f2 = threadIdx.x; f2 < F; f2 += 256) {    // sum_q g_a2[f2] = g2 sum M2 (exact) = sum G2 / ACT (scaled)
+    const double k2 = (double)a.K2[(size_t)f * F + f2];
+    sh1 += k2 * (double)((a.scaled ? iact : g2[f2]) * a.C2[(size_t)F * F + f2]);
+    t1 += k2 * (double)(a.scaled ? 1.0f : g2[f2]) * (double)a.C2[(size_t)f * F + f2];
+  }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { sh2 += __shfl_down(sh2, o, 64); sh1 += __shfl_down(sh1, o, 64); }
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sh2; red[1][threadIdx.x >> 6] = sh1; }
+  for (int o = 32; o > 0; o >>= 1) {
+    sh2 += __shfl_down(sh2, o, 64); sh1 += __shfl_down(sh1, o, 64); t2 += __shfl_down(t2, o, 64); t1 += __shfl_down(t1, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sh2; red[1][threadIdx.x >> 6] = sh1; red[2][threadIdx.x >> 6] = t2; red[3][threadIdx.x >> 6] = t1; }
   __syncthreads();
   if (threadIdx.x != 0) return;
   sh2 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
   sh1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  t2 = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+  t1 = red[3][0] + red[3][1] + red[3][2] + red[3][3];
   const float* b1 = a.bn;
   const float* b2 = a.bn + (size_t)4 * F;
-  // T = sum_q M R (exact); scaled: sum_q G A = (ACT g M)(ACT 2^e R) -> T = Ts 2^-e / (ACT^2 g)
-  double t1 = (double)a.T1[f], t2 = (double)a.T2[f];
+  // scaled: the GEMMs ran on A1 = ACT 2^e1 R1, G2 = ACT g2 M2 (C2s = ACT^2 2^e1[f1] g2[f2] C2: the gain is already in) and A2 = ACT 2^e2 R2
+  // against the raw im2col of g_o (C3s = ACT 2^e2[f] C3)
   if (a.scaled) {
-    t1 = g1[f] != 0.0f ? t1 * (double)pow2_of_gain_inv(g1[f]) * (double)iact * (double)iact / (double)g1[f] : 0.0;
-    t2 = g2[f] != 0.0f ? t2 * (double)pow2_of_gain_inv(g2[f]) * (double)iact * (double)iact / (double)g2[f] : 0.0;
+    t1 *= (double)pow2_of_gain_inv(g1[f]) * (double)iact * (double)iact;
+    t2 *= (double)pow2_of_gain_inv(g2[f]) * (double)iact;
   }
   a.db2[f] = a.scale * (a.scaled ? iact : g2[f]) * a.C2[(size_t)F * F + f];
   a.dbeta2[f] = a.scale * (float)sh2;
