@@ -573,17 +573,20 @@ int ensure_train(glowk_handle* h, int N) {
 // dimension into S slices where nb * tiles alone would not fill the chip, partials summed in a fixed order (bitwise repeatable, no
 // atomics); S = 1 writes C directly.  split: the three-product fp16 form (k_wgrad_h3; sa / sb = the scales the operands are split at),
 // else exact fp32 (k_wgrad_nt).
+// b_sums: row M of every C_b = the row sums of B_b (the bias / BatchNorm-offset sums a row of ones appended to A would deliver): inside
+// the split GEMM, by a k_rowsum pass after the exact one.
 int launch_wgrad(glowk_handle* h, bool split, const float* A, ptrdiff_t bsA, int M, const float* B, ptrdiff_t bsB, int N, int K, int nb, float sa, float sb,
-                 float* C, size_t csC, hipStream_t s) {
+                 float* C, size_t csC, bool b_sums, hipStream_t s) {
   const bool big = split ? N >= 256 : (M >= 256 && N >= 256 && getenv("GLOWK_WGRAD_128"));   // (fp32: 128 x 128 tiles measured 5 % slower than 64 x 64)
   const int TM = split ? 128 : big ? 128 : 64, TN = split ? (big ? 128 : 64) : TM;
   const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN, tiles = tm * tn;
   static const int wg_per_cu = getenv("GLOWK_WGRAD_WGS") ? atoi(getenv("GLOWK_WGRAD_WGS")) : 2;   // workgroups per CU the split aims at
   int S = std::max(1, std::min((wg_per_cu * num_cus() + tiles * nb - 1) / (tiles * nb), (K + 255) / 256));
-  S = (int)std::max<size_t>(1, std::min<size_t>((size_t)S, CPART_FLOATS / ((size_t)M * N * nb)));   // (the partial buffer bounds the split)
+  const bool in_gemm = b_sums && split;
+  const size_t n = (size_t)(M + (in_gemm ? 1 : 0)) * N;
+  S = (int)std::max<size_t>(1, std::min<size_t>((size_t)S, CPART_FLOATS / (n * nb)));   // (the partial buffer bounds the split)
   const int kslice = (((K + S - 1) / S) + 31) / 32 * 32;
   S = (K + kslice - 1) / kslice;
-  const size_t n = (size_t)M * N;
   if (S > 1 && (size_t)S * nb * n > CPART_FLOATS) return fail("wgrad: partial buffer too small");
   float* out = S == 1 ? C : h->trCpart;
   const size_t csz = S == 1 ? csC : n;
@@ -591,7 +594,7 @@ int launch_wgrad(glowk_handle* h, bool split, const float* A, ptrdiff_t bsA, int
   if (split) {
     WgradSplitArgs a;
     a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.kslice = kslice; a.S = S; a.tm = tm; a.tn = tn; a.bsA = bsA; a.bsB = bsB; a.sa = sa; a.sb = sb;
-    a.Cpart = out; a.csz = csz;
+    a.Cpart = out; a.csz = csz; a.b_sums = b_sums ? 1 : 0;
     const dim3 grid((unsigned)(tiles * S * nb));
     if (big && vec) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, true>), grid, dim3(256), 0, s, a);
     else if (big) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, false>), grid, dim3(256), 0, s, a);
@@ -611,6 +614,10 @@ int launch_wgrad(glowk_handle* h, bool split, const float* A, ptrdiff_t bsA, int
   if (S > 1) {
     hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((n + 255) / 256), nb), dim3(256), 0, s, (const float*)h->trCpart, S, n, C, csC);
     LAUNCHCHK("k_sum_parts");
+  }
+  if (b_sums && !in_gemm) {
+    hipLaunchKernelGGL(k_rowsum, dim3(N, nb), dim3(256), 0, s, B, K, C + (size_t)M * N, bsB, csC);
+    LAUNCHCHK("k_rowsum");
   }
   return 0;
 }
@@ -640,12 +647,9 @@ int train_network_grads(glowk_handle* h, TrainCtx* tc, int lvl, int k0, int nb, 
   static const bool gemm_f32 = getenv("GLOWK_WGRAD_F32") != nullptr;   // (A/B: the exact GEMMs under a split sweep)
   const bool sg = tc->split && !gemm_f32;
   const float act = sg ? GLOWK_ACT_SCALE : 1.0f;
-  if (int rc = launch_wgrad(h, sg, R2, r_bs, F, h->trGcol, (ptrdiff_t)gs, N3, Q, nb, 1.0f, act, h->trC3, c3s, s)) return rc;
-  hipLaunchKernelGGL(k_rowsum, dim3(N3, nb), dim3(256), 0, s, (const float*)h->trGcol, Q, h->trC3 + (size_t)F * N3, (ptrdiff_t)gs, c3s);
-  if (int rc = launch_wgrad(h, sg, R1, r_bs, F, M2, m_bs, F, Q, nb, 1.0f, 1.0f, h->trC2, c2s, s)) return rc;
-  if (int rc = launch_wgrad(h, sg, M1, m_bs, F, h->trXcol, (ptrdiff_t)xs, N1, Q, nb, 1.0f, act, h->trC1, c1s, s)) return rc;
-  hipLaunchKernelGGL(k_rowsum, dim3(F, nb), dim3(256), 0, s, M2, Q, h->trC2 + (size_t)F * F, m_bs, c2s);
-  LAUNCHCHK("k_rowsum");
+  if (int rc = launch_wgrad(h, sg, R2, r_bs, F, h->trGcol, (ptrdiff_t)gs, N3, Q, nb, 1.0f, act, h->trC3, c3s, true, s)) return rc;
+  if (int rc = launch_wgrad(h, sg, R1, r_bs, F, M2, m_bs, F, Q, nb, 1.0f, 1.0f, h->trC2, c2s, true, s)) return rc;
+  if (int rc = launch_wgrad(h, sg, M1, m_bs, F, h->trXcol, (ptrdiff_t)xs, N1, Q, nb, 1.0f, act, h->trC1, c1s, false, s)) return rc;
   // (3) assemble into the flat gradient vector
   const TrainOff t = train_off(c, F);
   const float* p = h->tr_params + train_step_pos(h, lvl, k0);

@@ -197,7 +197,9 @@ struct WgradSplitArgs {
   ptrdiff_t bsA, bsB;   // floats between the batch entries of A / B (may be negative)
   float sa, sb;      // powers of two; sa must be 1
   float* Cpart;      // output z = b * S + s starts at Cpart + z * csz
-  size_t csz;        // floats between consecutive outputs (>= M * N)
+  size_t csz;        // floats between consecutive outputs (>= M * N, or (M + 1) * N with b_sums)
+  int b_sums;        // 1: row M of every output = the row sums of B over the slice (what a row of ones appended to A would give; fp64
+                     // accumulation in the workgroups of the first row tile, which stage those rows anyway)
 };
 
 // VEC: K is a multiple of 4 (float4 loads; a template parameter because a run-time branch around every load makes hipcc wait for
@@ -276,11 +278,17 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h3(WgradSplitArgs a) {
     *reinterpret_cast<h4v*>(hi + row * LDH + lk) = h4v{h0[0], h0[1], h1[0], h1[1]};
     *reinterpret_cast<h4v*>(lo + row * LDH + lk) = h4v{l0[0], l0[1], l1[0], l1[1]};
   };
-  auto stage = [&](auto ub_tag, int buf) {        // (sa = 1 always: the A operands are the split kernels' own stores)
+  double bsum[EB];
+#pragma unroll
+  for (int e = 0; e < EB; ++e) bsum[e] = 0.0;
+  auto stage = [&](auto ub_tag, auto sum_tag, int buf) {        // (sa = 1 always: the A operands are the split kernels' own stores)
 #pragma unroll
     for (int e = 0; e < EA; ++e) put(std::true_type{}, ra[e], 1.0f, Ah[buf], Al[buf], lr + 32 * e);
 #pragma unroll
-    for (int e = 0; e < EB; ++e) put(ub_tag, rb[e], a.sb, Bh[buf], Bl[buf], lr + 32 * e);
+    for (int e = 0; e < EB; ++e) {
+      put(ub_tag, rb[e], a.sb, Bh[buf], Bl[buf], lr + 32 * e);
+      if constexpr (decltype(sum_tag)::value) bsum[e] += ((double)rb[e].x + (double)rb[e].y) + ((double)rb[e].z + (double)rb[e].w);
+    }
   };
   const int i32 = lane & 31, kh = lane >> 5;
   auto compute = [&](int buf) {
@@ -314,27 +322,42 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h3(WgradSplitArgs a) {
         for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
     }
   };
-  auto run = [&](auto full_tag, auto ub_tag) {
+  auto run = [&](auto full_tag, auto ub_tag, auto sum_tag) {
     fetch(full_tag, k_begin);
-    stage(ub_tag, 0);
+    stage(ub_tag, sum_tag, 0);
     if (k_begin + 32 < k_end) fetch(full_tag, k_begin + 32);
     __syncthreads();
     int buf = 0;
     for (long k0 = k_begin; k0 < k_end; k0 += 32, buf ^= 1) {
       const bool more = k0 + 32 < k_end;
-      if (more) stage(ub_tag, buf ^ 1);           // (buffer buf ^ 1 was last read before the barrier that ended the previous round)
+      if (more) stage(ub_tag, sum_tag, buf ^ 1);  // (buffer buf ^ 1 was last read before the barrier that ended the previous round)
       if (k0 + 64 < k_end) fetch(full_tag, k0 + 64);
       compute(buf);
       gemm_barrier();
     }
   };
+  const bool sums = a.b_sums && m0 == 0;
   if (k_begin < k_end) {
-    if (full && a.sb == 1.0f) run(std::true_type{}, std::true_type{});
-    else if (full) run(std::true_type{}, std::false_type{});
-    else run(std::false_type{}, std::false_type{});
+    if (sums) {
+      if (full && a.sb == 1.0f) run(std::true_type{}, std::true_type{}, std::true_type{});
+      else run(std::false_type{}, std::false_type{}, std::true_type{});
+    } else {
+      if (full && a.sb == 1.0f) run(std::true_type{}, std::true_type{}, std::false_type{});
+      else if (full) run(std::true_type{}, std::false_type{}, std::false_type{});
+      else run(std::false_type{}, std::false_type{}, std::false_type{});
+    }
   }
   const float inv = 1.0f / a.sb;
   float* C = a.Cpart + (size_t)zz * a.csz;
+  if (sums) {   // the 8 loader threads of a row hold its partial sums
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+      double t = bsum[e];
+      t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
+      const int n = n0 + lr + 32 * e;
+      if ((tid & 7) == 0 && n < a.N) C[(size_t)a.M * a.N + n] = (float)t;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < WTM; ++i)
 #pragma unroll
