@@ -126,6 +126,37 @@ def test_parameter_gradients_in_the_split_arithmetic(name):
     assert np.array_equal(flat, flat2)                     # repeatable bit for bit
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_step_by_step_and_recompute_paths_agree_with_the_level_batches(prec, monkeypatch):
+    """Three ways through the weight-gradient work, chosen by free memory (forced here by the environment switches the engine reads
+    when it sizes its training buffers): a level's steps as one batch of launches (default), step by step (GLOWK_TRAIN_PERSTEP), and
+    step by step with every step's forward network re-run instead of its hiddens kept (GLOWK_TRAIN_RECOMPUTE).  Same sums in a
+    different split-K order: equal to fp32 rounding, all three within the bar of the fp64 autograd."""
+    cfg, n = GlowConfig(H=32, W=32, C=1, L=3, K=3, F=256), 5
+    x = synthetic_mel_tiles(n, cfg, seed=23)
+    scale = -1.0 / n
+    flats = {}
+    for mode in ("batch", "GLOWK_TRAIN_PERSTEP", "GLOWK_TRAIN_RECOMPUTE"):
+        if mode != "batch":
+            monkeypatch.setenv(mode, "1")
+        eng, params = calibrated_engine(cfg, device=0, init_tiles=8)
+        if prec == "f16x3":
+            eng.set_precision(_lib.PREC_F16X3)
+            eng.set_range_policy("error")
+        lp, got, flat = engine_grads(eng, params, x, scale)
+        flats[mode] = flat.astype(np.float64)
+        if mode == "batch":
+            lp_ref, ref = oracle_param_grads(x, params, cfg, scale)
+        for k, r in ref.items():
+            np.testing.assert_allclose(got[k], r, atol=2e-4 * max(np.abs(r).max(), 1e-12), rtol=2e-3, err_msg="%s %s" % (mode, k))
+        eng.close()
+        if mode != "batch":
+            monkeypatch.delenv(mode)
+    ref_norm = np.linalg.norm(flats["batch"])
+    for mode in ("GLOWK_TRAIN_PERSTEP", "GLOWK_TRAIN_RECOMPUTE"):
+        assert np.linalg.norm(flats[mode] - flats["batch"]) < 2e-6 * ref_norm, mode
+
+
 @pytest.mark.parametrize("opt", ["adamax", "adam"])
 def test_optimizer_step_and_image_refresh(opt):
     """Two optimizer steps: the variables follow the Keras formulas on the engine's own gradients, and -- the part that
