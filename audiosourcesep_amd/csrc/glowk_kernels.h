@@ -1093,7 +1093,11 @@ __device__ __forceinline__ void h3s_Y(const float4* slot, const h8 (&bh)[2], con
 #pragma unroll
   for (int gi = 0; gi < NG; ++gi) {
     const int o0 = 2 * gi, o1 = 2 * gi + 1;
+#ifdef GLOWK_EXP_SAMEFRAG   // (diagnostic build, wrong results: every group reuses the first group's A fragments -- what do Y's LDS reads cost?)
+    if (gi == 0) load(A[1], 1);
+#else
     if (gi + 1 < NG) load(A[(gi + 1) & 1], gi + 1);
+#endif
     if (!g) {
       if (main_ok) {
 #pragma unroll
