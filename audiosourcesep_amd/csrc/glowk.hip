@@ -603,8 +603,9 @@ int launch_wgrad(glowk_handle* h, bool split, const float* A, ptrdiff_t bsA, int
     LAUNCHCHK("k_wgrad_h3");
   } else {
     WgradArgs a;
-    a.A = A; a.B = B; a.M = M; a.N = N; a.a_ones = 0; a.K = K; a.kslice = kslice; a.Cpart = out; a.S = S; a.bsA = bsA; a.bsB = bsB; a.csz = csz;
-    const dim3 grid(tm, tn, (unsigned)(S * nb));
+    a.A = A; a.B = B; a.M = M; a.N = N; a.a_ones = 0; a.K = K; a.kslice = kslice; a.Cpart = out; a.S = S; a.tm = tm; a.tn = tn; a.bsA = bsA; a.bsB = bsB;
+    a.csz = csz;
+    const dim3 grid((unsigned)(tiles * S * nb));
     if (big && vec) hipLaunchKernelGGL((k_wgrad_nt<2, true>), grid, dim3(256), 0, s, a);
     else if (big) hipLaunchKernelGGL((k_wgrad_nt<2, false>), grid, dim3(256), 0, s, a);
     else if (vec) hipLaunchKernelGGL((k_wgrad_nt<1, true>), grid, dim3(256), 0, s, a);

@@ -63,10 +63,18 @@ struct WgradArgs {
   int K;             // pixels
   int kslice;        // pixels per split (multiple of 32)
   float* Cpart;      // [batch][S][Mp][Np], Mp = M + a_ones, Np = N; output z = b * S + s starts at Cpart + z * csz
-  int S;             // slices per batch entry (blockIdx.z = b * S + s)
+  int S;             // slices per batch entry
+  int tm, tn;        // tiles in each direction (1-D grid of tm * tn * batch * S workgroups, XCD-aware order: see k_wgrad_h3)
   ptrdiff_t bsA, bsB;   // floats between the batch entries of A / B (may be negative)
   size_t csz;        // floats between consecutive outputs (>= Mp * Np)
 };
+
+// logical workgroup id of a 1-D grid such that each of the 8 XCDs (hardware deals consecutive ids round-robin to them) owns a contiguous
+// run of logical ids: tiles that share operand panels then share an L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_contiguous_id() {
+  const int nwg = (int)gridDim.x, orig = (int)blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
 
 // WT = 32 x 32 accumulator tiles per wave in each direction: workgroup tile (64 WT) x (64 WT).  WT = 2 (128 x 128, 64 accumulator
 // registers per lane, every LDS operand read feeds two MFMAs) for the square conv2 gradient, WT = 1 for the skinny ones.
@@ -79,10 +87,11 @@ __global__ __launch_bounds__(256) void k_wgrad_nt(WgradArgs a) {
   __shared__ float Bs[2][32][LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * TS, n0 = blockIdx.y * TS, s = blockIdx.z % a.S;
+  const int wg = xcd_contiguous_id(), tiles = a.tm * a.tn, tile = wg % tiles, zz = wg / tiles;
+  const int m0 = (tile % a.tm) * TS, n0 = (tile / a.tm) * TS, s = zz % a.S;
   const int Mp = a.M + a.a_ones;
-  a.A += (ptrdiff_t)(blockIdx.z / a.S) * a.bsA;
-  a.B += (ptrdiff_t)(blockIdx.z / a.S) * a.bsB;
+  a.A += (ptrdiff_t)(zz / a.S) * a.bsA;
+  a.B += (ptrdiff_t)(zz / a.S) * a.bsB;
   const long k_begin = (long)s * a.kslice;
   const long k_end = k_begin + a.kslice < a.K ? k_begin + a.kslice : a.K;
   f32x16 acc[WT][WT];
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(256) void k_wgrad_nt(WgradArgs a) {
       gemm_barrier();
     }
   }
-  float* C = a.Cpart + (size_t)blockIdx.z * a.csz;
+  float* C = a.Cpart + (size_t)zz * a.csz;
 #pragma unroll
   for (int i = 0; i < WT; ++i)
 #pragma unroll
@@ -220,11 +229,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h3(WgradSplitArgs a) {
   // L2); the tiles of one (batch entry, slice) share their operand panels, so they are made to share an XCD: ids are remapped so that
   // every XCD owns a contiguous run of logical ids (bijective for any grid size), and a logical id is (slice-major) tile-minor.
   // Without this the 128 x 128 form is bound by HBM at its own arithmetic intensity (fp32 operands: 32 flop / byte = 126 TFLOP/s measured).
-  int wg;
-  {
-    const int nwg = (int)gridDim.x, orig = (int)blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  }
+  const int wg = xcd_contiguous_id();
   const int tiles = a.tm * a.tn, tile = wg % tiles, zz = wg / tiles;
   const int m0 = (tile % a.tm) * TM, n0 = (tile / a.tm) * TN;
   const int b = zz / a.S, s = zz % a.S;

@@ -60,14 +60,18 @@ int main(int argc, char** argv) {
   }
   if (batch == 1) {
     WgradArgs a; a.A = A; a.B = B; a.M = M; a.N = N; a.a_ones = 0; a.K = K; a.kslice = kslice; a.Cpart = Cp; a.S = S; a.bsA = 0; a.bsB = 0; a.csz = (size_t)M * N;
-    dim3 grid((M + 63) / 64, (N + 63) / 64, S);
-    for (int it = 0; it < 3; ++it) hipLaunchKernelGGL((k_wgrad_nt<1, true>), grid, dim3(256), 0, 0, a);
-    CK(hipDeviceSynchronize());
-    CK(hipEventRecord(e0));
-    for (int it = 0; it < 20; ++it) hipLaunchKernelGGL((k_wgrad_nt<1, true>), grid, dim3(256), 0, 0, a);
-    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    report("k_wgrad_nt<1> (fp32 MFMA)", ms, 20);
+    for (int wt = 1; wt <= 2; ++wt) {
+      a.tm = (M + 64 * wt - 1) / (64 * wt); a.tn = (N + 64 * wt - 1) / (64 * wt);
+      dim3 grid(a.tm * a.tn * S);
+      auto go = [&]() { if (wt == 1) hipLaunchKernelGGL((k_wgrad_nt<1, true>), grid, dim3(256), 0, 0, a); else hipLaunchKernelGGL((k_wgrad_nt<2, true>), grid, dim3(256), 0, 0, a); };
+      for (int it = 0; it < 3; ++it) go();
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0));
+      for (int it = 0; it < 20; ++it) go();
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      report(wt == 1 ? "k_wgrad_nt<1> (fp32 MFMA)" : "k_wgrad_nt<2> (fp32 MFMA)", ms, 20);
+    }
   }
   return 0;
 }
