@@ -578,9 +578,11 @@ int ensure_train(glowk_handle* h, int N) {
 int launch_wgrad(glowk_handle* h, bool split, const float* A, ptrdiff_t bsA, int M, const float* B, ptrdiff_t bsB, int N, int K, int nb, float sa, float sb,
                  float* C, size_t csC, bool b_sums, hipStream_t s) {
   const bool big = split ? N >= 256 : (M >= 256 && N >= 256 && getenv("GLOWK_WGRAD_128"));   // (fp32: 128 x 128 tiles measured 5 % slower than 64 x 64)
-  const int TM = split ? 128 : big ? 128 : 64, TN = split ? (big ? 128 : 64) : TM;
+  const bool big8 = split && big && M % 256 == 0;   // 8 waves, 256 x 128: a quarter less staging per MFMA (254 -> 290 TFLOP/s on the level-0 conv2 batch)
+  const int TM = big8 ? 256 : split ? 128 : big ? 128 : 64, TN = split ? (big ? 128 : 64) : TM;
   const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN, tiles = tm * tn;
-  static const int wg_per_cu = getenv("GLOWK_WGRAD_WGS") ? atoi(getenv("GLOWK_WGRAD_WGS")) : 2;   // workgroups per CU the split aims at
+  static const int wg_env = getenv("GLOWK_WGRAD_WGS") ? atoi(getenv("GLOWK_WGRAD_WGS")) : 0;   // workgroups per CU the split aims at
+  const int wg_per_cu = wg_env > 0 ? wg_env : big8 ? 1 : 2;                                       // (what fits a CU: 1 of the 8-wave form)
   int S = std::max(1, std::min((wg_per_cu * num_cus() + tiles * nb - 1) / (tiles * nb), (K + 255) / 256));
   const bool in_gemm = b_sums && split;
   const size_t n = (size_t)(M + (in_gemm ? 1 : 0)) * N;
@@ -596,7 +598,9 @@ int launch_wgrad(glowk_handle* h, bool split, const float* A, ptrdiff_t bsA, int
     a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.kslice = kslice; a.S = S; a.tm = tm; a.tn = tn; a.bsA = bsA; a.bsB = bsB; a.sa = sa; a.sb = sb;
     a.Cpart = out; a.csz = csz; a.b_sums = b_sums ? 1 : 0;
     const dim3 grid((unsigned)(tiles * S * nb));
-    if (big && vec) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, true>), grid, dim3(256), 0, s, a);
+    if (big8 && vec) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 4, 2, true>), grid, dim3(512), 0, s, a);
+    else if (big8) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 4, 2, false>), grid, dim3(512), 0, s, a);
+    else if (big && vec) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, true>), grid, dim3(256), 0, s, a);
     else if (big) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, false>), grid, dim3(256), 0, s, a);
     else if (vec) hipLaunchKernelGGL((k_wgrad_h3<1, 2, 4, 1, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_wgrad_h3<1, 2, 4, 1, false>), grid, dim3(256), 0, s, a);

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_wgrad_nt(WgradArgs a) {
 // units they split them in, so the range guard of the sweep covers them (sa = 1) -- and the planar im2col arrays (raw units:
 // sb = GLOWK_ACT_SCALE, what the kernels' own gathers apply).  A workgroup converts every element ONCE while staging it (global ->
 // registers -> hi / lo planes in LDS, double buffered; rows of 32 k padded to 80 bytes: a wave's 16-byte fragment reads are
-// conflict free); a wave owns WTM x WTN accumulator tiles of 32 x 32.  Two shapes: 128 x 128 (2 x 2 waves of 64 x 64) for the square
+// conflict free); a wave owns WTM x WTN accumulator tiles of 32 x 32.  Shapes: 256 x 128 (4 x 2 waves of 64 x 64; 128 x 128 = 2 x 2 waves where M is not a multiple of 256) for the square
 // conv2 gradient, 128 x 64 (4 x 1 waves of 32 x 64) for the skinny conv1 / conv3 ones, which are bound by streaming (and converting) A.
 // A launch covers `batch` independent GEMMs (the steps of a level) of S slices each.
 struct WgradSplitArgs {
@@ -214,11 +214,12 @@ struct WgradSplitArgs {
 // VEC: K is a multiple of 4 (float4 loads; a template parameter because a run-time branch around every load makes hipcc wait for
 // each load in turn)
 template <int WTM, int WTN, int WM, int WN, bool VEC>
-__global__ __launch_bounds__(256, 2) void k_wgrad_h3(WgradSplitArgs a) {
-  static_assert(WM * WN == 4, "four waves");
+__global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void k_wgrad_h3(WgradSplitArgs a) {
+  static_assert(WM * WN == 4 || WM * WN == 8, "four or eight waves");
+  constexpr int RPP = 8 * WM * WN;     // rows one pass of the loader covers (8 threads per row of 32 k)
   constexpr int TM = 32 * WTM * WM, TN = 32 * WTN * WN;
   constexpr int LDH = 40;              // halves per LDS row: 32 k + 8 of padding
-  constexpr int EA = TM / 32, EB = TN / 32;
+  constexpr int EA = TM / RPP, EB = TN / RPP;
   __shared__ __attribute__((aligned(16))) _Float16 Ah[2][TM * LDH];
   __shared__ __attribute__((aligned(16))) _Float16 Al[2][TM * LDH];
   __shared__ __attribute__((aligned(16))) _Float16 Bh[2][TN * LDH];
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h3(WgradSplitArgs a) {
     for (int j = 0; j < WTN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  const int lr = tid >> 3, lk = (tid & 7) * 4;       // loader: rows lr + 32 e, 4 consecutive k
+  const int lr = tid >> 3, lk = (tid & 7) * 4;       // loader: rows lr + RPP e, 4 consecutive k
   float4 ra[EA], rb[EB];
   // full: the tile lies inside the matrices and the slice is whole 32-deep rounds -- no clamps, no selects (wave-uniform, decided once)
   const bool full = VEC && m0 + TM <= a.M && n0 + TN <= a.N && ((k_end - k_begin) & 31) == 0;
@@ -269,9 +270,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h3(WgradSplitArgs a) {
   };
   auto fetch = [&](auto full_tag, long k0) {
 #pragma unroll
-    for (int e = 0; e < EA; ++e) ra[e] = load4(full_tag, Ab, m0 + lr + 32 * e, a.M, k0 + lk);
+    for (int e = 0; e < EA; ++e) ra[e] = load4(full_tag, Ab, m0 + lr + RPP * e, a.M, k0 + lk);
 #pragma unroll
-    for (int e = 0; e < EB; ++e) rb[e] = load4(full_tag, Bb, n0 + lr + 32 * e, a.N, k0 + lk);
+    for (int e = 0; e < EB; ++e) rb[e] = load4(full_tag, Bb, n0 + lr + RPP * e, a.N, k0 + lk);
   };
   typedef _Float16 h4v __attribute__((ext_vector_type(4)));
   auto put = [&](auto unit_tag, const float4& v, float sc, _Float16* hi, _Float16* lo, int row) {
@@ -288,10 +289,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h3(WgradSplitArgs a) {
   for (int e = 0; e < EB; ++e) bsum[e] = 0.0;
   auto stage = [&](auto ub_tag, auto sum_tag, int buf) {        // (sa = 1 always: the A operands are the split kernels' own stores)
 #pragma unroll
-    for (int e = 0; e < EA; ++e) put(std::true_type{}, ra[e], 1.0f, Ah[buf], Al[buf], lr + 32 * e);
+    for (int e = 0; e < EA; ++e) put(std::true_type{}, ra[e], 1.0f, Ah[buf], Al[buf], lr + RPP * e);
 #pragma unroll
     for (int e = 0; e < EB; ++e) {
-      put(ub_tag, rb[e], a.sb, Bh[buf], Bl[buf], lr + 32 * e);
+      put(ub_tag, rb[e], a.sb, Bh[buf], Bl[buf], lr + RPP * e);
       if constexpr (decltype(sum_tag)::value) bsum[e] += ((double)rb[e].x + (double)rb[e].y) + ((double)rb[e].z + (double)rb[e].w);
     }
   };
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h3(WgradSplitArgs a) {
     for (int e = 0; e < EB; ++e) {
       double t = bsum[e];
       t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
-      const int n = n0 + lr + 32 * e;
+      const int n = n0 + lr + RPP * e;
       if ((tid & 7) == 0 && n < a.N) C[(size_t)a.M * a.N + n] = (float)t;
     }
   }
