@@ -389,8 +389,9 @@ def main():
             kernel, peak = "k_net_h3s<CI=%d,NF=%d> (level 0)" % (c0 // 2, cfg.F // 32), PEAK_F16_MFMA_TFLOPS / 3.0
             note = "fp16 dense MFMA peak / 3 (three fp16 MFMAs per fp32-equivalent product)"
         # HBM bytes per launch and MFMA-pipe busy fraction come from separate rocprofv3 --pmc passes of this same command
-        # (scripts/pmc_traffic.py, scripts/pmc_mfma.py), committed under profiles/: NOT measured by this process -- the
-        # `counters_source` object says which file and commit they were read from
+        # (scripts/final_run.sh, summarised by scripts/pmc_summary.py), committed under profiles/: NOT measured by this process -- the
+        # `counters_source` object says which file they were read from, the commit that file belongs to (where there is no git
+        # history -- the GPU box -- the commit of the build the counters were collected on, which the file records) and that build
         traffic = mfma_busy = None
         src = {}
         if cfg is CONFIG_B and n == 1024:
@@ -399,13 +400,13 @@ def main():
                 tj = json.load(open(os.path.join(ROOT, tpath)))
                 key = {"f32": "k_net_f32", "f16x3": "k_net_h3s", "f16x2": "k_net_h3s_two_term"}[precision]
                 traffic = tj["hbm_bytes_per_level0_launch"][key]
-                src["traffic"] = {"file": tpath, "commit": file_commit(tpath), "build": tj.get("build"), "measured_in_this_run": False}
+                src["traffic"] = {"file": tpath, "commit": file_commit(tpath) or tj.get("build"), "build": tj.get("build"), "measured_in_this_run": False}
             except Exception:
                 traffic = None
             try:
                 uj = json.load(open(os.path.join(ROOT, upath)))
                 mfma_busy = uj["level0"][{"f32": "k_net_f32", "f16x3": "k_net_h3s", "f16x2": "k_net_h3s_two_term"}[precision]]["mfma_utilisation"]
-                src["mfma_busy_pmc"] = {"file": upath, "commit": file_commit(upath), "build": uj.get("build"), "measured_in_this_run": False}
+                src["mfma_busy_pmc"] = {"file": upath, "commit": file_commit(upath) or uj.get("build"), "build": uj.get("build"), "measured_in_this_run": False}
             except Exception:
                 mfma_busy = None
         # what a bare MFMA loop with this kernel's operand pattern sustains on this chip under its power management
