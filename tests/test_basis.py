@@ -38,14 +38,23 @@ def test_db_mixing_and_its_gradient():
 
 
 @pytest.mark.gpu
-def test_basis_inner_loop_matches_oracle():
+@pytest.mark.parametrize("shape", ["16x16_L2_K3_F128", "configB_geometry_K2", "configB_geometry_K2_f16x3"])
+def test_basis_inner_loop_matches_oracle(shape):
+    """Three Langevin steps of run_basis_sep.py:163-181 with injected noise against the fp64 oracle loop: a small flow, and the
+    64x64 L=3 n_filters=512 geometry of BASELINE config 5 (K = 2 so that the oracle's fp64 autograd stays in seconds) in the exact
+    and in the split arithmetic (the default of GlowFlow's callers)."""
+    from audiosourcesep_amd import _lib
     from audiosourcesep_amd.flow_models.flow_glow import GlowFlow
     from audiosourcesep_amd.synthetic import calibrated_engine
-    cfg = GlowConfig(H=16, W=16, C=1, L=2, K=3, F=128)
+    cfg = GlowConfig(H=16, W=16, C=1, L=2, K=3, F=128) if shape.startswith("16x16") else GlowConfig(H=64, W=64, C=1, L=3, K=2, F=512)
     e1, p1 = calibrated_engine(cfg, device=0, init_tiles=16, seed=1)
     e2, p2 = calibrated_engine(cfg, device=0, init_tiles=16, seed=2)
+    if shape.endswith("f16x3"):
+        for e in (e1, e2):
+            e.set_precision(_lib.PREC_F16X3)
+            e.set_range_policy("error")
     m1, m2 = GlowFlow(e1), GlowFlow(e2)
-    n, T = 4, 3
+    n, T = (4, 3) if shape.startswith("16x16") else (3, 3)
     gt1, gt2 = synthetic_mel_tiles(n, cfg, seed=10), synthetic_mel_tiles(n, cfg, seed=11)
     mixed = basis_ref.g_db(gt1.astype(np.float64), gt2.astype(np.float64))
     rng = np.random.default_rng(3)
