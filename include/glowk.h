@@ -205,14 +205,18 @@ int glowk_coupling_net(glowk_handle* h, int level, int step, const float* xb_dev
  * tiles (scale = -1 / global batch), the caller all-reduces that vector across ranks (RCCL; torch.distributed in the mirror),
  * glowk_apply_gradients takes the optimizer step on the engine's device-resident master copy of the parameters and refreshes
  * the packed kernel images on the device.  The sweep runs in the handle's arithmetic: with GLOWK_PREC_F16X3 / F16X2 on the split
- * kernels (hidden tensors stored in their scaled units, undone in the gradient assembly; fp32-class gradients, ~2x the exact
- * sweep) wherever every level has training instances, under the range guard (a tripped sweep is repeated on the exact kernels
+ * kernels (hidden tensors stored in their scaled units, undone in the gradient assembly; weight-gradient GEMMs in the same
+ * three-product fp16 split; fp32-class gradients, ~3x the exact sweep) wherever every level has training instances, under the range guard (a tripped sweep is repeated on the exact kernels
  * unless the policy is GLOWK_RANGE_ERROR); otherwise, and with GLOWK_PREC_F32, on the exact fp32 kernels.  glowk_apply_gradients
  * refreshes the exact images always and the fp16 hi/lo images (BatchNorm folds, power-of-two scales, epilogue constants,
  * range-guard limits; bit for bit the host packer's) when the handle is in a split arithmetic.
  * Layout of the vector: glowk_param_offset.  It holds every tf.Variable of the flow except the frozen P, P_inv, sign_S; the
  * BatchNorm moving mean / variance (non-trainable, never updated by the reference: the layers are called without training=)
- * are carried with zero gradient. */
+ * are carried with zero gradient.
+ * Memory: the sweep keeps, per pixel and flow step, the two hidden activations of the coupling network (4 KB at n_filters 512:
+ * 5.6 GB for 32 tiles of 64x64, K = 32, L = 3) and, a level at a time, their two gradients (as much again for the largest
+ * level) when a quarter / a third of the free device memory holds them; otherwise it re-runs each step's forward network and
+ * works step by step -- slower, same results to fp32 rounding. */
 size_t glowk_param_vector_size(glowk_handle* h);
 /* where tensor `tensor_id` of (level, step) -- or a prior tensor (level, step ignored) -- sits in the vector */
 int glowk_param_offset(glowk_handle* h, int level, int step, int tensor_id, size_t* offset, size_t* count);
