@@ -102,9 +102,14 @@ struct glowk_handle {
   std::vector<size_t> tr_map_n;
   std::vector<int*> tr_map16;    // per level: half position in [RHp, Afwd) -> source code | lo bit (k_repack_f16), or null
   std::vector<size_t> tr_map16_n;
-  float* tr16_src = nullptr;     // [K][max cTot] scaled sources of one level's steps
-  int* tr16_S = nullptr;         // [K][6]
-  float* tr16_scales = nullptr;  // [K][8]
+  float* tr16_src = nullptr;     // [L][K][max cTot] scaled sources of a level's steps (a block per level: the levels refresh concurrently)
+  int* tr16_S = nullptr;         // [L][K][6]
+  float* tr16_scales = nullptr;  // [L][K][8]
+  size_t tr16_src_max = 0;
+  float* tr_pinned = nullptr;            // pinned host staging of glowk_apply_gradients (a pageable target would make every copy block the host)
+  std::vector<size_t> tr_pin_off;        // per level: [scales K*8 | small K*K1off | b3 K*c | affine blocks K*tail]
+  std::vector<hipStream_t> tr_streams;   // one per level: glowk_apply_gradients refreshes the levels' images side by side
+  std::vector<hipEvent_t> tr_events;     // [0] fork, [1 + lvl] join
   int trN = 0;
   float *trR1 = nullptr, *trR2 = nullptr, *trM1 = nullptr, *trM2 = nullptr, *trXcol = nullptr, *trGcol = nullptr, *trCpart = nullptr;
   float *trC1 = nullptr, *trC2 = nullptr, *trC3 = nullptr, *trGv = nullptr, *trGo = nullptr;
@@ -992,9 +997,10 @@ int train_begin(glowk_handle* h) {
       src_max = std::max(src_max, f16_code_bases(lv.c, h->cfg.F).total);
     }
     if (src_max) {
-      HIPCHK(hipMalloc(&h->tr16_src, (size_t)h->cfg.K * src_max * 4));
-      HIPCHK(hipMalloc(&h->tr16_S, (size_t)h->cfg.K * 6 * 4));
-      HIPCHK(hipMalloc(&h->tr16_scales, (size_t)h->cfg.K * 8 * 4));
+      HIPCHK(hipMalloc(&h->tr16_src, (size_t)h->cfg.L * h->cfg.K * src_max * 4));
+      HIPCHK(hipMalloc(&h->tr16_S, (size_t)h->cfg.L * h->cfg.K * 6 * 4));
+      HIPCHK(hipMalloc(&h->tr16_scales, (size_t)h->cfg.L * h->cfg.K * 8 * 4));
+      h->tr16_src_max = src_max;
     }
   }
   std::vector<float> flat;
@@ -1114,6 +1120,9 @@ int glowk_destroy(glowk_handle* h) {
   if (h->bufStat) hipFree(h->bufStat);
   if (h->saveV) { hipFree(h->saveV); hipFree(h->saveP); hipFree(h->saveM); hipFree(h->bufGz); }
   for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+  for (hipEvent_t e : h->tr_events) hipEventDestroy(e);
+  if (h->tr_pinned) hipHostFree(h->tr_pinned);
+  for (hipStream_t t : h->tr_streams) hipStreamDestroy(t);
   delete h;
   return 0;
 }
@@ -1778,71 +1787,104 @@ int glowk_apply_gradients(glowk_handle* h, const float* grad_dev, int optimizer,
   hipLaunchKernelGGL(k_optimizer, dim3((unsigned)((h->tr_n + 255) / 256)), dim3(256), 0, s, h->tr_params, grad_dev, h->tr_m, h->tr_v, h->tr_n, optimizer,
                      lr_t, (float)b1, (float)b2, 1e-7f);
   LAUNCHCHK("k_optimizer");
-  // ---- refresh what the exact-fp32 kernels read: conv images (device permutation), BatchNorm/bias block, fused affines, prior ----
+  // ---- refresh what the kernels read: conv images (device permutation), BatchNorm/bias block, fused affines, prior.  The levels are
+  //      independent and their kernels small and latency-bound (serial fp64 sums in the host packer's order, so that the images stay
+  //      bit for bit the host-packed ones): each level runs on a stream of its own, the host joins them once for the c x c algebra ----
+  if (h->tr_streams.empty()) {
+    h->tr_streams.resize(cfg.L); h->tr_events.resize(cfg.L + 1);
+    for (hipStream_t& t : h->tr_streams) HIPCHK(hipStreamCreateWithFlags(&t, hipStreamNonBlocking));
+    for (hipEvent_t& e : h->tr_events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    size_t tot = 0;
+    h->tr_pin_off.assign(cfg.L + 1, 0);
+    for (int lvl = 0; lvl < cfg.L; ++lvl) {
+      const StepLayout SL = step_layout(h->levels[lvl].c, F);
+      const TrainOff t = train_off(h->levels[lvl].c, F);
+      h->tr_pin_off[lvl] = tot;
+      tot += (size_t)cfg.K * (8 + t.K1 + h->levels[lvl].c + (SL.total - SL.Afwd));
+    }
+    h->tr_pin_off[cfg.L] = tot;
+    HIPCHK(hipHostMalloc((void**)&h->tr_pinned, tot * 4, hipHostMallocDefault));
+  }
+  HIPCHK(hipEventRecord(h->tr_events[0], s));
+  // pinned staging of level lvl: scales | small tensors | conv3 biases | folded affine blocks
+  auto pin_sc = [&](int lvl) { return h->tr_pinned + h->tr_pin_off[lvl]; };
+  auto pin_sm = [&](int lvl) { return pin_sc(lvl) + (size_t)cfg.K * 8; };
+  auto pin_b3 = [&](int lvl) { return pin_sm(lvl) + (size_t)cfg.K * train_off(h->levels[lvl].c, F).K1; };
+  auto pin_blk = [&](int lvl) { return pin_b3(lvl) + (size_t)cfg.K * h->levels[lvl].c; };
+  std::vector<char> refresh16(cfg.L, 0);
   for (int lvl = 0; lvl < cfg.L; ++lvl) {
     Level& lv = h->levels[lvl];
+    hipStream_t ls = h->tr_streams[lvl];
+    HIPCHK(hipStreamWaitEvent(ls, h->tr_events[0], 0));
     const StepLayout SL = step_layout(lv.c, F);
     const TrainOff t = train_off(lv.c, F);
     const float* p0 = h->tr_params + h->tr_level_off[lvl];
     float* img0 = h->arena + lv.dev[0].arena_off;
-    hipLaunchKernelGGL(k_repack_f32, dim3((unsigned)((h->tr_map_n[lvl] + 255) / 256), cfg.K), dim3(256), 0, s, (const int*)h->tr_map[lvl], h->tr_map_n[lvl],
+    hipLaunchKernelGGL(k_repack_f32, dim3((unsigned)((h->tr_map_n[lvl] + 255) / 256), cfg.K), dim3(256), 0, ls, (const int*)h->tr_map[lvl], h->tr_map_n[lvl],
                        p0, t.total, img0 + SL.K1p, SL.total);
-    hipLaunchKernelGGL(k_fold_bn, dim3((F + 255) / 256, cfg.K), dim3(256), 0, s, p0 + t.b1, p0 + t.b2, p0 + t.bn, t.total, F, cfg.bn_eps, img0 + SL.ep, SL.total);
+    hipLaunchKernelGGL(k_fold_bn, dim3((F + 255) / 256, cfg.K), dim3(256), 0, ls, p0 + t.b1, p0 + t.b2, p0 + t.bn, t.total, F, cfg.bn_eps, img0 + SL.ep, SL.total);
     LAUNCHCHK("k_repack_f32");
     // the fp16-split images, when the handle is in a split arithmetic (otherwise they are re-packed lazily by the host)
-    const bool refresh16 = h->precision != GLOWK_PREC_F32 && h->tr_map16[lvl];
-    std::vector<float> sc16;
-    if (refresh16) {
+    refresh16[lvl] = h->precision != GLOWK_PREC_F32 && h->tr_map16[lvl];
+    if (refresh16[lvl]) {
       const F16Codes q = f16_code_bases(lv.c, F);
       F16Prep fp;
       fp.params = p0; fp.param_stride = t.total; fp.ep = img0 + SL.ep; fp.img_stride = SL.total;
       fp.oK1 = t.K1; fp.oK2 = t.K2; fp.oK3 = t.K3; fp.ob1 = t.b1; fp.ob2 = t.b2; fp.c = lv.c; fp.F = F;
       fp.cA = q.A; fp.cB = q.B; fp.cC = q.C; fp.cD = q.D; fp.cE = q.E; fp.cG = q.G; fp.cTot = q.total;
-      fp.src = h->tr16_src; fp.S = h->tr16_S; fp.scales = h->tr16_scales;
+      fp.src = h->tr16_src + (size_t)lvl * cfg.K * h->tr16_src_max; fp.S = h->tr16_S + (size_t)lvl * cfg.K * 6; fp.scales = h->tr16_scales + (size_t)lvl * cfg.K * 8;
       const int NMT = (9 * lv.c + 31) / 32;
-      hipLaunchKernelGGL(k_f16_sources, dim3((unsigned)((q.total + 255) / 256), cfg.K), dim3(256), 0, s, fp);
-      hipLaunchKernelGGL(k_f16_absmax, dim3(6, cfg.K), dim3(1024), 0, s, fp);
-      hipLaunchKernelGGL(k_f16_consts, dim3((F + 32 * NMT + 255) / 256, cfg.K), dim3(256), 0, s, fp, img0 + SL.epH, NMT);
-      hipLaunchKernelGGL(k_f16_limits, dim3(2, cfg.K), dim3(512), 0, s, fp);
-      hipLaunchKernelGGL(k_repack_f16, dim3((unsigned)((h->tr_map16_n[lvl] + 255) / 256), cfg.K), dim3(256), 0, s, (const int*)h->tr_map16[lvl],
+      hipLaunchKernelGGL(k_f16_sources, dim3((unsigned)((q.total + 255) / 256), cfg.K), dim3(256), 0, ls, fp);
+      hipLaunchKernelGGL(k_f16_absmax, dim3(6, cfg.K), dim3(1024), 0, ls, fp);
+      hipLaunchKernelGGL(k_f16_consts, dim3((F + 32 * NMT + 255) / 256, cfg.K), dim3(256), 0, ls, fp, img0 + SL.epH, NMT);
+      hipLaunchKernelGGL(k_f16_limits, dim3(2, cfg.K), dim3(512), 0, ls, fp);
+      hipLaunchKernelGGL(k_repack_f16, dim3((unsigned)((h->tr_map16_n[lvl] + 255) / 256), cfg.K), dim3(256), 0, ls, (const int*)h->tr_map16[lvl],
                          h->tr_map16_n[lvl], fp, reinterpret_cast<unsigned short*>(img0 + SL.RHp), SL.total * 2);
       LAUNCHCHK("k_repack_f16");
-      sc16.resize((size_t)cfg.K * 8);
-      HIPCHK(hipMemcpyAsync(sc16.data(), h->tr16_scales, sc16.size() * 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(pin_sc(lvl), fp.scales, (size_t)cfg.K * 8 * 4, hipMemcpyDeviceToHost, ls));
     } else if (h->tr_map16[lvl]) {
       stale16 = true;
     }
     // small tensors: down to the host (they parameterise the fp64 fold of ActNorm + 1x1), folded, back up
     const size_t small = t.K1;
-    std::vector<float> sm((size_t)cfg.K * small), b3v((size_t)cfg.K * lv.c);
-    HIPCHK(hipMemcpy2DAsync(sm.data(), small * 4, p0, t.total * 4, small * 4, cfg.K, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpy2DAsync(b3v.data(), (size_t)lv.c * 4, p0 + t.b3, t.total * 4, (size_t)lv.c * 4, cfg.K, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    const size_t tail = SL.total - SL.Afwd;
-    std::vector<float> blocks((size_t)cfg.K * tail), tmp(SL.total);
+    HIPCHK(hipMemcpy2DAsync(pin_sm(lvl), small * 4, p0, t.total * 4, small * 4, cfg.K, hipMemcpyDeviceToHost, ls));
+    HIPCHK(hipMemcpy2DAsync(pin_b3(lvl), (size_t)lv.c * 4, p0 + t.b3, t.total * 4, (size_t)lv.c * 4, cfg.K, hipMemcpyDeviceToHost, ls));
+  }
+  for (int lvl = 0; lvl < cfg.L; ++lvl) {
+    Level& lv = h->levels[lvl];
+    hipStream_t ls = h->tr_streams[lvl];
+    HIPCHK(hipStreamSynchronize(ls));
+    const StepLayout SL = step_layout(lv.c, F);
+    const TrainOff t = train_off(lv.c, F);
+    float* img0 = h->arena + lv.dev[0].arena_off;
+    const size_t small = t.K1, tail = SL.total - SL.Afwd;
+    std::vector<float> tmp(SL.total);
+    float* blocks = pin_blk(lvl);
     for (int k = 0; k < cfg.K; ++k) {
-      const float* src = sm.data() + (size_t)k * small;
+      const float* src = pin_sm(lvl) + (size_t)k * small;
       const int c = lv.c;
       std::memcpy(lv.host[GLOWK_ACTNORM_LOG_SCALE][k].data(), src + t.als, c * 4);
       std::memcpy(lv.host[GLOWK_ACTNORM_SHIFT][k].data(), src + t.ash, c * 4);
       std::memcpy(lv.host[GLOWK_INV1X1_L][k].data(), src + t.L, (size_t)c * c * 4);
       std::memcpy(lv.host[GLOWK_INV1X1_LOG_S][k].data(), src + t.logS, c * 4);
       std::memcpy(lv.host[GLOWK_INV1X1_U][k].data(), src + t.U, (size_t)c * c * 4);
-      std::memcpy(lv.host[GLOWK_CONV3_BIAS][k].data(), b3v.data() + (size_t)k * c, c * 4);
+      std::memcpy(lv.host[GLOWK_CONV3_BIAS][k].data(), pin_b3(lvl) + (size_t)k * c, c * 4);
       std::string err;
       double ldc = 0;
       if (!pack_affine(cfg, lv, k, tmp.data(), &ldc, &err)) return fail("level " + std::to_string(lvl) + " step " + std::to_string(k) + ": " + err);
       h->ld_step[(size_t)lvl * cfg.K + k] = ldc;
-      std::memcpy(blocks.data() + (size_t)k * tail, tmp.data() + SL.Afwd, tail * 4);
-      if (refresh16) {      // the kernels' scale arguments and range-guard limits live in the host-side step descriptors
+      std::memcpy(blocks + (size_t)k * tail, tmp.data() + SL.Afwd, tail * 4);
+      if (refresh16[lvl]) {      // the kernels' scale arguments and range-guard limits live in the host-side step descriptors
         StepDev& d = lv.dev[k];
-        const float* q8 = sc16.data() + (size_t)k * 8;
+        const float* q8 = pin_sc(lvl) + (size_t)k * 8;
         if (SL.slotH || SL.slotS) { d.sc1 = q8[0]; d.sc2 = q8[1]; d.sc3 = q8[2]; d.xlim_f = q8[6]; }
         if (SL.slotHB || SL.slotSB) { d.scb1 = q8[3]; d.scb2 = q8[4]; d.scb3 = q8[5]; d.xlim_b = q8[7]; }
       }
     }
-    HIPCHK(hipMemcpy2DAsync(img0 + SL.Afwd, SL.total * 4, blocks.data(), tail * 4, tail * 4, cfg.K, hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));
+    // (pinned source, rewritten only by the next call, which first waits for this level's stream above)
+    HIPCHK(hipMemcpy2DAsync(img0 + SL.Afwd, SL.total * 4, blocks, tail * 4, tail * 4, cfg.K, hipMemcpyHostToDevice, ls));
+    HIPCHK(hipEventRecord(h->tr_events[1 + lvl], ls));
+    HIPCHK(hipStreamWaitEvent(s, h->tr_events[1 + lvl], 0));     // whatever the caller's stream runs next sees the refreshed images
   }
   h->ld_const = 0.0;
   for (double v : h->ld_step) h->ld_const += v;
