@@ -196,6 +196,35 @@ def test_convnet_against_torch_nn_modules(c, F):
     assert np.abs(o_tr - o).max() > 1e-3
 
 
+def test_conv_same_against_scipy_correlate2d():
+    """A fourth code base for the convolution reading (cross-correlation, not convolution; 'SAME' = zero padding of 1 on every
+    side; HWIO kernels): scipy.signal.correlate2d, channel pair by channel pair.  A flipped kernel or an off-by-one padding would
+    show: the kernel is not symmetric and the image is rectangular."""
+    from scipy.signal import correlate2d
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((2, 5, 7, 3))
+    k = rng.standard_normal((3, 3, 3, 4))
+    b = rng.standard_normal(4)
+    got = R.conv2d_same(x, k, b)
+    ref = np.zeros((2, 5, 7, 4))
+    for n in range(2):
+        for co in range(4):
+            for ci in range(3):
+                ref[n, :, :, co] += correlate2d(x[n, :, :, ci], k[:, :, ci, co], mode="same", boundary="fill", fillvalue=0.0)
+            ref[n, :, :, co] += b[co]
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
+    flipped = np.zeros_like(ref)
+    for n in range(2):
+        for co in range(4):
+            for ci in range(3):
+                flipped[n, :, :, co] += correlate2d(x[n, :, :, ci], k[::-1, ::-1, ci, co], mode="same", boundary="fill", fillvalue=0.0)
+            flipped[n, :, :, co] += b[co]
+    assert np.abs(flipped - got).max() > 0.1          # (a true convolution is something else)
+    # the 1x1 case (conv2, and the Invertible1x1Conv of flow_tfp_bijectors.py:304-305) is a matrix product over channels
+    k1 = rng.standard_normal((1, 1, 3, 6))
+    np.testing.assert_allclose(R.conv2d_same(x, k1, np.zeros(6)), x @ k1[0, 0], rtol=1e-12, atol=1e-12)
+
+
 @pytest.mark.parametrize("learntop", [True, False])
 def test_prior_against_torch_distributions(learntop):
     """flow_builder.py:131-144: Independent(MultivariateNormalDiag(loc, scale_diag=exp(v)), 2) / iid N(0, 1) over [h, w, c]."""
