@@ -654,15 +654,15 @@ __device__ __forceinline__ unsigned h3_act(const f32x16& acc, float sc, unsigned
   return bits;
 }
 
-// end of an X phase.  A training launch (MODE & 8) stores the hidden block from here in pass 0: 16 planar stores per wave (+ the mask
-// store of a saving pass), the wave's YOUNGEST memory operations -- everything the phase has to wait for (the DMA requested during the
-// previous Y) is older, and vmcnt counts in issue order, so the stores stay in flight instead of exposing their write latency at
-// every one of the 16 X phases (measured: the storing launches of a 32-tile sweep 47-70 us -> see DESIGN section 8a)
+// end of an X phase.  In pass 0 a saving launch stores the ReLU mask of the hidden block from here (1 store per wave) and a training
+// launch (MODE & 8) the block itself (16 planar stores): the wave's YOUNGEST memory operations -- everything the phase has to wait
+// for (the DMA requested during the previous Y) is older, and vmcnt counts in issue order, so the stores stay in flight instead of
+// exposing their write latency at every one of the 16 X phases
 template <int MODE, int PASS>
 __device__ __forceinline__ void h3_x_end(const H3Ctx& c) {
-  if constexpr ((MODE & 8) != 0 && PASS == 0) {
+  constexpr int NST = ((MODE & 8) ? 16 : 0) + (((MODE & 7) == NET_FWD_SAVE) ? 1 : 0);
+  if constexpr (NST != 0 && PASS == 0) {
     if (c.wok) {      // (a wave without a valid pixel issues no store: its youngest operations are the DMA)
-      constexpr int NST = 16 + (((MODE & 7) == NET_FWD_SAVE) ? 1 : 0);
       __builtin_amdgcn_s_waitcnt((NST & 15) | 0x0F70 | ((NST >> 4) << 14));   // vmcnt(NST)
       h3_barrier();
       return;
@@ -1247,14 +1247,14 @@ __device__ __forceinline__ void h3s_pass(const NetArgs& a, const H3Ctx& c, const
 #pragma nounroll
   for (int i0 = 0; i0 < NF; i0 += 2) {
     h3s_X<KIN, MOUT, NF, MODE, NP, 0, PASS>(a, c, i0, xh, xl, lane, bh, bl);
-    h3_wait_barrier();
+    h3_x_end<MODE, PASS>(c);
     if (PASS >= 1 && !SOLO && G::NCH == 1 && i0 == 0 && !g)   // single output chunk: slot D of the previous pass is read until the phase before this one
       stage4<G::MAINP, 50>(G::out_chunk(c.img, PASS, 0), c.sD, c.w4, c.voff);
     h3s_Y<KIN, MOUT, NF, MODE, NP, 1>(P0 ? c.sB : c.sA, bh, bl, acc2, lane, g, true, G::main_chunk(c.img, PASS, i0 + 1), P0 ? c.sA : c.sB,
                          c.k1img + (size_t)((i0 + 2) % NF) * G::K14, c.k1s0, c.w4, c.voff);
     h3_barrier();
     h3s_X<KIN, MOUT, NF, MODE, NP, 1, PASS>(a, c, i0 + 1, xh, xl, lane, bh, bl);
-    h3_wait_barrier();
+    h3_x_end<MODE, PASS>(c);
     h3s_Y<KIN, MOUT, NF, MODE, NP, 2>(P0 ? c.sA : c.sB, bh, bl, acc2, lane, g, i0 + 2 < NF || G::NCH >= 2,
                          i0 + 2 < NF ? G::main_chunk(c.img, PASS, i0 + 2) : G::out_chunk(c.img, PASS, 1),
                          P0 ? c.sB : c.sA, c.k1img + (size_t)((i0 + 3) % NF) * G::K14, c.k1s1, c.w4, c.voff);
