@@ -677,6 +677,13 @@ template <int KIN, int MOUT, int NF, int MODE, int NP, int KP, int PASS>
 __device__ __forceinline__ void h3_X(const NetArgs& a, const H3Ctx& c, int fi, const h8 (&xh)[(RingH<KIN, MOUT, NF, MODE, NP>::KS)],
                                      const h8 (&xl)[(RingH<KIN, MOUT, NF, MODE, NP>::KS)], int lane, h8 (&bh)[2], h8 (&bl)[2]) {
   using G = RingH<KIN, MOUT, NF, MODE, NP>;
+#ifdef GLOWK_EXP_NOX   // (diagnostic build, wrong results: X does nothing -- what do conv1 and its epilogue cost a phase?)
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { bh[s][j] = (_Float16)0.0f; bl[s][j] = (_Float16)0.0f; }
+  return;
+#endif
   f32x16 h1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) h1[r] = 0.0f;
