@@ -1,15 +1,16 @@
 // glowk device code, part 4: the training step's own kernels (train_glow.py:29-44: loss = sum(-log_prob) / global batch,
 // gradients wrt flow.trainable_variables, optimizer.apply_gradients).
 //
-// The data-gradient sweep of glowk_log_prob_grad already walks the steps in reverse; the training sweep adds, per step:
-//   1. k_net_f32<.., NET_FWD, STORE>   recompute the coupling network from the saved coupling input, storing
-//                                      R1 = relu(conv1 + b1), R2 = relu(conv2 + b2)           planar [F][Q]
-//   2. k_net_f32<.., NET_BWD, STORE>   the data-gradient kernel, also storing
-//                                      M2 = mask2 . conv3^T(g_o), M1 = mask1 . (K2 g_a2)       planar [F][Q]
+// The data-gradient sweep of glowk_log_prob_grad already walks the steps in reverse; the training sweep adds:
+//   1. the saving forward launch also stores  R1 = relu(conv1 + b1), R2 = relu(conv2 + b2)      planar [F][Q]
+//      (k_net_f32<.., STORE> / k_net_h3<.., MODE | 8>; kept for all steps, or recomputed per step when memory is short)
+//   2. the backward launch also stores        M2 = mask2 . conv3^T(g_o), M1 = mask1 . (K2 g_a2)   planar [F][Q]
+//   and then, for a whole level at a time (every kernel below takes a batch index = step; step by step when memory is short):
 //   3. k_im2col_planar                 Xcol[(tap, ci)][q] = v_b[q + d(tap)][ci] (+ a row of ones), Gcol[(tap, co)][q] = g_o[q - d(tap)][co]
-//   4. k_wgrad_nt (x3)                 C = A . B^T over the pixel dimension on the fp32 MFMA, split-K, deterministic partials:
+//   4. three GEMMs C = A . B^T over the pixel dimension, deterministic (fixed-order partial sums, no atomics):
 //                                      C3 = [R2; 1] . Gcol^T   C2 = [R1; 1] . M2^T   C1 = M1 . [Xcol; 1]^T
-//   5. k_rowdot, k_assemble_*          BatchNorm gamma/beta, biases, and the per-channel factors that turn C1..C3 into dK1..dK3
+//      k_wgrad_nt (exact: fp32 MFMA) or k_wgrad_h3 (sweeps in the split arithmetic: three-product fp16 split, fp32 accumulate)
+//   5. k_assemble_*                    BatchNorm gamma / beta, biases, and the per-channel factors that turn C1..C3 into dK1..dK3
 // Planar [channel][pixel] is the layout in which a channel row is K-contiguous for those GEMMs and in which the MFMA
 // accumulator tiles of k_net (row = channel in a register, column = pixel on the lane) store as 128-byte segments.
 // ActNorm / 1x1 gradients: k_affine_wgrad reduces dA = sum_q u^T g_v, db = sum_q g_v per step; the chain rule through
