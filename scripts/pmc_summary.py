@@ -23,7 +23,7 @@ def per_kernel(path):
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     for row in csv.DictReader(open(path)):
         k = row.get("Kernel_Name", "")
-        if k.startswith("void k_net_") or k.startswith("k_wgrad") or k.startswith("void k_couple"):
+        if k.startswith("void k_net_") or "k_wgrad" in k or k.startswith("void k_couple"):
             c = acc[k][row["Counter_Name"]]
             c[0] += float(row["Counter_Value"])
             c[1] += 1
