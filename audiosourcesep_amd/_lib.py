@@ -78,6 +78,8 @@ SYMBOLS = {
     "glowk_forward": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "glowk_inverse": (_i, [_vp, _vp, _i, _vp, _vp]),
     "glowk_log_prob": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "glowk_log_prob_sum": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "glowk_sum_f64": (_i, [_vp, ctypes.c_size_t, _vp, _i, ctypes.c_double, _vp]),
     "glowk_log_prob_grad": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "glowk_sample": (_i, [_vp, _vp, _i, _vp, _vp]),
     "glowk_prior_log_prob": (_i, [_vp, _vp, _i, _vp, _vp]),
@@ -96,9 +98,10 @@ SYMBOLS = {
     "glowk_apply_gradients": (_i, [_vp, _vp, _i, ctypes.c_float, _vp]),
     "glowk_crc32c": (ctypes.c_uint32, [_vp, ctypes.c_size_t]),
     "glowk_basis_update": (_i, [_vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, _vp, _vp,
-                                ctypes.c_uint64, ctypes.c_uint64, _vp, _vp]),
+                                ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, _vp, _vp]),
     "glowk_basis_mix": (_i, [_vp, _vp, _vp, ctypes.c_size_t, _vp]),
-    "glowk_random": (_i, [_vp, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint64, _i, _i, _vp]),
+    "glowk_random": (_i, [_vp, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint64, _i, _i, ctypes.c_uint64, _vp]),
+    "glowk_add_noise": (_i, [_vp, _vp, ctypes.c_size_t, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _i, ctypes.c_uint64, _vp]),
 }
 
 _lib = None

@@ -53,18 +53,29 @@ def mixing_db(*sources):
     return (10.0 / math.log(10.0)) * (torch.logsumexp(s * (math.log(10.0) / 10.0), dim=0) - math.log(float(k)))
 
 
-def device_randn(shape, device, seed, step=0, which=0, uniform=False):
+def device_randn(shape, device, seed, step=0, which=0, uniform=False, offset=0):
     """Standard-normal (or U(0, 1)) tensor from the engine's Philox stream (seed, step, which): the draws
-    ``glowk_basis_update`` makes itself when no noise is injected."""
+    ``glowk_basis_update`` makes itself when no noise is injected.  ``offset``: position of element 0 in the stream (a
+    multiple of 4) -- a rank holding tiles [a, b) of a batch passes ``a * H * W * C`` and gets the draws one process would have
+    made for those tiles, so the noise a tile sees does not depend on how the batch is sharded."""
     out = torch.empty(shape, device=device, dtype=torch.float32)
-    _lib.check(_lib.load().glowk_random(_p(out), out.numel(), int(seed), int(step), int(which), int(bool(uniform)), _s(out)))
+    _lib.check(_lib.load().glowk_random(_p(out), out.numel(), int(seed), int(step), int(which), int(bool(uniform)), int(offset), _s(out)))
     return out
 
 
-def langevin_update(mixed, x1, x2, g1, g2, eta, lambda_recon, eps1=None, eps2=None, seed=0, step=0, nonfinite=None):
+def add_device_noise(x, sigma, seed, step=0, which=2, offset=0):
+    """x + sigma * N(0, I) as ONE kernel of the engine (``glowk_add_noise``; the draws are ``device_randn(seed, step, which,
+    offset)``): train_noisy_glow.py:31."""
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().glowk_add_noise(_p(x), _p(out), x.numel(), float(sigma), int(seed), int(step), int(which), int(offset), _s(x)))
+    return out
+
+
+def langevin_update(mixed, x1, x2, g1, g2, eta, lambda_recon, eps1=None, eps2=None, seed=0, step=0, nonfinite=None, offset=0):
     """run_basis_sep.py:163-181 for two sources, IN PLACE on x1 / x2 (contiguous float32 CUDA tensors): one kernel."""
     _lib.check(_lib.load().glowk_basis_update(_p(x1), _p(x2), _p(g1), _p(g2), _p(mixed), x1.numel(), float(eta), float(lambda_recon),
-                                              _p(eps1), _p(eps2), int(seed), int(step), _p(nonfinite), _s(x1)))
+                                              _p(eps1), _p(eps2), int(seed), int(step), int(offset), _p(nonfinite), _s(x1)))
 
 
 def grad_mixing_db(*sources):
@@ -128,9 +139,10 @@ def _grad_pair(x1, x2, model1, model2, streams):
 
 
 def basis_inner_loop(mixed, x1, x2, model1, model2, sigma_idx, sigmas, delta=2e-5, T=100, noise_fn=None, debug=False,
-                     streams="auto", seed=0, step0=0):
+                     streams="auto", seed=0, step0=0, offset=0):
     """run_basis_sep.py:152-214 (model_type == 'glow').  ``noise_fn(t, which, shape) -> standard normal tensor`` replays given
-    draws; without it the update kernel draws from the device RNG stream (seed, step0 + t).
+    draws; without it the update kernel draws from the device RNG stream (seed, step0 + t), element ``offset`` onwards
+    (``offset`` = this shard's first tile * H * W * C: the draws of a tile are the same whatever the sharding).
     ``streams``: "auto" (two side streams when on the GPU and the models are distinct engines), None, or (s1, s2).
     ``debug``: the reference's NaN asserts (:183-191), from a flag the update kernel raises (one word read back per step)."""
     if streams == "auto":
@@ -150,7 +162,7 @@ def basis_inner_loop(mixed, x1, x2, model1, model2, sigma_idx, sigmas, delta=2e-
         g1, g2 = _grad_pair(x1, x2, model1, model2, streams)
         e1 = noise_fn(t, 0, x1.shape).to(torch.float32).contiguous() if noise_fn is not None else None
         e2 = noise_fn(t, 1, x2.shape).to(torch.float32).contiguous() if noise_fn is not None else None
-        langevin_update(mixed, x1, x2, g1, g2, eta, lambda_recon, e1, e2, seed=seed, step=step0 + t, nonfinite=flag)
+        langevin_update(mixed, x1, x2, g1, g2, eta, lambda_recon, e1, e2, seed=seed, step=step0 + t, nonfinite=flag, offset=offset)
         if debug:
             assert int(flag.item()) == 0, (sigma, t)   # run_basis_sep.py:183-191
     return x1, x2
@@ -173,10 +185,14 @@ def _inner_loop_host(mixed, x1, x2, model1, model2, eta, lambda_recon, T, noise_
 
 
 def basis_outer_loop(mixed, x1, x2, model1, model2, sigmas, restore_1=None, restore_2=None, T=100, delta=2e-5, noise_fn=None,
-                     debug=False, seed=0):
+                     debug=False, seed=0, tile_offset=0):
     """run_basis_sep.py:217-260.  ``restore_k``: optional ``{sigma: state_dict | path | GlowFlow}`` with the noise-conditioned
     weights of model k for each noise level (the per-sigma checkpoints of train_noisy_glow.py:309-358); a ``GlowFlow`` value is
-    used as is (all ten noise levels of both priors resident: 2 x 10 x 0.5 GB of packed weights)."""
+    used as is (all ten noise levels of both priors resident: 2 x 10 x 0.5 GB of packed weights).
+    ``tile_offset``: index of ``mixed[0]`` in the whole set of mixture tiles (``shard_bounds(n_mixed, world, rank)[0]`` on a rank
+    that holds a shard): folded into the device RNG's counter, so every tile sees the Langevin noise it would see in a
+    one-process run -- ranks do not repeat each other's draws and the result does not depend on the world size."""
+    elems_per_tile = int(np.prod(mixed.shape[1:]))
     x_arr = {"x1": [x1.cpu().numpy()], "x2": [x2.cpu().numpy()]}
     for sigma_idx, sigma in enumerate(sigmas):
         current = []
@@ -193,7 +209,7 @@ def basis_outer_loop(mixed, x1, x2, model1, model2, sigmas, restore_1=None, rest
         model1_s, model2_s = current
         nf = None if noise_fn is None else (lambda t, which, shape, _s=sigma_idx: noise_fn(_s, t, which, shape))
         x1, x2 = basis_inner_loop(mixed, x1, x2, model1_s, model2_s, sigma_idx, sigmas, delta=delta, T=T, noise_fn=nf, debug=debug,
-                                  seed=seed, step0=sigma_idx * T)
+                                  seed=seed, step0=sigma_idx * T, offset=int(tile_offset) * elems_per_tile)
         x_arr["x1"].append(x1.cpu().numpy())
         x_arr["x2"].append(x2.cpu().numpy())
     return x1, x2, x_arr

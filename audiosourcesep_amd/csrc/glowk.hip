@@ -1474,6 +1474,32 @@ int glowk_log_prob(glowk_handle* h, const float* x_dev, int N, float* logp_dev, 
   });
 }
 
+int glowk_log_prob_sum(glowk_handle* h, const float* x_dev, int N, float* logp_dev, float* z_dev, double* sum_dev, int accumulate, void* stream) {
+  if (!h) return fail("null handle");
+  DeviceGuard dg(h->device);
+  if (int rc = check_ready(h, N)) return rc;
+  if (!x_dev || !logp_dev || !sum_dev) return fail("null tensor");
+  hipStream_t s = (hipStream_t)stream;
+  float* z = z_dev ? z_dev : h->bufZ;
+  return guarded(h, s, [&]() -> int {
+    if (int rc = run_forward(h, x_dev, N, z, s)) return rc;
+    hipLaunchKernelGGL(k_prior, dim3(N), dim3(256), 0, s, (const float*)z, h->Hl * h->Wl * h->Cl, h->d_loc, h->d_log_scale,
+                       (const double*)h->bufLd, logp_dev, (float*)nullptr);
+    LAUNCHCHK("k_prior");
+    hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(1024), 0, s, (const float*)logp_dev, (size_t)N, sum_dev, accumulate, 1.0);
+    LAUNCHCHK("k_sum_f64");
+    return 0;
+  });
+}
+
+int glowk_sum_f64(const float* v_dev, size_t n, double* out_dev, int accumulate, double scale, void* stream) {
+  if (!out_dev || (!v_dev && n)) return fail("null tensor");
+  DeviceGuard dg(ptr_device(out_dev));
+  hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(1024), 0, (hipStream_t)stream, v_dev, n, out_dev, accumulate, scale);
+  LAUNCHCHK("k_sum_f64");
+  return 0;
+}
+
 int glowk_log_prob_grad(glowk_handle* h, const float* x_dev, int N, float* logp_dev, float* dx_dev, void* stream) {
   if (!h) return fail("null handle");
   DeviceGuard dg(h->device);
@@ -1900,15 +1926,16 @@ int glowk_apply_gradients(glowk_handle* h, const float* grad_dev, int optimizer,
 
 int glowk_basis_update(float* x1_dev, float* x2_dev, const float* g1_dev, const float* g2_dev, const float* mixed_dev, size_t n,
                        float eta, float lambda_recon, const float* eps1_dev, const float* eps2_dev, uint64_t seed, uint64_t step,
-                       int* nonfinite_dev, void* stream) {
+                       uint64_t offset, int* nonfinite_dev, void* stream) {
   if (!x1_dev || !x2_dev || !g1_dev || !g2_dev || !mixed_dev) return fail("null tensor");
+  if (offset % 4) return fail("basis_update: the stream offset must be a multiple of 4 elements");
   if (n == 0) return 0;
   if (n > ((size_t)1 << 40)) return fail("basis_update: too many elements");
   if (!(eta >= 0.0f)) return fail("basis_update: eta must be non-negative");
   DeviceGuard dg(ptr_device(x1_dev));
   BasisArgs a;
   a.x1 = x1_dev; a.x2 = x2_dev; a.g1 = g1_dev; a.g2 = g2_dev; a.mixed = mixed_dev; a.eps1 = eps1_dev; a.eps2 = eps2_dev; a.n = n;
-  a.eta = eta; a.lambda_recon = lambda_recon; a.noise_scale = std::sqrt(2.0f * eta); a.seed = seed; a.step = step; a.nonfinite = nonfinite_dev;
+  a.eta = eta; a.lambda_recon = lambda_recon; a.noise_scale = std::sqrt(2.0f * eta); a.seed = seed; a.step = step; a.q0 = offset / 4; a.nonfinite = nonfinite_dev;
   const size_t threads = (n + 3) / 4;
   hipLaunchKernelGGL(k_basis_update, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   LAUNCHCHK("k_basis_update");
@@ -1924,23 +1951,37 @@ int glowk_basis_mix(const float* x1_dev, const float* x2_dev, float* out_dev, si
   return 0;
 }
 
-int glowk_random(float* out_dev, size_t n, uint64_t seed, uint64_t step, int which, int uniform, void* stream) {
+int glowk_random(float* out_dev, size_t n, uint64_t seed, uint64_t step, int which, int uniform, uint64_t offset, void* stream) {
   if (!out_dev) return fail("null tensor");
   if (which < 0 || which > 15) return fail("random: stream id must be 0..15");
+  if (offset % 4) return fail("random: the stream offset must be a multiple of 4 elements");
   if (n == 0) return 0;
   DeviceGuard dg(ptr_device(out_dev));
   const size_t threads = (n + 3) / 4;
   hipLaunchKernelGGL(k_basis_noise, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out_dev, n, seed, step,
-                     (uint32_t)which, uniform);
+                     (uint32_t)which, uniform, offset / 4);
   LAUNCHCHK("k_basis_noise");
   return 0;
 }
 
-uint32_t glowk_crc32c(const void* host_data, size_t n) {
-  static uint32_t table[8][256];
-  static std::atomic<bool> ready(false);
-  if (!ready.load(std::memory_order_acquire)) {
-    uint32_t t[8][256];
+int glowk_add_noise(const float* x_dev, float* out_dev, size_t n, float sigma, uint64_t seed, uint64_t step, int which, uint64_t offset,
+                    void* stream) {
+  if (!x_dev || !out_dev) return fail("null tensor");
+  if (which < 0 || which > 15) return fail("add_noise: stream id must be 0..15");
+  if (offset % 4) return fail("add_noise: the stream offset must be a multiple of 4 elements");
+  if (n == 0) return 0;
+  DeviceGuard dg(ptr_device(out_dev));
+  const size_t threads = (n + 3) / 4;
+  hipLaunchKernelGGL(k_add_noise, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_dev, out_dev, n, sigma, seed,
+                     step, (uint32_t)which, offset / 4);
+  LAUNCHCHK("k_add_noise");
+  return 0;
+}
+
+namespace {
+struct Crc32cTable {
+  uint32_t t[8][256];
+  Crc32cTable() {
     for (uint32_t i = 0; i < 256; ++i) {
       uint32_t c = i;
       for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
@@ -1948,9 +1989,13 @@ uint32_t glowk_crc32c(const void* host_data, size_t n) {
     }
     for (uint32_t i = 0; i < 256; ++i)
       for (int s = 1; s < 8; ++s) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xFF];
-    std::memcpy(table, t, sizeof(t));      // (idempotent: concurrent first calls write the same bytes)
-    ready.store(true, std::memory_order_release);
   }
+};
+}  // namespace
+
+uint32_t glowk_crc32c(const void* host_data, size_t n) {
+  static const Crc32cTable tbl;            // function-local static: initialised once, thread-safe by the language (C++11 [stmt.dcl])
+  const uint32_t (&table)[8][256] = tbl.t;
   const unsigned char* p = static_cast<const unsigned char*>(host_data);
   uint32_t c = 0xFFFFFFFFu;
   while (n >= 8) {                         // slicing-by-8

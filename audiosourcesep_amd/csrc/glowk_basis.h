@@ -54,6 +54,7 @@ struct BasisArgs {
   size_t n;
   float eta, lambda_recon, noise_scale;   // noise_scale = sqrt(2 eta)
   uint64_t seed, step;
+  uint64_t q0;          // index of x[0] in the logical noise stream, in groups of four elements (shards: the global element offset / 4)
   int* nonfinite;       // optional: set to 1 if a gradient, a mixing term or an updated value is not finite (the reference's asserts, :183-191)
 };
 
@@ -65,8 +66,8 @@ __global__ __launch_bounds__(256) void k_basis_update(BasisArgs a) {
   const size_t e0 = (size_t)q * 4;
   if (e0 >= a.n) return;
   float z1[4], z2[4];
-  if (!a.eps1) normal4(a.seed, a.step, 0u, q, z1);
-  if (!a.eps2) normal4(a.seed, a.step, 1u, q, z2);
+  if (!a.eps1) normal4(a.seed, a.step, 0u, a.q0 + q, z1);
+  if (!a.eps2) normal4(a.seed, a.step, 1u, a.q0 + q, z2);
   const float L10 = 0.23025850929940457f;   // ln 10 / 10
   bool bad = false;
 #pragma unroll
@@ -103,10 +104,12 @@ __global__ __launch_bounds__(256) void k_basis_mix(const float* __restrict__ x1,
 
 // the standard-normal draws k_basis_update makes for (seed, step, which); also the engine's general device RNG
 // (uniform = 1: U(0, 1) instead -- the reference starts the chain from uniform noise, run_basis_sep.py:360-361)
-__global__ __launch_bounds__(256) void k_basis_noise(float* __restrict__ out, size_t n, uint64_t seed, uint64_t step, uint32_t which, int uniform) {
-  const uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t e0 = (size_t)q * 4;
+__global__ __launch_bounds__(256) void k_basis_noise(float* __restrict__ out, size_t n, uint64_t seed, uint64_t step, uint32_t which, int uniform,
+                                                    uint64_t q0) {
+  const uint64_t ql = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t e0 = (size_t)ql * 4;
   if (e0 >= n) return;
+  const uint64_t q = q0 + ql;     // position in the logical stream: a shard draws what the whole batch would have drawn for its elements
   float z[4];
   if (uniform) {
     uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32) ^ (which << 28), (uint32_t)step, (uint32_t)(step >> 32)};
@@ -119,4 +122,18 @@ __global__ __launch_bounds__(256) void k_basis_noise(float* __restrict__ out, si
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     if (e0 + j < n) out[e0 + j] = z[j];
+}
+
+// out = x + sigma N(0, I) with the draws of (seed, step, which) from element 4 q0 on: the noise of train_noisy_glow.py:31 (the
+// noise-conditioned priors of BASIS are trained on X + tf.random.normal(X.shape) * noise) without a tensor-library kernel
+__global__ __launch_bounds__(256) void k_add_noise(const float* __restrict__ x, float* __restrict__ out, size_t n, float sigma, uint64_t seed,
+                                                  uint64_t step, uint32_t which, uint64_t q0) {
+  const uint64_t ql = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t e0 = (size_t)ql * 4;
+  if (e0 >= n) return;
+  float z[4];
+  normal4(seed, step, which, q0 + ql, z);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (e0 + j < n) out[e0 + j] = fmaf(sigma, z[j], x[e0 + j]);
 }

@@ -368,6 +368,18 @@ __global__ __launch_bounds__(256) void k_prior(const float* __restrict__ z, int 
   if (logdet_out && threadIdx.x == 0) logdet_out[n] = (float)logdet[n];
 }
 
+// fp64 sum of n fp32 values in a fixed order (one workgroup of 1024 threads: thread t adds elements t, t + 1024, ...; then the
+// waves, then the 16 wave sums): the summed log-likelihood the trainers reduce over (train_glow.py:29-31, 52-54).  Deterministic
+// and independent of everything but n, so a shard's sum is bitwise repeatable; accumulate != 0 adds to *out (chunked batches);
+// scale: the -1 / global_batch of tf.nn.compute_average_loss when the caller wants the loss itself.
+__global__ __launch_bounds__(1024) void k_sum_f64(const float* __restrict__ v, size_t n, double* __restrict__ out, int accumulate, double scale) {
+  __shared__ double red[16];
+  double acc = 0.0;
+  for (size_t e = threadIdx.x; e < n; e += 1024) acc += (double)v[e];
+  const double tot = block_sum_any(acc, red);
+  if (threadIdx.x == 0) *out = accumulate ? *out + scale * tot : scale * tot;
+}
+
 // z = loc + exp(log_scale) * eps (prior.sample given the standard-normal draw)
 __global__ __launch_bounds__(256) void k_prior_sample(const float* __restrict__ eps, size_t total, int E,
                                                      const float* __restrict__ loc, const float* __restrict__ log_scale,

@@ -18,18 +18,24 @@ def shard_bounds(n, world_size, rank):
     return start, start + base + (1 if rank < extra else 0)
 
 
-def sharded_log_prob(log_prob_fn, x_local, group=None):
+def sharded_log_prob(log_prob_fn, x_local, group=None, total=None):
     """Evaluate the local shard and all-reduce the summed log-likelihood.
 
     Returns (lp_local [n_local] as produced by ``log_prob_fn``, total fp64 scalar tensor identical on every rank).
-    The sum is accumulated in fp64 so that its value does not depend on how tiles were sharded to ~1e-12."""
-    lp = log_prob_fn(x_local) if x_local.shape[0] else torch.zeros(0, dtype=torch.float32, device=x_local.device)
-    total = lp.sum(dtype=torch.float64).reshape(1)
+    The sum is accumulated in fp64 so that its value does not depend on how tiles were sharded to ~1e-12.
+    ``log_prob_fn`` may be a :class:`GlowEngine` (or anything with ``log_prob_sum``): the engine then leaves the fp64 sum on the
+    device itself (``glowk_log_prob_sum``, fixed summation order) in ``total`` (a [1] float64 tensor, allocated if missing), and
+    the only thing between the engine's kernels and the collective is the collective -- no tensor-library kernel."""
+    if hasattr(log_prob_fn, "log_prob_sum"):
+        lp, total = log_prob_fn.log_prob_sum(x_local, total=total)
+    else:
+        lp = log_prob_fn(x_local) if x_local.shape[0] else torch.zeros(0, dtype=torch.float32, device=x_local.device)
+        total = lp.sum(dtype=torch.float64).reshape(1)
     if dist.is_available() and dist.is_initialized():   # (a one-rank group still makes the call: same code path at every N)
         if total.is_cuda and dist.get_backend(group) == "gloo":   # rehearsal of the multi-process path without RCCL
             t = total.cpu()
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-            total = t.to(total.device)
+            total.copy_(t)
         else:
             dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
     return lp, total[0]
@@ -71,7 +77,11 @@ def distributed_train_step(param_grad_fn, apply_fn, x_local, global_batch_size, 
     if global_batch_size <= 0:
         raise ValueError("global_batch_size must be positive")
     lp, grad = param_grad_fn(x_local, -1.0 / float(global_batch_size))
-    loss = (-lp.sum(dtype=torch.float64) / float(global_batch_size)).reshape(1)
+    eng = getattr(param_grad_fn, "__self__", None)
+    if lp.is_cuda and hasattr(eng, "sum_f64"):    # the engine's own fixed-order fp64 reduction (no tensor-library kernel in the step)
+        loss = eng.sum_f64(lp, scale=-1.0 / float(global_batch_size))
+    else:
+        loss = (-lp.sum(dtype=torch.float64) / float(global_batch_size)).reshape(1)
     _all_reduce_sum(grad, group)
     _all_reduce_sum(loss, group)
     apply_fn(grad)

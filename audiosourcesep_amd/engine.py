@@ -137,7 +137,25 @@ class GlowEngine:
             self._fallbacks_seen = n
 
     def reserve(self, n, with_grad=False):
-        _lib.check(self.lib.glowk_reserve(self.h, min(int(n), self.grad_max_tiles if with_grad else self.max_tiles), int(with_grad)))
+        m = min(int(n), self.grad_max_tiles if with_grad else self.max_tiles)
+        self._reserve_or_shrink(m, with_grad)
+
+    def _reserve_or_shrink(self, m, with_grad):
+        """glowk_reserve; when the device cannot hold the gradient path's footprint for ``m`` tiles (memory went to something
+        else after the chunk was sized) the chunk is halved and tried again, so a later call chunks smaller instead of failing."""
+        while True:
+            try:
+                _lib.check(self.lib.glowk_reserve(self.h, int(m), int(with_grad)))
+                break
+            except _lib.GlowkError as e:
+                if not with_grad or m <= 1 or "out of memory" not in str(e).lower():
+                    raise
+                torch.cuda.empty_cache()
+                m = max(1, m // 2)
+                self._reserved_grad = 0          # (a failed glowk_reserve leaves the gradient buffers released)
+                self._grad_cap = m               # ... and every later chunk is at most this large
+        if with_grad:
+            self._reserved_grad = max(getattr(self, "_reserved_grad", 0), int(m))
 
     @property
     def max_tiles(self):
@@ -158,11 +176,17 @@ class GlowEngine:
         saturate long before that."""
         if not self._finalized:
             self.finalize()
-        key = (self.get_precision(), self._max_tiles_cap)
+        # the cached chunk is only as good as the memory picture it was sized on: what this engine has already reserved stays
+        # its own, anything else that was allocated since (a second prior's engine, training state, pinned staging) shrinks the
+        # budget -- so the key carries the free memory in 1-GiB steps plus this engine's own reservation
+        free = self._free_bytes()
+        own = self.workspace_bytes(self._reserved_grad, True) if getattr(self, "_reserved_grad", 0) else 0
+        key = (self.get_precision(), self._max_tiles_cap, (free + own) >> 30)
+        key = key + (getattr(self, "_grad_cap", None),)
         if getattr(self, "_grad_chunk", (None, 0))[0] == key:
             return self._grad_chunk[1]
-        budget = min(0.6 * self._free_bytes(), float(os.environ.get("GLOWK_GRAD_BUDGET_GB", "64")) * 2 ** 30)
-        lo, hi = 1, self.max_tiles
+        budget = min(0.6 * (free + own), float(os.environ.get("GLOWK_GRAD_BUDGET_GB", "64")) * 2 ** 30)
+        lo, hi = 1, min(self.max_tiles, getattr(self, "_grad_cap", None) or self.max_tiles)
         if self.workspace_bytes(hi, True) > budget:
             while lo < hi:      # largest n with bytes(n) <= budget (bytes is monotone in n)
                 mid = (lo + hi + 1) // 2
@@ -247,13 +271,42 @@ class GlowEngine:
                                                self._stream()))
         return (lp, z) if return_latent else lp
 
+    def log_prob_sum(self, x, out=None, total=None):
+        """-> (log_prob [N], total [1] float64 on the device = sum_n log_prob[n]): ``glowk_log_prob_sum``.  The sum is taken by the
+        engine in a fixed order (chunks accumulate in order), so nothing but the engine's kernels runs between the tiles and the
+        one-element all-reduce of train_glow.py:52-54."""
+        x = self._in(x, self.data_shape)
+        n = x.shape[0]
+        lp = out if out is not None else self._new(n)
+        if total is None:
+            total = torch.empty(1, device=self.device, dtype=torch.float64)
+        if n == 0:
+            _lib.check(self.lib.glowk_sum_f64(_ptr(None), 0, _ptr(total), 0, 1.0, self._stream()))
+            return lp, total
+        for i, (a, b) in enumerate(self._chunks(n)):
+            self._compute(self.lib.glowk_log_prob_sum(self.h, _ptr(x[a:b]), b - a, _ptr(lp[a:b]), _ptr(None), _ptr(total), int(i > 0),
+                                                   self._stream()))
+        return lp, total
+
+    def sum_f64(self, v, scale=1.0, out=None):
+        """scale * sum(v) as one fp64 device value, fixed summation order (``glowk_sum_f64``)."""
+        v = v.contiguous()
+        if out is None:
+            out = torch.empty(1, device=v.device, dtype=torch.float64)
+        _lib.check(self.lib.glowk_sum_f64(_ptr(v), v.numel(), _ptr(out), 0, float(scale), _stream_ptr(v.device)))
+        return out
+
     def log_prob_grad(self, x):
         x = self._in(x, self.data_shape)
         n = x.shape[0]
         lp, dx = self._new(n), torch.empty_like(x)
         if n == 0:
             return lp, dx
-        for a, b in self._chunks(n, self.grad_max_tiles):
+        chunk = self.grad_max_tiles
+        if min(n, chunk) > getattr(self, "_reserved_grad", 0):
+            self._reserve_or_shrink(min(n, chunk), True)      # (may shrink the chunk when the memory is no longer there)
+            chunk = min(chunk, self.grad_max_tiles)
+        for a, b in self._chunks(n, chunk):
             self._compute(self.lib.glowk_log_prob_grad(self.h, _ptr(x[a:b]), b - a, _ptr(lp[a:b]), _ptr(dx[a:b]), self._stream()))
         return lp, dx
 
@@ -270,7 +323,9 @@ class GlowEngine:
         return int(off.value), int(cnt.value)
 
     def param_grad(self, x, scale, grad=None):
-        """-> (log_prob [N], grad [param_vector_size]) with grad = scale * d sum_n log_prob(x_n) / d theta, exact fp32 kernels."""
+        """-> (log_prob [N], grad [param_vector_size]) with grad = scale * d sum_n log_prob(x_n) / d theta, in the handle's
+        arithmetic (the split sweep with hidden stores in f16x3 / f16x2 where every level has training instances, else -- and in
+        f32 -- the exact kernels); under the range policy like every compute call (a fallback is counted and warned about)."""
         x = self._in(x, self.data_shape)
         n = x.shape[0]
         if n > self.grad_max_tiles:
@@ -278,7 +333,7 @@ class GlowEngine:
         lp = self._new(n)
         if grad is None:
             grad = self._new(self.param_vector_size)
-        _lib.check(self.lib.glowk_param_grad(self.h, _ptr(x), n, float(scale), _ptr(lp), _ptr(grad), self._stream()))
+        self._compute(self.lib.glowk_param_grad(self.h, _ptr(x), n, float(scale), _ptr(lp), _ptr(grad), self._stream()))
         return lp, grad
 
     def apply_gradients(self, grad, optimizer="adamax", lr=1e-3):

@@ -35,7 +35,10 @@ class Variable:
 
 
 def _step_variable_shapes(c, F):
-    """Creation order inside GlowStep.__init__ (flow_glow.py:15-20)."""
+    """Tensors of one GlowStep in CREATION order (GlowStep.__init__, flow_glow.py:15-20): name, shape,
+    trainable.  This is NOT the order of ``flow.variables`` -- that one follows ``tf.Module``'s attribute traversal and lives in
+    ``tf_checkpoint.variable_order`` (the single source of truth for it); creation order is kept as the named alternative
+    ``GlowFlow.variables_in_creation_order``."""
     ci = c // 2
     return [
         ("actnorm/log_scale", (c,), True), ("actnorm/shift", (c,), True),
@@ -175,15 +178,26 @@ class GlowFlow:
         self.bijector = InvertedBijector(self.chain)
         self.event_shape = engine.data_shape
         cfg = self.cfg
-        vs = []
+        by_name = {}
+        creation = []
         for lvl, (h, w, c) in enumerate(cfg.level_shapes()):
             for k in range(cfg.K):
                 for name, shape, trainable in _step_variable_shapes(c, cfg.F):
-                    vs.append(Variable(engine, "b%d/s%d/%s" % (lvl, k, name), shape, trainable))
+                    v = Variable(engine, "b%d/s%d/%s" % (lvl, k, name), shape, trainable)
+                    by_name[v.name] = v
+                    creation.append(v)
         if cfg.learntop:
-            vs.append(Variable(engine, "prior/loc", cfg.latent_shape(), True))
-            vs.append(Variable(engine, "prior/log_scale", cfg.latent_shape(), True))
-        self._variables = tuple(vs)
+            for name in ("prior/loc", "prior/log_scale"):
+                by_name[name] = Variable(engine, name, cfg.latent_shape(), True)
+                creation.append(by_name[name])
+        # ONE source of truth for the position of a variable in ``flow.variables`` -- the checkpoint root of train_utils.py:67-68:
+        # tf_checkpoint.variable_order (tf.Module's attribute traversal, derived from the reference's source)
+        from ..tf_checkpoint import variable_order
+        order = variable_order(cfg)
+        assert sorted(order) == sorted(by_name), "variable_order and the step tensors disagree"
+        self._variables = tuple(by_name[n] for n in order)
+        self._creation_order = tuple(creation)
+        self._noise_step = 0      # train_step(noise_std > 0) calls so far: the device RNG's step counter when the caller gives none
 
     # --- tfd.Distribution surface ------------------------------------------------------------------
     def log_prob(self, x):
@@ -194,25 +208,37 @@ class GlowFlow:
         return self.engine.log_prob(x)
 
     def sample(self, n, seed=None):
-        """n -> [n,H,W,C] (train_glow.py:74): prior draw on the GPU (torch generator), chain.inverse in the engine."""
-        g = None
-        if seed is not None:
-            g = torch.Generator(device=self.engine.device)
-            g.manual_seed(int(seed))
-        eps = torch.randn((int(n),) + tuple(self.cfg.latent_shape()), device=self.engine.device, dtype=torch.float32, generator=g)
+        """n -> [n,H,W,C] (train_glow.py:74): the prior's standard-normal draw comes from the engine's own device RNG
+        (``glowk_random``, Philox stream ``seed``; unseeded calls take a fresh stream per call like ``tf.random``), the prior's
+        affine and ``chain.inverse`` run in the engine (``glowk_sample``)."""
+        from ..basis import device_randn
+        if seed is None:
+            seed = int.from_bytes(__import__("os").urandom(7), "little")
+        eps = device_randn((int(n),) + tuple(self.cfg.latent_shape()), self.engine.device, int(seed), step=0, which=3)
         return self.engine.sample_from_eps(eps)
 
-    def train_step(self, x, optimizer="adamax", lr=1e-3, global_batch_size=None, group=None, noise_std=0.0, seed=0, step=0):
+    def train_step(self, x, optimizer="adamax", lr=1e-3, global_batch_size=None, group=None, noise_std=0.0, seed=0, step=None,
+                   tile_offset=None):
         """One step of train_glow.py's ``distributed_train_step`` (:37-54) on this rank's tiles ``x``: loss =
         sum(-log_prob(x)) / global_batch_size, gradients wrt ``trainable_variables``, summed over the ranks of ``group``
         (one all-reduce of the flat gradient vector), ``optimizer.apply_gradients``.  ``noise_std`` > 0 adds N(0, noise_std^2) to
-        the tiles first (train_noisy_glow.py:31: the noise-conditioned priors of BASIS), drawn by the engine's device RNG from
-        the stream (seed, step).  Returns the global loss (fp64 scalar tensor)."""
+        the tiles first (train_noisy_glow.py:31: the noise-conditioned priors of BASIS; fresh noise every step and on every
+        replica), drawn by the engine's device RNG: stream ``seed``, step = ``step`` or, when None, this flow's own count of
+        noisy steps (so two consecutive calls never reuse a draw), element offset = ``tile_offset`` tiles -- default: this rank's
+        position in the global batch, rank * local batch, so no two ranks draw the same noise and a tile's draw does not depend
+        on the world size.  Returns the global loss (fp64 scalar tensor)."""
         from ..distributed import distributed_train_step
         x = self.engine._in(x, self.engine.data_shape)
         if noise_std:
-            from ..basis import device_randn
-            x = x + float(noise_std) * device_randn(tuple(x.shape), x.device, seed, step, which=2)
+            import torch.distributed as dist
+            from ..basis import add_device_noise
+            if step is None:
+                step = self._noise_step
+            self._noise_step = int(step) + 1
+            if tile_offset is None:
+                tile_offset = dist.get_rank(group) * x.shape[0] if (dist.is_available() and dist.is_initialized()) else 0
+            elems = int(np.prod(self.engine.data_shape))
+            x = add_device_noise(x, noise_std, seed, step, which=2, offset=int(tile_offset) * elems)
         gb = int(global_batch_size) if global_batch_size else x.shape[0]
         return distributed_train_step(self.engine.param_grad, lambda g: self.engine.apply_gradients(g, optimizer, lr), x, gb, group=group)
 
@@ -226,7 +252,14 @@ class GlowFlow:
 
     @property
     def variables(self):
+        """In the order of the reference's ``flow.variables`` (``tf_checkpoint.variable_order``: the derived ``tf.Module``
+        traversal -- variable i is checkpoint key ``variables/<i>``)."""
         return self._variables
+
+    @property
+    def variables_in_creation_order(self):
+        """The same variables in constructor creation order (flow_glow.py:15-20), the named alternative."""
+        return self._creation_order
 
     @property
     def trainable_variables(self):

@@ -16,6 +16,20 @@ which is re-derived here from the attribute names in the reference's source -- s
 checks every tensor's shape against the slot it lands in and refuses a checkpoint that does not fit; the order remains
 overridable (``order=``).  Whoever has TensorFlow at hand can confirm it with
 ``[v.name for v in flow.variables]``.
+
+Shapes cannot tell apart the groups a wrong guess would permute -- per step the eleven ``[F]`` vectors (conv1 / conv2 bias, and
+moving_mean, moving_variance, gamma, beta of both BatchNorm layers), ActNorm's ``log_scale`` / ``shift`` (``[c]``), ``log_S`` /
+``sign_S`` (``[c]``), ``L`` / ``U`` / ``P`` / ``P_inv`` (``[c, c]``), and the prior pair -- so after the shape check the import tests
+what the VALUES of a reference checkpoint must satisfy (``check_value_invariants``): ``P`` is a 0/1 permutation matrix and
+``P_inv`` its transpose, ``sign_S`` is +-1, ``L`` is zero above and ``U`` zero on and below the diagonal (the masked entries get
+zero gradient, flow_tfp_bijectors.py:300-303), moving variances are positive -- and, because the reference never runs
+BatchNormalization in training mode (the layers are called without ``training=``), moving_mean == 0 and moving_variance == 1
+exactly.  A checkpoint that violates one of them is refused with the offending variable named.
+
+Optimizer state: the reference's checkpoint also tracks ``optimizer`` (Adam / Adamax slot variables ``m`` / ``v`` and the
+iteration count, under ``variables/<i>/.OPTIMIZER_SLOT/...`` and ``optimizer/...`` keys).  The import reads the flow's
+variables only: a run resumed from an imported checkpoint starts its moments from zero (``glowk_apply_gradients`` creates them
+at the first step) -- fine-tuning works as in train_noisy_glow.py:331-335, the first steps are not bit-for-bit a TensorFlow resume.
 """
 import ctypes
 import struct
@@ -229,7 +243,9 @@ def variable_order(cfg, prior_order=("loc", "log_scale")):
       batch_norm_1, conv2, batch_norm_2, conv3; flow_tfk_layers.py:56-71) is met first; inside a layer ``_non_trainable_weights``
       sorts before ``_trainable_weights``: BatchNormalization -> moving_mean, moving_variance, gamma, beta; Conv2D -> kernel, bias;
     * prior (flow_builder.py:131-139): ``prior_order`` -- loc and the TransformedVariable's pre-transformed (log) scale have the
-      same shape, so a wrong guess here cannot be caught by the shape check; pass the other order if TensorFlow says so."""
+      same shape and no value-level invariant separates them; pass the other order if TensorFlow says so.
+    Same-shaped groups the shape check cannot separate (all but the prior pair are covered by ``check_value_invariants`` where
+    their values differ in kind): the eleven [F] vectors of a step, log_scale / shift, log_S / sign_S, L / U / P / P_inv."""
     names = []
     for lvl in range(cfg.L):
         for k in range(cfg.K):
@@ -262,9 +278,46 @@ def _expected_shapes(cfg):
     return shapes
 
 
-def state_dict_from_checkpoint(prefix, cfg, order=None):
+def check_value_invariants(state, cfg, reference_batchnorm=True):
+    """Value-level invariants of a reference checkpoint (module docstring): raises ValueError naming the first variable that
+    breaks one -- which is what a wrong ``variable_order`` produces when it permutes same-shaped neighbours.
+    ``reference_batchnorm``: also require moving_mean == 0 and moving_variance == 1 (the reference never updates them)."""
+    def bad(name, what):
+        raise ValueError("checkpoint tensor mapped to %s %s: either the checkpoint was not written by the reference's build_glow "
+                         "or the derived variable order is wrong for it (pass order=)" % (name, what))
+
+    for lvl, (h, w, c) in enumerate(cfg.level_shapes()):
+        eye = np.eye(c)
+        for k in range(cfg.K):
+            pre = "b%d/s%d/" % (lvl, k)
+            P, Pinv = np.asarray(state[pre + "inv1x1/P"], np.float64), np.asarray(state[pre + "inv1x1/P_inv"], np.float64)
+            if not (np.isin(P, (0.0, 1.0)).all() and (P.sum(0) == 1).all() and (P.sum(1) == 1).all()):
+                bad(pre + "inv1x1/P", "is not a 0/1 permutation matrix")
+            if not np.array_equal(Pinv, P.T):
+                bad(pre + "inv1x1/P_inv", "is not the transpose (= inverse) of P")
+            if not np.isin(np.asarray(state[pre + "inv1x1/sign_S"]), (-1.0, 1.0)).all():
+                bad(pre + "inv1x1/sign_S", "has entries other than -1 / +1")
+            if np.any(np.triu(np.asarray(state[pre + "inv1x1/L"]), 1) != 0):
+                bad(pre + "inv1x1/L", "is not lower triangular")
+            if np.any(np.tril(np.asarray(state[pre + "inv1x1/U"]), 0) != 0):
+                bad(pre + "inv1x1/U", "is not strictly upper triangular")
+            if not np.isfinite(np.asarray(state[pre + "inv1x1/log_S"])).all():
+                bad(pre + "inv1x1/log_S", "is not finite")
+            for bn in ("bn1", "bn2"):
+                var, mean = np.asarray(state[pre + "nn/%s/var" % bn]), np.asarray(state[pre + "nn/%s/mean" % bn])
+                if not (var > 0).all():
+                    bad(pre + "nn/%s/var" % bn, "has non-positive moving variances")
+                if reference_batchnorm and not (np.all(var == 1.0) and np.all(mean == 0.0)):
+                    bad(pre + "nn/%s/{mean,var}" % bn, "are not the untouched moving statistics (mean 0, variance 1) the reference leaves behind "
+                                                      "(it never runs BatchNormalization in training mode; reference_batchnorm=False skips this test)")
+    del eye
+
+
+def state_dict_from_checkpoint(prefix, cfg, order=None, check_values=True, reference_batchnorm=True):
     """Read ``variables/<i>/.ATTRIBUTES/VARIABLE_VALUE`` of the checkpoint ``prefix`` (e.g. ``tf_ckpts/ckpt-21``) into this
-    repository's ``{name: ndarray}``, checking count and every shape against ``order`` (default: ``variable_order(cfg)``)."""
+    repository's ``{name: ndarray}``, checking count and every shape against ``order`` (default: ``variable_order(cfg)``), then
+    the value-level invariants of a reference checkpoint (``check_value_invariants``; ``check_values=False`` skips them,
+    ``reference_batchnorm=False`` accepts trained moving statistics).  Optimizer slots in the checkpoint are not imported."""
     order = list(order) if order is not None else variable_order(cfg)
     tensors = read_bundle(prefix)
     vals = {}
@@ -280,6 +333,8 @@ def state_dict_from_checkpoint(prefix, cfg, order=None):
             raise ValueError("variables/%d has shape %s but position %d of the variable order is %s %s: the checkpoint was written by another "
                              "configuration or the derived order is wrong (pass order=)" % (i, tuple(vals[i].shape), i, name, shapes[name]))
         state[name] = vals[i].astype(np.float32)
+    if check_values:
+        check_value_invariants(state, cfg, reference_batchnorm)
     return state
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GLOWK_VERSION 200
+#define GLOWK_VERSION 300
 
 /* Arguments of build_glow (flow_builder.py:60-61) + SpecPreprocessing kwargs (flow_tfp_bijectors.py:365). */
 typedef struct glowk_config {
@@ -92,13 +92,20 @@ enum glowk_status {
   GLOWK_ERR_RANGE = 2    /* a split-precision call left the fp16 range (see glowk_range_policy); outputs are not usable */
 };
 
-/* Range guard of the split arithmetics (F16X3 / F16X2).  They need |hidden activation| * 4 < 65504; beyond that the fp16
- * split produces inf - inf, every network output of the pixel turns non-finite, and the coupling / gradient kernels that
- * consume those outputs raise a sticky per-handle flag on the device (no cost in the MFMA kernels).  What a compute call
- * (forward, inverse, log_prob, log_prob_grad, sample, step_*, coupling_net) does with the flag:
+/* Range guard of the split arithmetics (F16X3 / F16X2).  Every value that is split into fp16 hi + lo must stay below
+ * 65504 / 4 in magnitude; beyond that hi = inf, lo = -inf, the next contraction is NaN -- and the ReLU after it turns that NaN
+ * into 0: a finite, WRONG result that no test of the outputs can see.  The guard is therefore STATIC: glowk_finalize_weights
+ * (and the device-side refresh after glowk_apply_gradients) bounds every split value of a flow step by the L1 norms of its
+ * BatchNorm-folded weights as a linear function of the largest coupling-network INPUT, and solves for the input magnitude
+ * `xlim` up to which no split can overflow; the network kernels compare the inputs they gather against it (prologue, once per
+ * pixel; nothing in the MFMA loops) and raise a sticky per-handle flag on the device.  It is a worst-case bound: it may send a
+ * legitimate call to the exact kernels, it cannot miss an overflow.  Second, free source of the same flag: a non-finite network
+ * output, coupling result or gradient seen by the coupling / gradient kernels (non-finite input tiles, a genuinely exploding
+ * flow -- what the reference's callers assert on, run_basis_sep.py:183-191, train_glow.py:115-118).
+ * What a compute call (forward, inverse, log_prob, log_prob_sum, log_prob_grad, param_grad, sample, step_*, coupling_net) does
+ * with the flag:
  *   GLOWK_RANGE_ERROR (default)  after its launches the call waits for the stream, reads the flag and, if set, clears it and
- *                                returns GLOWK_ERR_RANGE -- the reference's callers assert on NaN the same way
- *                                (run_basis_sep.py:183-191, train_glow.py:115-118);
+ *                                returns GLOWK_ERR_RANGE: the outputs of the call are not usable;
  *   GLOWK_RANGE_FALLBACK         same check, but the call is re-run inside the engine on the exact fp32 kernels and returns
  *                                that result (0); glowk_range_status counts the re-runs;
  *   GLOWK_RANGE_IGNORE           no wait, no read: calls stay fully asynchronous (hipGraph capture); the caller polls
@@ -164,6 +171,14 @@ int glowk_inverse(glowk_handle* h, const float* z_dev, int N, float* x_dev, void
 /* TransformedDistribution.log_prob(x) (train_glow.py:30, run_basis_sep.py:77): logp [N];
  * z_dev may be NULL or receives the latent */
 int glowk_log_prob(glowk_handle* h, const float* x_dev, int N, float* logp_dev, float* z_dev, void* stream);
+/* glowk_log_prob that also leaves sum_n logp[n] on the device as ONE fp64 value (accumulate != 0: added to *sum_dev -- batches
+ * evaluated in chunks): the summed log-likelihood of train_glow.py:29-31 / :52-54, which is what the ranks all-reduce (one
+ * element, RCCL).  The sum is taken in a fixed order (k_sum_f64), so it is bitwise repeatable for a given shard. */
+int glowk_log_prob_sum(glowk_handle* h, const float* x_dev, int N, float* logp_dev, float* z_dev, double* sum_dev, int accumulate,
+                       void* stream);
+/* the reduction alone: *out_dev = (accumulate ? *out_dev : 0) + scale * sum of n floats, fp64, fixed order; no handle needed
+ * (scale = -1 / global batch gives the replica's share of tf.nn.compute_average_loss, train_glow.py:29-31) */
+int glowk_sum_f64(const float* v_dev, size_t n, double* out_dev, int accumulate, double scale, void* stream);
 /* compute_grad_logprob (run_basis_sep.py:73-79): logp [N] and d sum(logp) / dx [N,H,W,C] */
 int glowk_log_prob_grad(glowk_handle* h, const float* x_dev, int N, float* logp_dev, float* dx_dev, void* stream);
 /* TransformedDistribution.sample(n) (train_glow.py:74) with the standard-normal draw supplied by the
@@ -234,16 +249,23 @@ int glowk_apply_gradients(glowk_handle* h, const float* grad_dev, int optimizer,
  * with g_k = compute_grad_logprob(x_k, model_k) supplied by the caller (glowk_log_prob_grad).  All tensors hold n floats.
  * The normal draws come from the engine's counter-based device RNG (Philox4x32-10 keyed by `seed`, counter = element, `step`,
  * source) unless eps1_dev / eps2_dev supply them (tests replay the oracle's draws; the reference draws unseeded).
+ * `offset` (a multiple of 4) is the position of element 0 in that stream: a rank that holds tiles [a, b) of the mixture passes
+ * a * H * W * C and draws exactly what one process would have drawn for those tiles, so a sharded run is the unsharded one.
  * nonfinite_dev (optional, one int on the device): set to 1 when a gradient, the mixture or an updated value is not finite --
  * the reference's debug asserts (:183-191). */
 int glowk_basis_update(float* x1_dev, float* x2_dev, const float* g1_dev, const float* g2_dev, const float* mixed_dev, size_t n,
                        float eta, float lambda_recon, const float* eps1_dev, const float* eps2_dev, uint64_t seed, uint64_t step,
-                       int* nonfinite_dev, void* stream);
+                       uint64_t offset, int* nonfinite_dev, void* stream);
 /* g(x1, x2) alone: the mixture of two sources in dB, sum in power (:133-141) */
 int glowk_basis_mix(const float* x1_dev, const float* x2_dev, float* out_dev, size_t n, void* stream);
 /* the device RNG itself: out[e] = the draw glowk_basis_update makes for element e of (seed, step, which); uniform != 0 gives
- * U(0, 1) from the same stream instead of N(0, 1) (the chain's initial state, run_basis_sep.py:360-361) */
-int glowk_random(float* out_dev, size_t n, uint64_t seed, uint64_t step, int which, int uniform, void* stream);
+ * U(0, 1) from the same stream instead of N(0, 1) (the chain's initial state, run_basis_sep.py:360-361); `offset` (a multiple
+ * of 4): out[0] is element `offset` of the stream, as for glowk_basis_update */
+int glowk_random(float* out_dev, size_t n, uint64_t seed, uint64_t step, int which, int uniform, uint64_t offset, void* stream);
+/* out = x + sigma * N(0, I), the draws being those of glowk_random(seed, step, which, offset): the input noise of the
+ * noise-conditioned training step (train_noisy_glow.py:31, X + tf.random.normal(X.shape) * noise).  out_dev may equal x_dev. */
+int glowk_add_noise(const float* x_dev, float* out_dev, size_t n, float sigma, uint64_t seed, uint64_t step, int which, uint64_t offset,
+                    void* stream);
 
 /* --- host utility ----------------------------------------------------------------------------------------------------------- */
 /* CRC-32C (Castagnoli) of a host buffer: the checksum of TFRecord frames (datasets/preprocessing.py:197-271) and of TensorFlow

@@ -156,3 +156,85 @@ def test_inner_loop_with_device_rng_is_reproducible_and_leaves_inputs_alone():
     assert torch.equal(x1, x1c) and torch.equal(x2, x2c)
     assert torch.equal(a1, b1) and torch.equal(a2, b2) and not torch.equal(a1, c1)
     assert torch.isfinite(a1).all() and float((a1 - x1).abs().max()) > 1e-3
+
+
+@pytest.mark.gpu
+def test_noise_streams_do_not_depend_on_sharding_and_never_repeat():
+    """Round-2 advisor finding: train_step(noise_std > 0) reused one noise tensor on every step and rank, and sharded BASIS ranks
+    all drew the same Langevin noise.  Now the element offset of a shard is part of the Philox counter: a rank holding tiles
+    [a, b) draws exactly what one process draws for those tiles (so results do not change with the world size), two ranks never
+    share a draw, and the flow counts its own noisy steps (train_noisy_glow.py:31: fresh noise every step, every replica)."""
+    from audiosourcesep_amd.flow_models.flow_glow import GlowFlow
+    from audiosourcesep_amd.synthetic import calibrated_engine
+    cfg = GlowConfig(H=16, W=16, C=1, L=2, K=2, F=128)
+    E = cfg.H * cfg.W * cfg.C
+    whole = basis.device_randn((12, cfg.H, cfg.W, cfg.C), "cuda", seed=5, step=9, which=2)
+    for a, b in ((0, 5), (5, 9), (9, 12)):                                     # three ragged shards
+        part = basis.device_randn((b - a, cfg.H, cfg.W, cfg.C), "cuda", seed=5, step=9, which=2, offset=a * E)
+        assert torch.equal(part, whole[a:b])
+    assert not torch.equal(whole[0:4], whole[4:8])                             # "rank 0" and "rank 1" of a 4-tile-per-rank job
+    with pytest.raises(Exception):
+        basis.device_randn((4,), "cuda", seed=5, offset=2)                     # offsets are multiples of 4 elements
+    # the fused x + sigma * noise kernel draws from the same stream
+    x = torch.from_numpy(synthetic_mel_tiles(12, cfg, seed=1)).cuda()
+    y = basis.add_device_noise(x, 0.5, seed=5, step=9, which=2)
+    assert torch.allclose(y, x + 0.5 * whole, rtol=0, atol=1e-5)               # (fma vs mul + add: one rounding apart)
+    y1 = basis.add_device_noise(x[5:9], 0.5, seed=5, step=9, which=2, offset=5 * E)
+    assert torch.equal(y1, y[5:9])
+    # the Langevin update of a shard == the same tiles inside the whole batch (device RNG, no injected noise)
+    rng = np.random.default_rng(2)
+    mk = lambda: torch.from_numpy(rng.uniform(-80, 10, (12, cfg.H, cfg.W, cfg.C)).astype(np.float32)).cuda()   # noqa: E731
+    mixed, x1, x2, g1, g2 = mk(), mk(), mk(), mk() * 0.01, mk() * 0.01
+    w1, w2 = x1.clone(), x2.clone()
+    basis.langevin_update(mixed, w1, w2, g1, g2, 1e-3, 4.0, seed=77, step=3)
+    s1, s2 = x1[5:9].clone().contiguous(), x2[5:9].clone().contiguous()
+    basis.langevin_update(mixed[5:9].contiguous(), s1, s2, g1[5:9].contiguous(), g2[5:9].contiguous(), 1e-3, 4.0, seed=77, step=3, offset=5 * E)
+    assert torch.equal(s1, w1[5:9]) and torch.equal(s2, w2[5:9])
+    # GlowFlow.train_step: consecutive noisy steps use consecutive RNG steps (engine-owned counter), never the same draw twice
+    eng, _ = calibrated_engine(cfg, device=0, init_tiles=8)
+    flow = GlowFlow(eng)
+    seen = []
+    orig = basis.add_device_noise
+
+    def spy(x, sigma, seed, step=0, which=2, offset=0):
+        out = orig(x, sigma, seed, step, which, offset)
+        seen.append((int(step), int(offset), (out - x).clone()))
+        return out
+
+    basis.add_device_noise = spy
+    try:
+        xs = x[:4].contiguous()
+        flow.train_step(xs, lr=1e-5, noise_std=0.1)
+        flow.train_step(xs, lr=1e-5, noise_std=0.1)
+        flow.train_step(xs, lr=1e-5, noise_std=0.1, tile_offset=4)             # what rank 1 of a 4-tile-per-rank job passes
+    finally:
+        basis.add_device_noise = orig
+    assert [s[0] for s in seen] == [0, 1, 2] and [s[1] for s in seen] == [0, 0, 4 * E]
+    assert not torch.equal(seen[0][2], seen[1][2]) and not torch.equal(seen[1][2], seen[2][2])
+
+
+@pytest.mark.gpu
+def test_log_prob_sum_is_the_fp64_sum_in_a_fixed_order():
+    """glowk_log_prob_sum: the fp64 summed log-likelihood leaves the engine itself (no tensor-library reduction between the
+    engine's kernels and the all-reduce of train_glow.py:52-54); chunked batches accumulate; bitwise repeatable."""
+    from audiosourcesep_amd.synthetic import calibrated_engine
+    from audiosourcesep_amd.distributed import sharded_log_prob
+    cfg = GlowConfig(H=16, W=16, C=1, L=2, K=2, F=128)
+    eng, _ = calibrated_engine(cfg, device=0, init_tiles=8)
+    x = torch.from_numpy(synthetic_mel_tiles(37, cfg, seed=4)).cuda()
+    lp, tot = eng.log_prob_sum(x)
+    assert tot.dtype == torch.float64 and tot.shape == (1,)
+    assert torch.equal(lp, eng.log_prob(x))
+    ref = lp.double().sum()
+    assert abs(float(tot[0] - ref)) <= 1e-12 * abs(float(ref))
+    lp2, tot2 = eng.log_prob_sum(x)
+    assert torch.equal(tot, tot2)
+    eng._max_tiles_cap = 8                                                     # five chunks: the engine accumulates in order
+    lp3, tot3 = eng.log_prob_sum(x)
+    eng._max_tiles_cap = None
+    assert torch.equal(lp3, lp) and abs(float(tot3[0] - ref)) <= 1e-12 * abs(float(ref))
+    # the sharding helper takes the engine and hands back the same total (one rank: no process group)
+    lp4, t4 = sharded_log_prob(eng, x)
+    assert torch.equal(lp4, lp) and float(t4) == float(tot[0])
+    _, t0 = eng.log_prob_sum(x[:0])
+    assert float(t0[0]) == 0.0
