@@ -72,6 +72,8 @@ SYMBOLS = {
     "glowk_set_range_policy": (_i, [_vp, _i]),
     "glowk_get_range_policy": (_i, [_vp]),
     "glowk_range_status": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_int64), _vp]),
+    "glowk_range_probe_begin": (_i, [_vp]),
+    "glowk_range_probe_end": (_i, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _vp]),
     "glowk_workspace_bytes": (ctypes.c_size_t, [_vp, _i, _i]),
     "glowk_reserve": (_i, [_vp, _i, _i]),
     "glowk_max_tiles": (_i, [_vp]),

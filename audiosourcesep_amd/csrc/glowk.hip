@@ -64,6 +64,7 @@ struct glowk_handle {
   int64_t range_fallbacks = 0;
   int* d_flag = nullptr;        // sticky range flag (device), written by k_couple / k_bwd_light
   int* h_flag = nullptr;        // pinned host word it is read back into
+  unsigned* d_probe = nullptr;  // glowk_range_probe_begin .. end: [2][L][K] largest gathered network input (float bits) of the forward / backward launches
   std::vector<Level> levels;
   int Hl = 0, Wl = 0, Cl = 0;
   std::vector<float> prior_loc, prior_log_scale;
@@ -110,6 +111,10 @@ struct glowk_handle {
   std::vector<size_t> tr_pin_off;        // per level: [scales K*8 | small K*K1off | b3 K*c | affine blocks K*tail]
   std::vector<hipStream_t> tr_streams;   // one per level: glowk_apply_gradients refreshes the levels' images side by side
   std::vector<hipEvent_t> tr_events;     // [0] fork, [1 + lvl] join
+  std::vector<float> tr_bfac;    // per level: power of two the split training sweep scales g_o by (BwdArgs::go_scale), adapted after every
+                                 // sweep from the largest |g_o| it saw (dynamic gradient scaling); 1 until the first sweep has run
+  unsigned* tr_gmax = nullptr;   // [L] device: that maximum (float bits), per level
+  float* h_gmax = nullptr;       // pinned host copy (read back with the sweep's one synchronisation)
   int trN = 0;
   float *trR1 = nullptr, *trR2 = nullptr, *trM1 = nullptr, *trM2 = nullptr, *trXcol = nullptr, *trGcol = nullptr, *trCpart = nullptr;
   float *trC1 = nullptr, *trC2 = nullptr, *trC3 = nullptr, *trGv = nullptr, *trGo = nullptr;
@@ -169,6 +174,15 @@ int fwd_mode(const glowk_handle* h) { return h->precision == GLOWK_PREC_F16X3 ? 
 // the light kernels raise the sticky range flag only for calls in a split arithmetic (in exact fp32 a non-finite value is the
 // reference's own result, and the fp32 re-run of the FALLBACK policy must not re-arm it)
 int* flagp(const glowk_handle* h) { return h->precision == GLOWK_PREC_F32 ? nullptr : h->d_flag; }
+
+// normalisation target of the split backward kernels for a step whose static bound allows inputs up to xlim_b (scaled units):
+// the largest power of two T with 2 T <= xlim_b, at most 2^10; 0 if even 2^-4 does not fit
+float bwd_norm_target(float xlim_b) {
+  if (!(xlim_b >= 0.125f)) return 0.0f;
+  int e = 0;
+  std::frexp(xlim_b * 0.5f, &e);                 // xlim_b / 2 = f 2^e, f in [0.5, 1): largest power of two <= it is 2^(e-1)
+  return std::ldexp(1.0f, std::min(e - 1, 10));
+}
 
 int launch_net_raw(int c, int F, const NetArgs& a, int mode, hipStream_t s, bool dry = false) {
 #define NETCASE(CI_, NF_) if (c == 2 * CI_ && F == 32 * NF_) return launch_net_t<CI_, NF_>(a, mode, s, dry);
@@ -350,6 +364,8 @@ NetArgs net_args(glowk_handle* h, const Level& lv, const StepDev& sd, const floa
   a.K1p = sd.K1p; a.ep = sd.ep; a.R0p = sd.R0p; a.mask1 = nullptr; a.mask2 = nullptr; a.P = h->bufP;
   a.RHp = sd.RHp; a.RSp = sd.RSp; a.fam16 = (sd.RSp && sd.RSBp) ? 1 : 0; a.eph = sd.epH; a.pstride = h->pstride; a.max_np = 4; a.sc1 = sd.sc1; a.sc2 = sd.sc2; a.sc3 = sd.sc3;
   a.flag = flagp(h); a.xlim = sd.xlim_f; a.st1 = nullptr; a.st2 = nullptr;
+  a.bnorm = 1.0f;
+  a.xmax_out = h->d_probe ? h->d_probe + ((&lv - h->levels.data()) * h->cfg.K + (&sd - lv.dev.data())) : nullptr;
   return a;
 }
 
@@ -642,7 +658,7 @@ struct TrainCtx {
 // Entry b reads the saved coupling input v + b v_bs [Q][c], the gradient wrt the network output g_o + b go_bs [Q][c], R1 + b r_bs
 // (R2 follows at + F Q) and M1 / M2 + b m_bs, all planar [F][Q].
 int train_network_grads(glowk_handle* h, TrainCtx* tc, int lvl, int k0, int nb, const float* v, ptrdiff_t v_bs, const float* g_o, ptrdiff_t go_bs,
-                        const float* R1, ptrdiff_t r_bs, const float* M1, const float* M2, ptrdiff_t m_bs, int N, hipStream_t s) {
+                        const float* R1, ptrdiff_t r_bs, const float* M1, const float* M2, ptrdiff_t m_bs, int N, hipStream_t s, float bfac = 1.0f) {
   const Level& lv = h->levels[lvl];
   const int F = h->cfg.F, c = lv.c, ci = c / 2, Q = N * lv.h * lv.w;
   const int N1 = 9 * ci + 1, N3 = 9 * c;
@@ -666,7 +682,7 @@ int train_network_grads(glowk_handle* h, TrainCtx* tc, int lvl, int k0, int nb, 
   float* g = tc->grad + train_step_pos(h, lvl, k0);
   StepGradArgs a;
   a.F = F; a.c = c; a.K2 = p + t.K2; a.K3 = p + t.K3; a.bn = p + t.bn; a.ep = lv.dev[k0].ep; a.eps = h->cfg.bn_eps; a.scaled = tc->split ? 1 : 0;
-  a.C1 = h->trC1; a.C2 = h->trC2; a.C3 = h->trC3; a.scale = tc->scale;
+  a.C1 = h->trC1; a.C2 = h->trC2; a.C3 = h->trC3; a.scale = tc->scale / bfac;   // (g_o, M1, M2 and their sums all carry bfac: a power of two, exact)
   a.dK1 = g + t.K1; a.dK2 = g + t.K2; a.dK3 = g + t.K3; a.db1 = g + t.b1; a.db2 = g + t.b2; a.db3 = g + t.b3;
   a.dgamma1 = g + t.bn; a.dbeta1 = g + t.bn + F; a.dgamma2 = g + t.bn + 4 * (size_t)F; a.dbeta2 = g + t.bn + 5 * (size_t)F;
   a.ps = t.total; a.es = nb > 1 ? (size_t)(lv.dev[k0 + 1].ep - lv.dev[k0].ep) : 0; a.c1s = c1s; a.c2s = c2s; a.c3s = c3s;
@@ -714,6 +730,9 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
     const int Q = N * lv.h * lv.w;
     const size_t blocks = (((size_t)Q + 255) / 256) * 8;
     int npg = 1;                    // partials of Pg the previous network launch of this level left in bufP
+    // split training sweep: g_o (and with it everything linear in it: the backward network, its stored hiddens, the im2col of g_o,
+    // the weight-gradient GEMMs) is carried times a power of two sized on the previous sweep's gradient magnitudes
+    const float bfac = (tc && tc->split && !h->tr_bfac.empty()) ? h->tr_bfac[lvl] : 1.0f;
     // training sweep: per-step slots of g_o, g_v, M1 / M2 when the level's weight-gradient work runs as one batch after its sweep
     const bool level_batch = tc && h->trNB == K && K > 1;
     const size_t go_slot = level_batch ? (size_t)Q * lv.c : 0, m_slot = level_batch ? (size_t)cfg.F * Q : 0;
@@ -723,6 +742,7 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       const size_t sidx = (size_t)lvl * K + (K - 1 - k);
       BwdArgs ba;
       ba.Q = Q; ba.h = lv.h; ba.w = lv.w; ba.flag = flagp(h);
+      ba.go_scale = bfac; ba.pg_scale = 1.0f / bfac; ba.gmax = (tc && h->tr_gmax) ? h->tr_gmax + lvl : nullptr;
       ba.v = h->saveV + h->offV[sidx]; ba.P = h->saveP + h->offP[sidx]; ba.np = h->save_parts[sidx]; ba.pstride = h->save_pstride; ba.b3 = sd.b3;
       float* go_k = tc ? h->trGo + (size_t)k * go_slot : g_o;
       ba.g_o = go_k; ba.ghalf_out = gh_b; ba.gu_out = nullptr;
@@ -747,7 +767,19 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       na.mask1 = h->saveM + h->offM[sidx];
       na.mask2 = na.mask1 + blocks * NF * 64;
       const bool h3b = (tc ? tc->split : h->precision != GLOWK_PREC_F32) && sd.RHBp;
-      if (h3b) { na.RHp = sd.RHBp; na.RSp = sd.RSBp; na.eph = nullptr; na.sc1 = sd.scb1; na.sc2 = sd.scb2; na.sc3 = sd.scb3; na.xlim = sd.xlim_b; }
+      if (h3b) {
+        na.RHp = sd.RHBp; na.RSp = sd.RSBp; na.eph = nullptr; na.sc1 = sd.scb1; na.sc2 = sd.scb2; na.sc3 = sd.scb3; na.xlim = sd.xlim_b;
+        // the backward network is linear, so the kernels normalise every pixel's gradient vector to [T, 2T) (a power of two, exact;
+        // glowk_kernels.h: pixel_norm): T = the largest power of two for which the host's worst-case bound (xlim_b: L1 norms of the
+        // folded transposed weights) rules an fp16 overflow out.  Weights so large that even T = 2^-4 is not safe (the low bits of
+        // the smaller components would go) are handled like a tripped guard: the call's range policy decides.
+        na.bnorm = tc ? 1.0f : bwd_norm_target(sd.xlim_b);      // (training: one scale per launch instead, see bfac)
+        if (na.bnorm == 0.0f) {
+          na.bnorm = 1.0f;
+          if (na.flag) HIPCHK(hipMemsetAsync(na.flag, 1, sizeof(int), s));
+        }
+      }
+      if (na.xmax_out) na.xmax_out += (size_t)cfg.L * cfg.K;     // (range probe: the backward launches' half)
       if (tc) { na.st1 = h->trM2 + (size_t)k * m_slot; na.st2 = h->trM1 + (size_t)k * m_slot; }
       if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, tc ? (tc->split ? 11 : 8) : h3b ? 5 : NET_BWD, &npg)) return rc;
       if (tc && !level_batch) {
@@ -760,13 +792,14 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
           nf.P = h->bufP + 2 * h->pstride; nf.st1 = h->trR1; nf.st2 = h->trR1 + (size_t)cfg.F * Q;
           if (launch_net_raw(lv.c, cfg.F, nf, 7, s) < 0) return 1;
         }
-        if (int rc = train_network_grads(h, tc, lvl, k, 1, h->saveV + h->offV[sidx], 0, go_k, 0, R1, 0, h->trM1, h->trM2, 0, N, s)) return rc;
+        if (int rc = train_network_grads(h, tc, lvl, k, 1, h->saveV + h->offV[sidx], 0, go_k, 0, R1, 0, h->trM1, h->trM2, 0, N, s, bfac)) return rc;
       }
     }
     // first forward step of the block (k = K-1): merge, then through its ActNorm + 1x1 -> g_u of the squeezed block input
     {
       BwdArgs ba;
       ba.Q = Q; ba.h = lv.h; ba.w = lv.w; ba.flag = flagp(h);
+      ba.go_scale = 1.0f; ba.pg_scale = 1.0f / bfac; ba.gmax = nullptr;
       ba.ghalf_in = gh_a; ba.Pg = Pg; ba.npg = npg; ba.pgstride = h->pstride; ba.gv_direct = nullptr; ba.gvd_stride = 0; ba.gvd_off = 0;
       ba.A = lv.dev[K - 1].Afwd;
       ba.v = nullptr; ba.P = nullptr; ba.np = 1; ba.pstride = 0; ba.b3 = nullptr; ba.g_o = nullptr; ba.ghalf_out = nullptr; ba.gu_out = g_o;   // reuse g_o as g_u
@@ -782,7 +815,7 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       const float* v0 = h->saveV + h->offV[(size_t)lvl * K + (K - 1)];
       const float* R10 = h->trKeep + h->trKeepOff[(size_t)lvl * K + (K - 1)] * (size_t)N;
       const ptrdiff_t r_bs = -(ptrdiff_t)(2 * (size_t)cfg.F * Q);
-      if (int rc = train_network_grads(h, tc, lvl, 0, K, v0, v_bs, h->trGo, (ptrdiff_t)go_slot, R10, r_bs, h->trM1, h->trM2, (ptrdiff_t)m_slot, N, s)) return rc;
+      if (int rc = train_network_grads(h, tc, lvl, 0, K, v0, v_bs, h->trGo, (ptrdiff_t)go_slot, R10, r_bs, h->trM1, h->trM2, (ptrdiff_t)m_slot, N, s, bfac)) return rc;
       if (int rc = train_affine_sums(h, lvl, 0, K, v0, v_bs, h->trGv, (ptrdiff_t)go_slot, N, s)) return rc;
     }
     if (lvl > 0) {
@@ -1107,6 +1140,9 @@ int glowk_destroy(glowk_handle* h) {
   DeviceGuard dg(h->device);
   if (h->arena) hipFree(h->arena);
   if (h->d_flag) hipFree(h->d_flag);
+  if (h->d_probe) hipFree(h->d_probe);
+  if (h->tr_gmax) hipFree(h->tr_gmax);
+  if (h->h_gmax) hipHostFree(h->h_gmax);
   if (h->h_flag) hipHostFree(h->h_flag);
   {
     void* tr[] = {h->tr_params, h->tr_m, h->tr_v, h->trR1, h->trR2, h->trM1, h->trM2, h->trXcol, h->trGcol, h->trCpart, h->trC1, h->trC2, h->trC3,
@@ -1408,6 +1444,40 @@ int glowk_range_status(glowk_handle* h, int* tripped, int64_t* fallbacks, void* 
       }
     }
   }
+  return 0;
+}
+
+int glowk_range_probe_begin(glowk_handle* h) {
+  if (!h) return fail("null handle");
+  DeviceGuard dg(h->device);
+  const size_t n = (size_t)2 * h->cfg.L * h->cfg.K;
+  if (!h->d_probe) HIPCHK(hipMalloc(&h->d_probe, n * sizeof(unsigned)));
+  HIPCHK(hipMemset(h->d_probe, 0, n * sizeof(unsigned)));
+  return 0;
+}
+
+int glowk_range_probe_end(glowk_handle* h, float* fwd_ratio, float* bwd_ratio, void* stream) {
+  if (!h) return fail("null handle");
+  if (!h->d_probe) return fail("glowk_range_probe_end without glowk_range_probe_begin");
+  DeviceGuard dg(h->device);
+  const int LK = h->cfg.L * h->cfg.K;
+  std::vector<float> v((size_t)2 * LK);
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  HIPCHK(hipMemcpy(v.data(), h->d_probe, v.size() * sizeof(float), hipMemcpyDeviceToHost));
+  hipFree(h->d_probe);
+  h->d_probe = nullptr;
+  float rf = 0.f, rb = 0.f;
+  for (int l = 0; l < h->cfg.L; ++l)
+    for (int k = 0; k < h->cfg.K; ++k) {
+      const StepDev& sd = h->levels[l].dev[k];
+      const int i = l * h->cfg.K + k;
+      if (sd.xlim_f > 0.f) rf = std::max(rf, v[i] / sd.xlim_f);
+      // (the backward kernels normalise their inputs per pixel: what can fail is the STATIC requirement 2 * 2^-4 <= xlim_b;
+      //  reported as that ratio -- the recorded gradient magnitudes v[LK + i] no longer matter for the range)
+      if (sd.xlim_b > 0.f && v[LK + i] > 0.f) rb = std::max(rb, 0.125f / sd.xlim_b);
+    }
+  if (fwd_ratio) *fwd_ratio = rf;
+  if (bwd_ratio) *bwd_ratio = rb;
   return 0;
 }
 
@@ -1752,6 +1822,12 @@ static int param_grad_impl(glowk_handle* h, const float* x_dev, int N, float sca
                        grad_dev + h->tr_prior_off, grad_dev + h->tr_prior_off + pad4((size_t)E));
     LAUNCHCHK("k_prior_wgrad");
   }
+  if (!h->tr_gmax) {
+    HIPCHK(hipMalloc(&h->tr_gmax, sizeof(unsigned) * 4));
+    HIPCHK(hipHostMalloc(&h->h_gmax, sizeof(float) * 4));
+    h->tr_bfac.assign(4, 1.0f);
+  }
+  HIPCHK(hipMemsetAsync(h->tr_gmax, 0, sizeof(unsigned) * 4, s));
   TrainCtx tc{grad_dev, scale, split};
   // (the input gradient falls out of the sweep as well; the trainer has no use for it: it lands in the block-level scratch,
   //  which is free again by the time the last kernel of the sweep writes it)
@@ -1761,12 +1837,27 @@ static int param_grad_impl(glowk_handle* h, const float* x_dev, int N, float sca
   std::vector<double> sums(steps * AFF_NOUT_MAX);
   HIPCHK(hipMemcpyAsync(sums.data(), h->trAffSum, sums.size() * 8, hipMemcpyDeviceToHost, s));
   if (split) HIPCHK(hipMemcpyAsync(h->h_flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(h->h_gmax, h->tr_gmax, sizeof(float) * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   if (split && h->h_flag[0]) {       // the range guard of the split arithmetic fired somewhere in the sweep: its gradients are not usable
     h->h_flag[0] = 0;
     HIPCHK(hipMemsetAsync(h->d_flag, 0, sizeof(int), s));
     *tripped = true;
     return 0;
+  }
+  {
+    // dynamic gradient scaling of the NEXT split sweep: per level, the power of two that puts this sweep's largest |g_o| a factor
+    // 16 below what the static bound of the level's backward networks admits (xlim_b, in units of GLOWK_ACT_SCALE * g_o) -- room
+    // for the gradients to grow 16x from one step to the next before a sweep has to be repeated on the exact kernels
+    const float* gm = h->h_gmax;
+    for (int lvl = 0; lvl < cfg.L; ++lvl) {
+      float xl = 0.f;
+      for (const StepDev& sd : h->levels[lvl].dev) xl = xl == 0.f ? sd.xlim_b : std::min(xl, sd.xlim_b);
+      if (!(gm[lvl] > 0.f) || !(gm[lvl] < 3.0e38f) || !(xl > 0.f)) continue;
+      int e = 0;
+      std::frexp(xl / 16.0f / ((float)GLOWK_ACT_SCALE * gm[lvl]), &e);
+      h->tr_bfac[lvl] = std::ldexp(1.0f, std::max(-100, std::min(100, e - 1)));
+    }
   }
   for (int lvl = 0; lvl < cfg.L; ++lvl) {
     const Level& lv = h->levels[lvl];

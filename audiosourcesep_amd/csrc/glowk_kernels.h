@@ -53,6 +53,11 @@ struct NetArgs {
   float sc1, sc2, sc3;   // f16x3: 2^-S of the three layers' weight scales (sc3 also undoes the activation scale)
   int* flag;             // sticky range flag of the handle, or null
   float xlim;            // split kernels: raise the flag when a gathered input (times GLOWK_ACT_SCALE) exceeds this magnitude
+  float bnorm;           // split kernels, backward network (linear in its input): every pixel's gathered gradient vector is scaled by the
+                         // power of two that brings its largest magnitude into [bnorm, 2 bnorm) before the split, and the pixel's outputs
+                         // are scaled back (exact): no gradient magnitude can leave the fp16 range, small pixels keep all their bits
+  unsigned* xmax_out;    // diagnostic (glowk_range_probe_begin), normally null: the largest gathered |input| (times GLOWK_ACT_SCALE) of
+                         // this launch, as float bits (non-negative floats order like unsigned ints), one atomic per wave
   // training (k_net_f32<..., STORE = true>): the two hidden tensors of this launch, PLANAR [F][Q] (the layout whose rows are the
   // K-contiguous operands of the weight-gradient GEMMs, glowk_train.h).  Forward: st1 = relu(conv1 + b1), st2 = relu(conv2 + b2)
   // (before BatchNorm); backward: st1 = mask2 * conv3^T(g_o) (gradient wrt relu2's output), st2 = mask1 * (K2 g_a2) (wrt relu1's)
@@ -522,6 +527,25 @@ __device__ __forceinline__ float range8(float m, const float (&v)[8]) {
   return m;
 }
 
+// margin of the static range guard: wave maximum of the gathered input magnitudes -> one atomic per wave (diagnostic runs only)
+__device__ __forceinline__ void range_probe(unsigned* out, float xmax) {
+  float m = xmax == xmax ? xmax : 3.0e38f;                 // (a NaN input counts as "beyond any limit")
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// backward network: factor (a power of two) that brings a pixel's largest gathered magnitude m into [target, 2 target), and its inverse
+// `undo` for the pixel's outputs.  m = 0 (no gradient: padding, an idle lane), a subnormal or non-finite m: 1, 1.
+__device__ __forceinline__ float pixel_norm(float m, float target, float& undo) {
+  const unsigned E = (__float_as_uint(m) >> 23) & 0xFFu;                 // m >= 0: 2^(E - 127) <= m < 2^(E - 126)
+  const unsigned T = (__float_as_uint(target) >> 23) & 0xFFu;            // target = 2^(T - 127)
+  const int ef = (int)T - (int)E + 127, eu = (int)E - (int)T + 127;      // biased exponents of target / 2^(E-127) and of its inverse
+  const bool ok = E >= 1u && E <= 254u && ef >= 1 && ef <= 254 && eu >= 1 && eu <= 254;
+  undo = ok ? __uint_as_float((unsigned)eu << 23) : 1.0f;
+  return ok ? __uint_as_float((unsigned)ef << 23) : 1.0f;
+}
+
 // x = hi + lo with hi = fp16(x), lo = fp16(x - hi), two values at a time: one packed conversion for the hi pair, two
 // conversions back, one packed subtraction, one packed conversion for the lo pair (3 instructions per value; hipcc's scalar
 // form of the same arithmetic converts hi twice: 4)
@@ -613,6 +637,7 @@ struct H3Ctx {                      // wave-uniform pointers of the kernel (LDS 
   bool wok;                         // it holds at least one pixel
   int w4;
   unsigned voff;
+  float ub[2];                      // backward: per-lane (per pixel) power of two the pixel's outputs are multiplied by (NetArgs::bnorm); [1] = the 16x16 family's second pixel
 };
 
 // activation epilogue of 16 accumulator values: forward max(acc * sc, 0) (+ the ReLU decisions as bits), backward
@@ -621,7 +646,7 @@ struct H3Ctx {                      // wave-uniform pointers of the kernel (LDS 
 //  st_blk = wave-uniform base of the hidden block's 32 rows, st_lane = this lane's byte offset, st_row = bytes per row)
 template <int MODE>
 __device__ __forceinline__ unsigned h3_act(const f32x16& acc, float sc, unsigned mask, h8 (&bh)[2], h8 (&bl)[2], bool do_st = false,
-                                           float* st_blk = nullptr, unsigned st_lane = 0, unsigned st_row = 0) {
+                                           float* st_blk = nullptr, unsigned st_lane = 0, unsigned st_row = 0, float stu = 1.0f) {
   unsigned bits = 0;
   const unsigned long long st_base = reinterpret_cast<unsigned long long>(st_blk);
 #pragma unroll
@@ -645,7 +670,8 @@ __device__ __forceinline__ unsigned h3_act(const f32x16& acc, float sc, unsigned
       unsigned off = st_lane + (unsigned)(16 * s) * st_row;      // rows 8 (r >> 2) + (r & 3): registers 8 s .. 8 s + 7 = rows 16 s + {0..3, 8..11}
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        asm volatile("global_store_dword %0, %1, %2" GLOWK_ST_MOD ::"v"(off), "v"(v[j]), "s"(st_base) : "memory");
+        const float sv = (MODE & 7) == NET_BWD ? v[j] * stu : v[j];      // backward: back in the pixel's own units (NetArgs::bnorm)
+        asm volatile("global_store_dword %0, %1, %2" GLOWK_ST_MOD ::"v"(off), "v"(sv), "s"(st_base) : "memory");
         off += (j == 3 ? 5u : 1u) * st_row;
       }
     }
@@ -704,7 +730,7 @@ __device__ __forceinline__ void h3_X(const NetArgs& a, const H3Ctx& c, int fi, c
   const int stq = (int)c.wblk * 32 + (lane & 31);
   const unsigned bits = h3_act<MODE>(h1, a.sc1, mask, bh, bl, (MODE & 8) && PASS == 0 && stq < a.Q,
                                      (MODE & 8) ? uniform_fptr(a.st1 + (size_t)fi * 32 * a.Q) : nullptr,
-                                     ((unsigned)(4 * (lane >> 5)) * (unsigned)a.Q + (unsigned)stq) * 4u, (unsigned)a.Q * 4u);
+                                     ((unsigned)(4 * (lane >> 5)) * (unsigned)a.Q + (unsigned)stq) * 4u, (unsigned)a.Q * 4u, c.ub[0]);
   if ((MODE & 7) == NET_FWD_SAVE && PASS == 0 && c.wok) a.mask1[(c.wblk * NF + fi) * 64 + lane] = (unsigned short)bits;
 }
 
@@ -791,7 +817,7 @@ __device__ __forceinline__ void h3_Z(const NetArgs& a, const H3Ctx& c, const flo
       if ((MODE & 7) == NET_BWD) mask = c.mkl[((size_t)(threadIdx.x >> 6) * NF + PASS * NFH + fo) * 64 + lane];   // mask1: the ReLU after conv1
       const unsigned bits = h3_act<MODE>(acc2[fo], a.sc2, mask, bh, bl, (MODE & 8) && qok,
                                          (MODE & 8) ? uniform_fptr(a.st2 + (size_t)(PASS * NFH + fo) * 32 * a.Q) : nullptr,
-                                         ((unsigned)(4 * hh) * (unsigned)a.Q + (unsigned)q) * 4u, (unsigned)a.Q * 4u);
+                                         ((unsigned)(4 * hh) * (unsigned)a.Q + (unsigned)q) * 4u, (unsigned)a.Q * 4u, c.ub[0]);
       if ((MODE & 7) == NET_FWD_SAVE && first_group && c.wok) a.mask2[(c.wblk * NF + PASS * NFH + fo) * 64 + lane] = (unsigned short)bits;
     }
     if (fo == 0) {
@@ -804,7 +830,8 @@ __device__ __forceinline__ void h3_Z(const NetArgs& a, const H3Ctx& c, const flo
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mt * 32 + mfma_row(r, hh);
-        if (m < M3 && qok) Pp[(size_t)m * a.Q + q] = (PASS == 0 && (MODE & 7) != NET_BWD) ? fmaf(acc3[ml][r], a.sc3, pb[m]) : acc3[ml][r] * a.sc3;
+        if (m < M3 && qok) Pp[(size_t)m * a.Q + q] = (MODE & 7) == NET_BWD ? acc3[ml][r] * (a.sc3 * c.ub[0])
+                                                     : PASS == 0 ? fmaf(acc3[ml][r], a.sc3, pb[m]) : acc3[ml][r] * a.sc3;
       }
     }
   }
@@ -905,6 +932,7 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
   c.wok = (long)c.wblk * 32 < a.Q;
   c.w4 = wave & 3;
   c.voff = (unsigned)lane * 16u;
+  c.ub[0] = c.ub[1] = 1.0f;
 
   // first the DMA of everything the first phases need (it has the longest latency of the prologue), then the gathers
   if (!g) {
@@ -927,17 +955,40 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
     const int rem = qq % hw;
     const int i = rem / a.w, j0 = rem % a.w;
     const float* base = a.vin + (long)qq * a.in_stride + a.in_off;
+    if constexpr ((MODE & 7) == NET_BWD) {
+      // the backward network is linear: normalise the pixel's gradient vector (its two lanes hh = 0, 1 hold it) by a power of two
+      float v[KS][8];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      float v[8];
-      gather8<KIN, (MODE & 7) != NET_BWD, SGN>(base, i, j0, a.h, a.w, a.in_stride, qok, 16 * s + 8 * hh, v);
-      xmax = range8(xmax, v);
-      split8(v, xh[s], xl[s]);
+      for (int s = 0; s < KS; ++s) {
+        gather8<KIN, false, SGN>(base, i, j0, a.h, a.w, a.in_stride, qok, 16 * s + 8 * hh, v[s]);
+        xmax = range8(xmax, v[s]);
+      }
+      xmax = fmaxf(xmax, __shfl_xor(xmax, 32, 64));
+      // (training, MODE & 8: the hiddens this launch stores feed GEMMs over ALL pixels, so one scale has to serve the whole
+      //  launch -- the producer pre-scaled g_o by a host-chosen power of two, BwdArgs::go_scale, and the static bound xlim checks it)
+      const float fac = (MODE & 8) ? 1.0f : pixel_norm(xmax, a.bnorm, c.ub[0]);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[s][j] *= fac;
+        split8(v[s], xh[s], xl[s]);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        float v[8];
+        gather8<KIN, true, SGN>(base, i, j0, a.h, a.w, a.in_stride, qok, 16 * s + 8 * hh, v);
+        xmax = range8(xmax, v);
+        split8(v, xh[s], xl[s]);
+      }
     }
   }
   if ((MODE & 7) != NET_BWD)
     for (int i = tid; i < G::EPN; i += 512) epl[i] = a.eph[i];
-  if (xmax > a.xlim && a.flag) *a.flag = 1;                // beyond this input magnitude the host cannot rule out an fp16 overflow
+  // forward: beyond this input magnitude the host cannot rule out an fp16 overflow; backward (normalised per pixel): only a
+  // non-finite gradient can
+  if ((((MODE & 7) == NET_BWD && !(MODE & 8)) ? !(xmax <= 3.0e38f) : !(xmax <= a.xlim)) && a.flag) *a.flag = 1;
+  if (a.xmax_out) range_probe(a.xmax_out, xmax);           // (diagnostic runs only: how far below the limit do the inputs stay?)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                         // constants and the first chunks visible to every wave
 
@@ -1213,7 +1264,8 @@ __device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const fl
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = mt * 16 + 4 * kq + r;
-            const float val = (PASS == 0 && MODE != NET_BWD) ? fmaf(acc3[ml][hf][r], a.sc3, pb[m]) : acc3[ml][hf][r] * a.sc3;
+            const float val = MODE == NET_BWD ? acc3[ml][hf][r] * (a.sc3 * c.ub[hf])
+                              : PASS == 0 ? fmaf(acc3[ml][hf][r], a.sc3, pb[m]) : acc3[ml][hf][r] * a.sc3;
             if (MERGE && PASS == 0) { keep[ml][hf][r] = val; continue; }     // pass 1 adds it and stores once
 #ifdef GLOWK_EXP_NOSTORE   // (diagnostic build, wrong results: only one row tile of P is written -- what do the P stores cost?)
             if (mt == 0)
@@ -1314,6 +1366,7 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
   c.wok = (long)c.wblk * 32 < a.Q;
   c.w4 = wave & 3;
   c.voff = (unsigned)lane * 16u;
+  c.ub[0] = c.ub[1] = 1.0f;
 
   if (!g) {
     stage4<G::MAINP, 60>(G::main_chunk(c.img, solo_pass, 0), slotA, c.w4, c.voff);
@@ -1337,18 +1390,41 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
       const int rem = qq % hw;
       const int i = rem / a.w, j0 = rem % a.w;
       const float* base = a.vin + (long)qq * a.in_stride + a.in_off;
+      if constexpr (MODE == NET_BWD) {
+        // linear network: the pixel's gradient vector (held by its four lanes kq = 0..3) is normalised by a power of two
+        float v[KS][8];
+        float pm = 0.0f;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        float v[8];
-        gather8<KIN, MODE != NET_BWD, SGN>(base, i, j0, a.h, a.w, a.in_stride, qok[hf], 32 * s + 8 * kq, v);
-        xmax = range8(xmax, v);
-        split8(v, xh[s][hf], xl[s][hf]);
+        for (int s = 0; s < KS; ++s) {
+          gather8<KIN, false, SGN>(base, i, j0, a.h, a.w, a.in_stride, qok[hf], 32 * s + 8 * kq, v[s]);
+          pm = range8(pm, v[s]);
+        }
+        pm = fmaxf(pm, __shfl_xor(pm, 16, 64));
+        pm = fmaxf(pm, __shfl_xor(pm, 32, 64));
+        xmax = fmaxf(xmax, pm);
+        const float fac = pixel_norm(pm, a.bnorm, c.ub[hf]);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[s][j] *= fac;
+          split8(v[s], xh[s][hf], xl[s][hf]);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          float v[8];
+          gather8<KIN, true, SGN>(base, i, j0, a.h, a.w, a.in_stride, qok[hf], 32 * s + 8 * kq, v);
+          xmax = range8(xmax, v);
+          split8(v, xh[s][hf], xl[s][hf]);
+        }
       }
     }
   }
   if (MODE != NET_BWD)
     for (int i = tid; i < G::EPN; i += 512) epl[i] = a.eph[i];   // RingS::EPN <= RingH::EPN, same content
-  if (xmax > a.xlim && a.flag) *a.flag = 1;                // beyond this input magnitude the host cannot rule out an fp16 overflow
+  // forward: the static bound; backward (normalised per pixel): only a non-finite gradient can leave the range
+  if ((MODE == NET_BWD ? !(xmax <= 3.0e38f) : xmax > a.xlim) && a.flag) *a.flag = 1;
+  if (a.xmax_out) range_probe(a.xmax_out, xmax);           // (diagnostic runs only: how far below the limit do the inputs stay?)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 

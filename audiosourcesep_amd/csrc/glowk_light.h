@@ -444,6 +444,13 @@ struct BwdArgs {
   int Q, h, w;
   int* flag;               // sticky range flag (see CoupleArgs); may be null
   float* gv_out;           // training: [Q][C] the merged g_v of (1) (the weight gradients of step s's ActNorm + 1x1 need it), or null
+  // training in the split arithmetic: the backward network and the weight-gradient GEMMs are linear in g_o, so g_o is written
+  // times a power of two `go_scale` chosen by the host from the gradient magnitudes of the previous sweep (dynamic scaling: it
+  // keeps every value the split kernels and GEMMs convert to fp16 inside the static range bound whatever the loss scale is),
+  // the per-tap network gradients Pg that come back carry it and are multiplied by `pg_scale` = 1 / go_scale here, and the
+  // assembly of the weight gradients divides by it.  gmax (optional): atomic maximum of |g_o| (unscaled, float bits) per launch.
+  float go_scale, pg_scale;
+  unsigned* gmax;
 };
 
 template <int C>
@@ -498,7 +505,10 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
       o[c] += __shfl_xor(o[c], 1, 64);
       o[c] += __shfl_xor(o[c], 2, 64);
     }
-    if (r4 != 0 || !live) return;
+    float gomax = 0.0f;      // largest |g_o| this lane writes (unscaled)
+    if (r4 == 0 && live) {
+#pragma unroll
+    for (int c = 0; c < CI; ++c) gsum[c] *= a.pg_scale;
     if (a.flag) {
       bool bad = false;
 #pragma unroll
@@ -544,8 +554,10 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
         const float va = a.v[(size_t)q * C + k];
         const float gya = gy[k];
         const float g_ls = gya * sc * va + 1.0f;          // + 1: d(sum log_s)/d log_s (flow_tfp_bijectors.py:150-153)
-        go[k] = g_ls * (1.0f - log_s * log_s);            // through tanh
-        go[CI + k] = gya;                                 // g_t
+        const float g_pre = g_ls * (1.0f - log_s * log_s); // through tanh
+        gomax = fmaxf(gomax, fmaxf(fabsf(g_pre), fabsf(gya)));
+        go[k] = g_pre * a.go_scale;
+        go[CI + k] = gya * a.go_scale;                    // g_t
         gh[k] = gya * sc;                                 // g_va
         gh[CI + k] = gy[CI + k];                          // g_yb (the network's contribution is merged by the next call)
       }
@@ -553,6 +565,13 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
       float* gu = a.gu_out + (size_t)q * C;
 #pragma unroll
       for (int c = 0; c < C; ++c) gu[c] = gy[c];
+    }
+    }
+    if (a.gmax) {            // (wave-uniform branch; every lane is here: idle ones carry 0)
+      if (!(gomax == gomax)) gomax = __uint_as_float(0x7f800000u);     // NaN counts as "not finite"
+#pragma unroll
+      for (int o2 = 32; o2 > 0; o2 >>= 1) gomax = fmaxf(gomax, __shfl_xor(gomax, o2, 64));
+      if ((threadIdx.x & 63) == 0 && gomax > 0.0f) atomicMax(a.gmax, __float_as_uint(gomax));
     }
   }
 }

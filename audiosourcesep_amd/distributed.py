@@ -18,7 +18,7 @@ def shard_bounds(n, world_size, rank):
     return start, start + base + (1 if rank < extra else 0)
 
 
-def sharded_log_prob(log_prob_fn, x_local, group=None, total=None):
+def sharded_log_prob(log_prob_fn, x_local, group=None, total=None, out=None):
     """Evaluate the local shard and all-reduce the summed log-likelihood.
 
     Returns (lp_local [n_local] as produced by ``log_prob_fn``, total fp64 scalar tensor identical on every rank).
@@ -27,7 +27,7 @@ def sharded_log_prob(log_prob_fn, x_local, group=None, total=None):
     device itself (``glowk_log_prob_sum``, fixed summation order) in ``total`` (a [1] float64 tensor, allocated if missing), and
     the only thing between the engine's kernels and the collective is the collective -- no tensor-library kernel."""
     if hasattr(log_prob_fn, "log_prob_sum"):
-        lp, total = log_prob_fn.log_prob_sum(x_local, total=total)
+        lp, total = log_prob_fn.log_prob_sum(x_local, out=out, total=total)
     else:
         lp = log_prob_fn(x_local) if x_local.shape[0] else torch.zeros(0, dtype=torch.float32, device=x_local.device)
         total = lp.sum(dtype=torch.float64).reshape(1)

@@ -125,6 +125,17 @@ class GlowEngine:
         _lib.check(self.lib.glowk_range_status(self.h, ctypes.byref(tripped) if sync else None, ctypes.byref(n), self._stream()))
         return bool(tripped.value), int(n.value)
 
+    def range_probe_begin(self):
+        """Start measuring the margin of the static range bound (``glowk_range_probe_begin``)."""
+        _lib.check(self.lib.glowk_range_probe_begin(self.h))
+
+    def range_probe_end(self):
+        """-> (forward, backward): largest gathered network input / its limit over the split launches since ``range_probe_begin``
+        (< 1: inside the bound; 0: no such launch)."""
+        f, b = ctypes.c_float(0), ctypes.c_float(0)
+        _lib.check(self.lib.glowk_range_probe_end(self.h, ctypes.byref(f), ctypes.byref(b), self._stream()))
+        return float(f.value), float(b.value)
+
     def _after_call(self):
         if self.get_precision() == _lib.PREC_F32:
             return

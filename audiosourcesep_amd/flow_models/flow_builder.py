@@ -61,7 +61,7 @@ def initial_variables(cfg: GlowConfig, rng):
 
 
 def build_glow(minibatch, data_shape, L=3, K=32, n_filters=512, learntop=True, l2_reg=None,
-               mirrored_strategy=None, data_type="image", seed=None, device=None, precision=None, **kwargs):
+               mirrored_strategy=None, data_type="image", seed=None, device=None, precision=None, actnorm_init="reference", **kwargs):
     """Same arguments as the reference (flow_builder.py:60-61).
 
     * ``L`` outside {2,3,4} raises ``ValueError("L should be 2, 3 or 4")`` (:76-77).
@@ -76,7 +76,14 @@ def build_glow(minibatch, data_shape, L=3, K=32, n_filters=512, learntop=True, l
       accuracy, ~3x the speed).  ``seed`` / ``device`` are extensions too.
     * ``minibatch`` drives the data-dependent ActNorm init exactly like the reference constructor, including the
       raw-minibatch quirk of the 3/4-level graphs (flow_glow.py:162-165), on the GPU.
+    * ``actnorm_init`` (extension): ``"reference"`` visits the steps in constructor order 0..K-1 although ``tfb.Chain`` applies them
+      K-1..0 -- the flow that comes out is NOT normalised (log_prob per dimension of the order of -1e5 on its own
+      minibatch) and only training repairs it; ``"runtime"`` visits them in the order the forward pass applies them, from the
+      propagated tensors: every step's input is normalised from the first call on.  Short training runs (the noise-conditioned
+      priors of the BASIS chain test) use ``"runtime"``.
     """
+    if actnorm_init not in ("reference", "runtime"):
+        raise ValueError("actnorm_init must be 'reference' or 'runtime'")
     if L not in (2, 3, 4):
         raise ValueError("L should be 2, 3 or 4")
     if data_type == "image":
@@ -95,7 +102,7 @@ def build_glow(minibatch, data_shape, L=3, K=32, n_filters=512, learntop=True, l
         minibatch = torch.as_tensor(np.asarray(minibatch, dtype=np.float32))
     if tuple(minibatch.shape[1:]) != (H, W, C):
         raise ValueError("minibatch must be [N, %d, %d, %d]" % (H, W, C))     # ActNorm asserts, flow_tfp_bijectors.py:218-220
-    eng.actnorm_data_init(minibatch, runtime_order=False, raw_minibatch_quirk=True)
+    eng.actnorm_data_init(minibatch, runtime_order=actnorm_init == "runtime", raw_minibatch_quirk=actnorm_init == "reference")
     flow = GlowFlow(eng)
     if precision is not None:
         flow.set_precision(precision)

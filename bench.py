@@ -83,7 +83,7 @@ def cpu_info():
 
 def cpu_baseline(cfg, params, budget_s=24.0):
     """Oracle port on the host cores: torch-CPU fp32 restatement of the reference graph (oracle/glowref_torch.py; not
-    TensorFlow).  Bounded sample of the same workload: median of three passes each
+    TensorFlow).  Bounded sample of the same workload: median of ten passes each
     of (a) the deduplicated graph (one network evaluation per step) at the host share of threads -- the headline `value`,
     (b) the faithful graph (two evaluations per step, as TFP's forward + forward_log_det_jacobian do), (c) one thread."""
     from oracle import glowref_torch as RT
@@ -103,7 +103,7 @@ def _cpu_baseline_pinned(RT, cfg, params, budget_s, threads):
     x = torch.from_numpy(synthetic_mel_tiles(128, cfg, seed=4321))
     d = cfg.as_dict()
 
-    def timed(tiles, evals, reps=3):
+    def timed(tiles, evals, reps=10):
         ts = []
         for _ in range(reps):
             t0 = time.perf_counter()
@@ -118,14 +118,17 @@ def _cpu_baseline_pinned(RT, cfg, params, budget_s, threads):
         t0 = time.perf_counter()
         RT.log_prob(x[:2], p, d)
         t1 = (time.perf_counter() - t0) / 2.0
-        share = budget_s / 3.0 / 3.0                  # three variants x three passes
+        share = budget_s / 3.0 / 10.0                 # three variants x ten passes (>= 10 timed passes, median)
         # (the same tile count for the deduplicated and the faithful graph: per-tile CPU time depends on the batch --
         #  hidden activations of 64 tiles no longer fit the caches -- and the two variants are meant to be compared)
-        tiles = int(max(1, min(32, share / max(1.5 * t1, 1e-3))))
+        tiles = int(max(2, min(32, share / max(1.5 * t1, 1e-3))))
+        t0 = time.perf_counter()                      # (the two-tile probe over-estimates the per-tile time of a larger batch: one
+        RT.log_prob(x[:tiles], p, d)                  #  pass at the first guess, then the tile count that fills the share)
+        tiles = int(max(2, min(32, tiles * share / max(time.perf_counter() - t0, 1e-3))))
         med, tot = timed(tiles, 1)
         spent += tot
         out = {"value": tiles / med, "unit": "passes/s", "cores": threads, "kind": "port",
-               "sample": "median of 3 passes over %d tiles of the same config (%.1f s of CPU work in all three variants), torch-CPU "
+               "sample": "median of 10 passes over %d tiles of the same config (%.1f s of CPU work in all three variants), torch-CPU "
                          "fp32 restatement of the reference graph (oracle/glowref_torch.py; NOT TensorFlow), deduplicated graph "
                          "(one network evaluation per step)" % (tiles, 0.0)}
         tf = tiles
@@ -139,83 +142,192 @@ def _cpu_baseline_pinned(RT, cfg, params, budget_s, threads):
         RT.log_prob(x[:1], p, d)
         t1 = time.perf_counter() - t0
         t1n = int(max(1, min(4, share / max(t1, 1e-3))))
-        med, tot = timed(t1n, 1)
+        med, tot = timed(t1n, 1, reps=3)
         spent += tot
-        out["threads_1"] = {"value": t1n / med, "unit": "passes/s", "cores": 1, "tiles": t1n, "note": "deduplicated graph, one thread"}
+        out["threads_1"] = {"value": t1n / med, "unit": "passes/s", "cores": 1, "tiles": t1n, "note": "deduplicated graph, one thread, median of 3 passes"}
         torch.set_num_threads(threads)
     out["sample"] = out["sample"].replace("(0.0 s", "(%.1f s" % spent)
     out["host"] = cpu_info()
     return out
 
 
-def secondary_workload(args, cfg, eng, params, rank, world, local_rank, dist):
-    """log_prob_grad: one step = log_prob + d/dx over the resident batch.  basis: one step = one Langevin update of the
-    BASIS loop (two flow priors, run_basis_sep.py:163-181) over ``--batch`` mixture tiles per GPU (reference: 30)."""
-    from audiosourcesep_amd import basis
-    from audiosourcesep_amd.flow_models.flow_glow import GlowFlow
-    from audiosourcesep_amd.synthetic import calibrated_engine
-    n = args.batch
-    x = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=1234 + rank)).cuda()
-    if args.workload == "log_prob_grad":
-        def step():
-            eng.log_prob_grad(x)
-        unit, metric, per_step = "tiles/s", "Glow log_prob + input-gradient tiles/sec", n
-    elif args.workload == "train":
-        # one step of train_glow.py:37-54: loss + all parameter gradients (in --precision: the split kernels with hidden stores, or
-        # the exact fp32 ones), ONE all-reduce of the flat gradient vector (RCCL), Adamax, device-side refresh of the kernel images
-        from audiosourcesep_amd.distributed import distributed_train_step
-        state = {}
-
-        def step():
-            state["loss"] = distributed_train_step(eng.param_grad, lambda g: eng.apply_gradients(g, "adamax", 1e-4), x, n * world)
-        unit, metric, per_step = "tiles/s", "Glow training step tiles/sec (loss + all gradients + Adamax)", n
-    else:
-        eng2, _ = calibrated_engine(cfg, device=local_rank, init_tiles=max(n, 64), seed=4048)
-        eng2.set_precision(eng.get_precision())
-        m1, m2 = GlowFlow(eng), GlowFlow(eng2)
-        x2 = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=4321 + rank)).cuda()
-        mixed = basis.mixing_db(x, x2)
-        # state: mel-like tiles (other seeds), not the reference's uniform draw -- the synthetic priors are far out of their
-        # domain on uniform noise (log_prob ~ -1e33), and timing a loop that carries inf/NaN would not be a measurement
-        state = {"x1": torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=777 + rank)).cuda(),
-                 "x2": torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=888 + rank)).cuda()}
-        sigmas = basis.get_sigmas(1.0, 0.01, 10)
-
-        def step():   # every step starts from the same state: with these untrained priors the chain itself diverges within ~8 steps
-            state["y1"], state["y2"] = basis.basis_inner_loop(mixed, state["x1"], state["x2"], m1, m2, 9, sigmas, T=1)
-        unit, metric, per_step = "tile-steps/s", "BASIS Langevin tile-steps/sec (2 Glow priors)", n
-    for _ in range(args.warmup):
+def _timed_steps(step, steps, warmup, dist, rehearsal):
+    """W untimed + K timed calls of `step`, bracketed by barrier + synchronize on both sides; max over ranks."""
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if args.workload == "basis":
-        assert torch.isfinite(state["y1"]).all() and torch.isfinite(state["y2"]).all(), "BASIS update left the finite range"
-    if args.workload == "train":
-        assert torch.isfinite(state["loss"]).all(), "training diverged"
     if dist is not None:
-        t = torch.tensor([elapsed], device="cpu" if dist.get_backend() == "gloo" else "cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    return elapsed
+
+
+def grad_workload(cfg, n, precision, steps, warmup, rank, local_rank, dist, rehearsal):
+    """log_prob + d/dx (compute_grad_logprob, run_basis_sep.py:73-79) over a resident batch, under GLOWK_RANGE_ERROR."""
+    from audiosourcesep_amd.synthetic import calibrated_engine
+    eng, _ = calibrated_engine(cfg, device=local_rank, init_tiles=n)
+    eng.set_precision(precision)
+    eng.set_range_policy("error")
+    eng.reserve(n, with_grad=True)
+    x = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=1234 + rank)).cuda()
+    el = _timed_steps(lambda: eng.log_prob_grad(x), steps, warmup, dist, rehearsal)
+    assert eng.range_status() == (False, 0), "the range guard fired"
+    eng.close()
+    return el
+
+
+def train_workload(cfg, n, precision, steps, warmup, rank, world, local_rank, dist, rehearsal):
+    """One step of train_glow.py:37-54: loss + all parameter gradients (in `precision`: the split kernels with hidden stores, or the
+    exact ones), ONE all-reduce of the flat gradient vector (RCCL), Adamax, device-side refresh of the kernel images.  The range
+    policy is "fallback" -- a sweep whose gradient scale is not yet known is repeated on the exact kernels -- and the number of such
+    repeats inside the run is part of the result."""
+    from audiosourcesep_amd.synthetic import calibrated_engine
+    from audiosourcesep_amd.distributed import distributed_train_step
+    eng, _ = calibrated_engine(cfg, device=local_rank, init_tiles=n)
+    eng.set_precision(precision)
+    eng.set_range_policy("fallback")
+    eng.reserve(n, with_grad=True)
+    x = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=1234 + rank)).cuda()
+    state = {}
+
+    def step():
+        state["loss"] = distributed_train_step(eng.param_grad, lambda g: eng.apply_gradients(g, "adamax", 1e-4), x, n * world)
+    for _ in range(2):      # (the first sweep sizes the dynamic gradient scale of the split sweep; not part of the measurement)
+        step()
+    before = eng.range_status(sync=False)[1]
+    el = _timed_steps(step, steps, warmup, dist, rehearsal)
+    fallbacks = eng.range_status(sync=False)[1] - before
+    assert torch.isfinite(state["loss"]).all(), "training diverged"
+    pv = eng.param_vector_size
+    eng.close()
+    return el, fallbacks, pv
+
+
+def basis_workload(args, K, levels, train_steps, T, steps, warmup, rank, world, local_rank, dist, rehearsal, precision):
+    """BASELINE config 5 as it is meant: two noise-conditioned Glow priors (L = 3, n_filters = 512, K steps per level) are trained
+    here with the repo's own training step on the reference's 30 real tiles per stem (tests/golden/basis_real_tiles.npz; the ladder
+    of train_noisy_glow.py:309-358), kept resident per sigma, and the BASIS chain (run_basis_sep.py:217-260) runs on the 30 mixture
+    tiles from the reference's uniform start in `precision` under GLOWK_RANGE_ERROR.  Timed: `steps` CONSECUTIVE Langevin steps of
+    that chain at the last (smallest) sigma, after the chain has run T steps at every level -- no restart, the state carries over.
+    Every rank separates the same 30 tiles with its own noise stream (weak scaling of independent chains)."""
+    from audiosourcesep_amd import basis
+    from audiosourcesep_amd.flow_models.flow_builder import build_glow
+    from audiosourcesep_amd.noise_conditioned import fine_tune_ladder, psnr_db, db_schedule
+    f = np.load(os.path.join(ROOT, "tests", "golden", "basis_real_tiles.npz"))
+    gt1, gt2, mixed = (torch.from_numpy(f[k].astype(np.float32))[..., None].cuda() for k in ("gt1", "gt2", "mixed"))
+    n = mixed.shape[0]
+    t0 = time.perf_counter()
+    priors, ladders, fb_train = [], [], []
+    for i, gt in enumerate((gt1, gt2)):
+        flow = build_glow(gt, [96, 64, 1], L=3, K=K, n_filters=512, learntop=True, seed=100 + i, precision=precision, actnorm_init="runtime",
+                          device=local_rank, data_type="melspec", minval=-100.0, maxval=20.0, use_logit=False)
+        flow.engine.set_range_policy("fallback")
+        sig_db, delta_db = db_schedule(flow.cfg, sigma1=0.3, sigmaL=0.01, num_classes=levels)
+        models, losses = fine_tune_ladder(flow, gt, sig_db, [3 * train_steps] + [train_steps] * (levels - 1), lr=1e-3, seed=7 + i)
+        assert all(np.isfinite(losses[float(s)]).all() for s in sig_db), "prior training diverged"
+        fb_train.append(flow.engine.range_status()[1])
+        priors.append(flow)
+        ladders.append(models)
+    torch.cuda.synchronize()
+    t_train = time.perf_counter() - t0
+    cfg = priors[0].cfg
+    engines = [m[float(s)].engine for m in ladders for s in sig_db]
+    for e in engines:
+        e.set_range_policy("error")
+        e.range_probe_begin()
+    x1 = -100.0 + 120.0 * basis.device_randn(tuple(mixed.shape), mixed.device, seed=11 + rank, which=0, uniform=True)
+    x2 = -100.0 + 120.0 * basis.device_randn(tuple(mixed.shape), mixed.device, seed=11 + rank, which=1, uniform=True)
+    start = (psnr_db(x1, gt1), psnr_db(x2, gt2))
+    t0 = time.perf_counter()
+    y1, y2, _ = basis.basis_outer_loop(mixed, x1, x2, priors[0], priors[1], sig_db, restore_1=ladders[0], restore_2=ladders[1], T=T,
+                                       delta=delta_db, seed=3 + rank)
+    torch.cuda.synchronize()
+    t_chain = time.perf_counter() - t0
+    assert torch.isfinite(y1).all() and torch.isfinite(y2).all(), "the chain left the finite range"
+    # timed region: consecutive steps at the last level, the state carried from call to call
+    last = len(sig_db) - 1
+    m1, m2 = ladders[0][float(sig_db[last])], ladders[1][float(sig_db[last])]
+    state = {"x1": y1, "x2": y2, "t": len(sig_db) * T}
+
+    def step():
+        state["x1"], state["x2"] = basis.basis_inner_loop(mixed, state["x1"], state["x2"], m1, m2, last, sig_db, delta=delta_db, T=1,
+                                                          seed=3 + rank, step0=state["t"])
+        state["t"] += 1
+    el = _timed_steps(step, steps, warmup, dist, rehearsal)
+    assert torch.isfinite(state["x1"]).all() and torch.isfinite(state["x2"]).all(), "the chain left the finite range"
+    margins = [e.range_probe_end() for e in engines]
+    trips = sum(int(e.range_status()[0]) + e.range_status(sync=False)[1] for e in engines)
+    end = (psnr_db(state["x1"], gt1), psnr_db(state["x2"], gt2))
+    flop_step = 2 * 2 * cfg.flop_per_tile()     # two priors, forward + data gradient (SURVEY 8d: 2x forward FLOPs with stored hiddens)
+    out = {
+        "value": n * world * steps / el, "unit": "tile-steps/s", "ms_per_step": el / steps * 1e3, "dtype": precision, "steps": steps,
+        "config": {"workload": "BASIS Langevin steps, 2 trained noise-conditioned Glow priors, 96x64x1 real mel tiles (30 per GPU), L=3 K=%d "
+                               "n_filters=512, %d sigma levels x T=%d then %d timed consecutive steps at sigma_L" % (K, levels, T, steps)},
+        "roofline": {"bound": "mfma", "achieved": n * steps / el * flop_step / 1e12, "peak": PEAK_F16_MFMA_TFLOPS / 3.0 if precision != "f32" else PEAK_F32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "note": "2 priors x (forward + data gradient = 2x forward FLOP) per tile-step"},
+        "range_guard": {"policy": "GLOWK_RANGE_ERROR on every chain step", "trips_or_fallbacks_in_chain": trips,
+                        "largest_forward_input_over_limit": max(m[0] for m in margins), "backward_static_ratio": max(m[1] for m in margins),
+                        "fallback_sweeps_while_training": fb_train},
+        "priors": {"trained_here_s": t_train, "sigmas_db": [float(s) for s in sig_db], "delta_db2": delta_db,
+                   "train_steps_per_level": [3 * train_steps] + [train_steps] * (levels - 1)},
+        "chain": {"levels_x_T_s": t_chain, "tile_steps_per_s_whole_ladder": n * len(sig_db) * T / t_chain,
+                  "psnr_db_start": start, "psnr_db_end": end,
+                  "psnr_db_reference_shipped_result": (psnr_db(f["x1"].astype(np.float32), f["gt1"].astype(np.float32)),
+                                                       psnr_db(f["x2"].astype(np.float32), f["gt2"].astype(np.float32)))},
+    }
+    out["roofline"]["frac"] = out["roofline"]["achieved"] / out["roofline"]["peak"]
+    for e in engines:
+        e.close()
+    return out
+
+
+def secondary_workload(args, cfg, rank, world, local_rank, dist, rehearsal, extra):
+    """--workload log_prob_grad | train | basis as the ONE line of the run."""
+    n = args.batch
+    prec = {"f32": 0, "f16x3": 1, "f16x2": 2}[args.precision]
+    base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic"}
+    if args.workload == "log_prob_grad":
+        el = grad_workload(cfg, n, prec, args.steps, args.warmup, rank, local_rank, dist, rehearsal)
+        v = n * world * args.steps / el
+        out = dict(base, metric="Glow log_prob + input-gradient tiles/sec", value=v, unit="tiles/s", ms_per_step=el / args.steps * 1e3,
+                   config={"workload": "log_prob_grad, %dx%dx%d tiles, L=%d K=%d n_filters=%d, %d tiles/GPU" % (cfg.H, cfg.W, cfg.C, cfg.L, cfg.K, cfg.F, n)},
+                   roofline=grad_roofline(cfg, v / world, args.precision, 2))
+    elif args.workload == "train":
+        el, fb, pv = train_workload(cfg, n, prec, args.steps, args.warmup, rank, world, local_rank, dist, rehearsal)
+        v = n * world * args.steps / el
+        out = dict(base, metric="Glow training step tiles/sec (loss + all gradients + Adamax)", value=v, unit="tiles/s",
+                   ms_per_step=el / args.steps * 1e3, param_vector_floats=pv, fallback_sweeps_in_timed_region=fb,
+                   config={"workload": "train, %dx%dx%d tiles, L=%d K=%d n_filters=%d, %d tiles/GPU" % (cfg.H, cfg.W, cfg.C, cfg.L, cfg.K, cfg.F, n)},
+                   roofline=grad_roofline(cfg, v / world, args.precision, 3))
+    else:
+        r = basis_workload(args, args.basis_K, args.basis_levels, args.basis_train_steps, args.basis_T, args.steps, args.warmup, rank, world,
+                           local_rank, dist, rehearsal, args.precision)
+        out = dict(base, metric="BASIS Langevin tile-steps/sec (2 trained noise-conditioned Glow priors)", data="real mel tiles shipped with the reference (30 per stem); priors trained in this run", **r)
+    out.update(extra)
     if rank == 0:
-        print(json.dumps({
-            "metric": metric, "value": per_step * world * args.steps / elapsed, "unit": unit, "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "%s, %dx%dx%d tiles, L=%d K=%d n_filters=%d, %d tiles/GPU" % (args.workload, cfg.H, cfg.W, cfg.C, cfg.L, cfg.K, cfg.F, n)},
-            **({"param_vector_floats": eng.param_vector_size, "gflop_per_tile_fwd": cfg.flop_per_tile() / 1e9,
-                "tflops_at_4x_fwd_flops": per_step * world * args.steps / elapsed * 4 * cfg.flop_per_tile() / 1e12 / world} if args.workload == "train" else {}),
-        }), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
+
+
+def grad_roofline(cfg, tiles_per_s_per_gpu, precision, fwd_multiples):
+    """Whole-path roofline of the gradient workloads: algorithmic FLOP = `fwd_multiples` x the forward pass (forward +
+    data gradient = 2x; the training step adds the weight gradients: 3x) against the MFMA peak of the arithmetic."""
+    peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS / 3.0
+    ach = tiles_per_s_per_gpu * fwd_multiples * cfg.flop_per_tile() / 1e12
+    return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "note": "%dx the forward pass's algorithmic FLOP per tile (%.2f GFLOP), whole step incl. light kernels and optimizer" % (fwd_multiples, cfg.flop_per_tile() / 1e9)}
 
 
 def self_launch(args):
@@ -262,6 +374,11 @@ def main():
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "f16x2"],
                     help="f16x3: error-compensated fp16 split on the fp16 MFMA (fp32-class accuracy, demonstrated in the line); "
                          "f32: exact fp32-input MFMA")
+    ap.add_argument("--basis-K", type=int, default=32, help="--workload basis: flow steps per level of the two priors")
+    ap.add_argument("--basis-levels", type=int, default=4, help="--workload basis: sigma levels of the ladder (reference: 10)")
+    ap.add_argument("--basis-train-steps", type=int, default=100, help="--workload basis: training steps per sigma level (3x at the first)")
+    ap.add_argument("--basis-T", type=int, default=100, help="--workload basis: Langevin steps per sigma level before the timed region")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the log_prob_grad / train / basis sub-objects of the N=1 default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-shapes", action="store_true", help="skip the config-A line inside the N=1 default run")
     ap.add_argument("--cpu-budget", type=float, default=24.0, help="seconds of CPU work for the cpu_baseline sample")
@@ -294,6 +411,19 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    # what the collective actually saw: an all-reduce of ones over the job's process group (= the number of ranks RCCL connected),
+    # and the device every rank computes on -- so that a line with n_gpus = N validates itself
+    dist_info = {}
+    if dist is not None:
+        ones = torch.ones(1, dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        props = torch.cuda.get_device_properties(local_rank)
+        mine = {"rank": rank, "local_rank": local_rank, "cuda_device": torch.cuda.current_device(), "name": props.name,
+                "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None)}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        dist_info = {"rccl_ranks_seen": int(ones.item()), "backend": dist.get_backend(), "rank_devices": gathered}
+
     cfg = {"A": CONFIG_A, "B": CONFIG_B, "YAML": CONFIG_YAML}[args.config]
     from audiosourcesep_amd import _lib
     from audiosourcesep_amd.synthetic import calibrated_engine
@@ -302,10 +432,10 @@ def main():
     n = args.batch
 
     if args.workload != "log_prob":
-        eng, params = calibrated_engine(cfg, device=local_rank, init_tiles=n)
-        eng.set_precision(PREC[args.precision])
-        eng.reserve(n, with_grad=True)
-        secondary_workload(args, cfg, eng, params, rank, world, local_rank, dist)
+        secondary_workload(args, cfg, rank, world, local_rank, dist, rehearsal, dict(dist_info, git_head=git_head()))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
         return
 
     def measure(cfg, precision, steps, warmup, with_others):
@@ -323,9 +453,9 @@ def main():
         total = torch.zeros(1, device="cuda", dtype=torch.float64)
 
         def step():
-            # local shard on this GPU, then ONE all-reduce of the fp64 summed log-likelihood (RCCL over xGMI)
-            _, tot = sharded_log_prob(lambda xx: eng.log_prob(xx, out=lp), x)
-            total.copy_(tot)
+            # local shard on this GPU -- log_prob [n] and its fp64 sum both leave the engine (glowk_log_prob_sum) --, then ONE
+            # all-reduce of that one element (RCCL over xGMI).  Nothing but the engine's kernels and the collective runs here.
+            sharded_log_prob(eng, x, total=total, out=lp)
 
         def timed(k_steps):
             torch.cuda.synchronize()
@@ -480,8 +610,28 @@ def main():
         out["config_A_32x32_K16_L2"]["roofline"] = {k: la["roofline"][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "flop_per_launch")}
         ra["eng"].close()
         del ra
+        torch.cuda.empty_cache()
+    # the secondary workloads of the path (BASELINE config 5) as compact sub-objects of the ONE line, each a few
+    # seconds: the input-gradient path at the headline batch, the training step at the reference's batch of 32, and the BASIS chain
+    # on the reference's 30 real mixture tiles with two priors trained here (K = 32, a shortened three-level ladder)
+    if world == 1 and cfg is CONFIG_B and not args.no_secondary:
+        el = grad_workload(CONFIG_B, 1024, PREC[args.precision], 3, 1, rank, local_rank, None, False)
+        v = 1024 * 3 / el
+        out["log_prob_grad_1024"] = {"value": v, "unit": "tiles/s", "ms_per_step": el / 3 * 1e3, "dtype": args.precision,
+                                     "config": {"workload": "log_prob + input gradient, 64x64x1, L=3 K=32 n_filters=512, 1024 tiles"},
+                                     "range_guard": "GLOWK_RANGE_ERROR, not tripped", "roofline": grad_roofline(CONFIG_B, v, args.precision, 2)}
+        torch.cuda.empty_cache()
+        el, fb, pv = train_workload(CONFIG_B, 32, PREC[args.precision], 8, 2, rank, 1, local_rank, None, False)
+        v = 32 * 8 / el
+        out["train_32"] = {"value": v, "unit": "tiles/s", "ms_per_step": el / 8 * 1e3, "dtype": args.precision, "fallback_sweeps_in_timed_region": fb,
+                           "config": {"workload": "training step (loss + all gradients + Adamax + image refresh), 64x64x1, L=3 K=32 n_filters=512, 32 tiles"},
+                           "param_vector_floats": pv, "roofline": grad_roofline(CONFIG_B, v, args.precision, 3)}
+        torch.cuda.empty_cache()
+        out["basis_30"] = basis_workload(args, 32, 3, 60, 30, 20, 2, rank, 1, local_rank, None, False, args.precision)
+        torch.cuda.empty_cache()
     if rank == 0:
         out["git_head"] = git_head()
+        out.update(dist_info)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, params_main, args.cpu_budget)
         print(json.dumps(out), flush=True)

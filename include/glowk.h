@@ -150,6 +150,15 @@ int glowk_get_range_policy(const glowk_handle* h);
 /* waits for `stream`, reports whether the sticky range flag is set (and clears it) and how many calls were re-run on the
  * fp32 kernels so far; either output may be NULL */
 int glowk_range_status(glowk_handle* h, int* tripped, int64_t* fallbacks, void* stream);
+/* The margin of the static bound, measured: between glowk_range_probe_begin and glowk_range_probe_end every split-kernel launch
+ * of the handle also records the largest coupling-network input it gathered (one atomic per wave, in the kernels' prologue);
+ * glowk_range_probe_end waits for `stream` and returns, over all those launches, the largest  input / limit  of the forward
+ * networks -- below 1 the guard did not fire, 0 means no split launch ran -- and, for the backward (gradient) networks, which
+ * are linear and normalise every pixel's gradient vector by a power of two before the split (so that no gradient magnitude can
+ * leave the range), the static ratio (smallest usable normalisation) / (what the weights' worst-case bound allows).  A
+ * diagnostic (bench.py reports it for the trained BASIS priors); off by default. */
+int glowk_range_probe_begin(glowk_handle* h);
+int glowk_range_probe_end(glowk_handle* h, float* fwd_ratio, float* bwd_ratio, void* stream);
 /* device memory (bytes) the engine allocates for batches up to N: the forward/inverse workspace, plus -- with_grad != 0 --
  * the per-step saves and gradient scratch of glowk_log_prob_grad in the handle's current precision.  glowk_reserve allocates
  * exactly that up front, so that no later compute call of that kind with that batch size (or a smaller one in the same

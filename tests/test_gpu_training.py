@@ -268,6 +268,12 @@ def test_split_training_steps_refresh_the_f16_images_on_the_device(cfg):
     # one more step from the device-refreshed images equals one more step from the host-packed ones
     eng.set_precision(_lib.PREC_F16X3)
     other.set_precision(_lib.PREC_F16X3)
+    # (to fp32 rounding, not bit for bit: since round 3 the split sweep carries g_o times a power of two sized on the PREVIOUS
+    #  sweep's gradient magnitudes -- dynamic gradient scaling, DESIGN section 8a -- and `eng` has a history that `other` lacks;
+    #  a power-of-two scale moves which low bits of the small values fall into fp16's subnormal range)
     _, g1 = eng.param_grad(x, -1.0 / 24.0)
     _, g2 = other.param_grad(x, -1.0 / 24.0)
-    assert torch.equal(g1, g2)
+    assert float((g1 - g2).abs().max()) <= 2e-6 * float(g2.abs().max())
+    _, g3 = other.param_grad(x, -1.0 / 24.0)                       # with the same history: bit for bit
+    _, g4 = other.param_grad(x, -1.0 / 24.0)
+    assert torch.equal(g3, g4)
