@@ -62,6 +62,7 @@ struct glowk_handle {
   int precision = GLOWK_PREC_F32;
   int range_policy = GLOWK_RANGE_ERROR;
   int64_t range_fallbacks = 0;
+  int64_t fused_steps = 0;      // flow steps that ran as ONE network + coupling kernel (net_and_couple)
   int* d_flag = nullptr;        // sticky range flag (device), written by k_couple / k_bwd_light
   int* h_flag = nullptr;        // pinned host word it is read back into
   unsigned* d_probe = nullptr;  // glowk_range_probe_begin .. end: [2][L][K] largest gathered network input (float bits) of the forward / backward launches
@@ -238,6 +239,50 @@ int launch_couple(int c, const CoupleArgs& a, int N, hipStream_t s) {
   return 0;
 }
 
+// One flow step's coupling network + coupling.  Plain forward direction of the split arithmetics at the 4-channel level with a grid
+// that fills the chip: ONE kernel (k_net_h3s<..., MODE | 16>: the per-tap conv3 outputs never leave the workgroup) plus
+// k_couple_edge for the pixel rows whose 3 x 3 neighbourhood straddles two workgroups and the per-sample log-det; otherwise k_net
+// (P to HBM) + k_couple.  na: the network launch (na.P / pstride as for launch_net); ca: the coupling as k_couple takes it.
+bool fuse_geometry_ok(int h, int w) {
+  const int hw = h * w;
+  if (w < 4 || w > FUSE_EW || (w & (w - 1)) || 256 % w) return false;
+  if (hw % 256 == 0) return true;
+  return hw >= 32 && hw < 256 && (hw & (hw - 1)) == 0;
+}
+
+int net_and_couple(glowk_handle* h, int lvl, int c, int F, NetArgs na, CoupleArgs ca, int N, hipStream_t s, int mode) {
+  const bool no_fuse = getenv("GLOWK_NO_FUSE") != nullptr;     // (A/B timing and the fused-vs-unfused parity test: read per call)
+  const int hw = ca.h * ca.w;
+  if (!no_fuse && c == 4 && (mode == 3 || mode == 6) && na.RSp && ca.vin && !ca.log_s_out && ca.out && na.in_stride == 4 &&
+      ca.out_stride % 4 == 0 && ca.out_off % 4 == 0 && fuse_geometry_ok(ca.h, ca.w) && na.P == h->bufP) {
+    const size_t wgs = ((size_t)ca.Q + 255) / 256;
+    const size_t edge_floats = (wgs * 4 * FUSE_EW * 4 + 3) & ~(size_t)3;
+    const size_t nld = wgs * 8;                                          // one fp64 log-det partial per wave (32 pixels)
+    if ((edge_floats + 2 * nld + 4) <= 4 * h->pstride) {                // (the scratch lives in the P buffers the fused launch does not use)
+      na.fuse = 1;
+      na.fz_b3 = ca.b3; na.fz_A = ca.A; na.fz_b = ca.b; na.fz_out = ca.out; na.fz_out_stride = ca.out_stride; na.fz_out_off = ca.out_off;
+      na.fz_inverse = ca.inverse;
+      na.fz_edge = h->bufP;
+      na.fz_ldpart = ca.logdet ? reinterpret_cast<double*>(h->bufP + edge_floats) : nullptr;
+    }
+  }
+  int np = 1;
+  if (int rc = launch_net(h, lvl, c, F, na, s, mode, &np)) return rc;
+  if (np != 100) {
+    ca.P = na.P; ca.np = np; ca.pstride = na.pstride;
+    return launch_couple(c, ca, N, s);
+  }
+  ++h->fused_steps;
+  if (hw > 256 || ca.logdet) {
+    EdgeArgs ea;
+    ea.vin = ca.vin; ea.edge = na.fz_edge; ea.ldpart = na.fz_ldpart; ea.A = ca.A; ea.b = ca.b; ea.out = ca.out; ea.out_stride = ca.out_stride;
+    ea.out_off = ca.out_off; ea.inverse = ca.inverse; ea.logdet = ca.logdet; ea.h = ca.h; ea.w = ca.w; ea.flag = ca.flag;
+    hipLaunchKernelGGL(k_couple_edge, dim3(N), dim3(256), 0, s, ea);
+    LAUNCHCHK("k_couple_edge");
+  }
+  return 0;
+}
+
 PreArgs pre_args(const glowk_config& cfg) {
   PreArgs p;
   p.minval = cfg.minval; p.maxval = cfg.maxval; p.alpha = cfg.alpha; p.use_logit = cfg.use_logit;
@@ -365,6 +410,8 @@ NetArgs net_args(glowk_handle* h, const Level& lv, const StepDev& sd, const floa
   a.RHp = sd.RHp; a.RSp = sd.RSp; a.fam16 = (sd.RSp && sd.RSBp) ? 1 : 0; a.eph = sd.epH; a.pstride = h->pstride; a.max_np = 4; a.sc1 = sd.sc1; a.sc2 = sd.sc2; a.sc3 = sd.sc3;
   a.flag = flagp(h); a.xlim = sd.xlim_f; a.st1 = nullptr; a.st2 = nullptr;
   a.bnorm = 1.0f;
+  a.fuse = 0; a.fz_b3 = nullptr; a.fz_A = nullptr; a.fz_b = nullptr; a.fz_out = nullptr; a.fz_out_stride = 0; a.fz_out_off = 0; a.fz_inverse = 0;
+  a.fz_edge = nullptr; a.fz_ldpart = nullptr;
   a.xmax_out = h->d_probe ? h->d_probe + ((&lv - h->levels.data()) * h->cfg.K + (&sd - lv.dev.data())) : nullptr;
   return a;
 }
@@ -425,8 +472,11 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
         na.st1 = h->trKeep + h->trKeepOff[sidx] * (size_t)N;
         na.st2 = na.st1 + (size_t)cfg.F * Q;
       }
-      if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, keep_hidden ? (h->precision == GLOWK_PREC_F32 ? 9 : 10)
-                                                            : save ? (h->precision == GLOWK_PREC_F32 ? NET_FWD_SAVE : 4) : fwd_mode(h), &np)) return rc;
+      const bool plain = !keep_hidden && !save;       // the plain forward direction: network + coupling may run as one kernel
+      if (!plain) {
+        if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, keep_hidden ? (h->precision == GLOWK_PREC_F32 ? 9 : 10)
+                                                              : (h->precision == GLOWK_PREC_F32 ? NET_FWD_SAVE : 4), &np)) return rc;
+      }
       if (save) h->save_parts[sidx] = np;
       CoupleArgs ca;
       ca.vin = cur; ca.P = na.P; ca.np = np; ca.pstride = na.pstride; ca.b3 = sd.b3; ca.logdet = h->bufLd; ca.log_s_out = nullptr; ca.t_out = nullptr;
@@ -440,7 +490,8 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
       } else {
         ca.A = nullptr; ca.b = nullptr; ca.out = z_dst; ca.out_stride = h->Cl; ca.out_off = lv.z_off;
       }
-      if (int rc = launch_couple(lv.c, ca, N, s)) return rc;
+      if (plain) { if (int rc = net_and_couple(h, lvl, lv.c, cfg.F, na, ca, N, s, fwd_mode(h))) return rc; }
+      else if (int rc = launch_couple(lv.c, ca, N, s)) return rc;
       if (k > 0) {
         if (save) cur = next; else std::swap(cur, oth);
       } else if (lvl < L - 1) {
@@ -847,13 +898,11 @@ int run_inverse(glowk_handle* h, const float* z, int N, float* x, hipStream_t s)
     std::swap(cur, oth);
     for (int k = 0; k < K; ++k) {   // Chain.inverse: step 0 first
       const StepDev& sd = lv.dev[k];
-      int np = 1;
-      if (int rc = launch_net(h, lvl, lv.c, cfg.F, net_args(h, lv, sd, cur, lv.c, lv.c / 2, N), s, fwd_mode(h), &np)) return rc;
       CoupleArgs ca;
-      ca.vin = cur; ca.P = h->bufP; ca.np = np; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
+      ca.vin = cur; ca.P = h->bufP; ca.np = 1; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
       ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 1; ca.flag = flagp(h);
       ca.A = sd.Ainv; ca.b = sd.binv; ca.out = oth; ca.out_stride = lv.c; ca.out_off = 0;
-      if (int rc = launch_couple(lv.c, ca, N, s)) return rc;
+      if (int rc = net_and_couple(h, lvl, lv.c, cfg.F, net_args(h, lv, sd, cur, lv.c, lv.c / 2, N), ca, N, s, fwd_mode(h))) return rc;
       std::swap(cur, oth);
     }
   }
@@ -1613,6 +1662,8 @@ int glowk_prior_log_prob(glowk_handle* h, const float* z_dev, int N, float* logp
   LAUNCHCHK("k_prior");
   return 0;
 }
+
+int64_t glowk_fused_steps(const glowk_handle* h) { return h ? h->fused_steps : -1; }
 
 int glowk_profile_begin(glowk_handle* h) {
   if (!h) return fail("null handle");

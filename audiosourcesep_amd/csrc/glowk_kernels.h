@@ -56,6 +56,15 @@ struct NetArgs {
   float bnorm;           // split kernels, backward network (linear in its input): every pixel's gathered gradient vector is scaled by the
                          // power of two that brings its largest magnitude into [bnorm, 2 bnorm) before the split, and the pixel's outputs
                          // are scaled back (exact): no gradient magnitude can leave the fp16 range, small pixels keep all their bits
+  // ---- coupling fused into k_net_h3s<..., MODE | 16> (fused_couple): what k_couple would have been given
+  int fuse;              // host side: ask the launch policy for the fused instance (it answers 100 instead of a number of partials)
+  const float* fz_b3;    // [C] conv3 bias
+  const float* fz_A;     // post affine [C][C] or null (forward: the NEXT step's ActNorm + 1x1; inverse: this step's inverse 1x1 + ActNorm)
+  const float* fz_b;     // [C]
+  float* fz_out;         // element (q, co) at fz_out[q * fz_out_stride + fz_out_off + co] (stride and offset multiples of 4)
+  int fz_out_stride, fz_out_off, fz_inverse;
+  float* fz_edge;        // [workgroup][4][64][4]: partial sums of its first / last pixel row, contributions to the rows above / below
+  double* fz_ldpart;     // per workgroup (h w >= 256) or per sample: sum of log_s over the pixels completed in the kernel; or null
   unsigned* xmax_out;    // diagnostic (glowk_range_probe_begin), normally null: the largest gathered |input| (times GLOWK_ACT_SCALE) of
                          // this launch, as float bits (non-negative floats order like unsigned ints), one atomic per wave
   // training (k_net_f32<..., STORE = true>): the two hidden tensors of this launch, PLANAR [F][Q] (the layout whose rows are the
@@ -637,6 +646,7 @@ struct H3Ctx {                      // wave-uniform pointers of the kernel (LDS 
   bool wok;                         // it holds at least one pixel
   int w4;
   unsigned voff;
+  float* pl;                        // fused coupling: LDS copy of the workgroup's per-tap outputs, [36][FUSE_PSTR]
   float ub[2];                      // backward: per-lane (per pixel) power of two the pixel's outputs are multiplied by (NetArgs::bnorm); [1] = the 16x16 family's second pixel
 };
 
@@ -1019,10 +1029,15 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// KIN / MOUT / MODE / NP as for RingH
+constexpr int FUSE_PSTR = 260;     // fused coupling: floats per LDS row of P: 4 * 260 = 16 (mod 64) banks apart, so the four row
+                                   // quarters (kq) of a 16 x 16 accumulator tile store to disjoint banks
+constexpr int FUSE_EW = 64;        // pixels per row slot of the edge buffer
+
+// KIN / MOUT / MODE / NP as for RingH; MODE | 16: the coupling fused into the kernel (fused_couple)
 template <int KIN, int MOUT, int NF, int MODE, int NP>
 struct RingS {
-  static constexpr bool BWD = MODE == NET_BWD;
+  static constexpr bool BWD = (MODE & 7) == NET_BWD;
+  static constexpr bool FUSE = (MODE & 16) != 0;                   // coupling fused into the kernel (see fused_couple); plain forward modes only
   static constexpr int NFH = NF / NP;                             // hidden 32-channel blocks per pass
   static constexpr int NRB = 2 * NFH;                             // 16-row blocks per pass
   static constexpr int K1 = 9 * KIN;
@@ -1044,7 +1059,8 @@ struct RingS {
   static constexpr int MASK2B = BWD ? 2 * NF * 512 * 2 : 0;       // backward: both ReLU masks of the workgroup's 8 column blocks
   static constexpr size_t LDS_BYTES = (size_t)3 * MAIN4 * 16 + (size_t)2 * K14 * 16 + (size_t)EPN * 4 + MASK2B;
   static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && NFH >= 2 && KS <= (NP == 2 ? 3 : 5) && NGRP <= 3 &&
-                               (NGRP == 1 || GT % TPC == 0);   // (chunks do not straddle groups)
+                               (NGRP == 1 || GT % TPC == 0) &&   // (chunks do not straddle groups)
+                               (!FUSE || (MOUT == 36 && NP == 2 && LDS_BYTES + (size_t)36 * FUSE_PSTR * 4 + 4096 + 128 <= 160 * 1024));
   // image (one for every NP, laid out for NP = 2): conv1 operands of all blocks, then per half of the hidden width the main
   // chunks (NF row blocks) and the conv3 tiles of NF/2 hidden blocks, 16 tiles per chunk; a pass of NP = 4 reads its half
   static constexpr int K1TOT4 = NF * K14;
@@ -1074,7 +1090,7 @@ struct RingS {
 #ifdef GLOWK_NO_MERGE   // (A/B builds only, scripts/ab.py)
   static constexpr bool MERGE = false;
 #else
-  static constexpr bool MERGE = NP == 2 && NGRP == 1 && NMT <= 3 && (MODE == NET_FWD || MODE == NET_FWD2);
+  static constexpr bool MERGE = NP == 2 && NGRP == 1 && NMT <= 3 && ((MODE & 7) == NET_FWD || (MODE & 7) == NET_FWD2);
 #endif
 };
 
@@ -1119,7 +1135,7 @@ __device__ __forceinline__ void h3s_X(const NetArgs& a, const H3Ctx& c, int fi, 
                                       const h8 (&xl)[(RingS<KIN, MOUT, NF, MODE, NP>::KS)][2], int lane, h8 (&bh)[2], h8 (&bl)[2]) {
   using G = RingS<KIN, MOUT, NF, MODE, NP>;
   unsigned mask = 0;
-  if (MODE == NET_BWD) mask = c.mkl[((size_t)(8 + (threadIdx.x >> 6)) * NF + fi) * 64 + lane];   // mask2: the ReLU after conv2
+  if ((MODE & 7) == NET_BWD) mask = c.mkl[((size_t)(8 + (threadIdx.x >> 6)) * NF + fi) * 64 + lane];   // mask2: the ReLU after conv2
   f32x4 h1[2][2];   // [row block][pixel half]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1137,7 +1153,7 @@ __device__ __forceinline__ void h3s_X(const NetArgs& a, const H3Ctx& c, int fi, 
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
-          h1[rb][hf] = mfma3s<MODE == NET_FWD2>(kf[(s * 2 + rb) * 2 + 0], kf[(s * 2 + rb) * 2 + 1], xh[s][hf], xl[s][hf], h1[rb][hf]);
+          h1[rb][hf] = mfma3s<(MODE & 7) == NET_FWD2>(kf[(s * 2 + rb) * 2 + 0], kf[(s * 2 + rb) * 2 + 1], xh[s][hf], xl[s][hf], h1[rb][hf]);
   } else {
 #pragma unroll
     for (int s = 0; s < G::KS; ++s)
@@ -1145,13 +1161,13 @@ __device__ __forceinline__ void h3s_X(const NetArgs& a, const H3Ctx& c, int fi, 
       for (int rb = 0; rb < 2; ++rb) {
         const h8 ah = k1[((s * 2 + rb) * 2 + 0) * 64], al = k1[((s * 2 + rb) * 2 + 1) * 64];
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) h1[rb][hf] = mfma3s<MODE == NET_FWD2>(ah, al, xh[s][hf], xl[s][hf], h1[rb][hf]);
+        for (int hf = 0; hf < 2; ++hf) h1[rb][hf] = mfma3s<(MODE & 7) == NET_FWD2>(ah, al, xh[s][hf], xl[s][hf], h1[rb][hf]);
       }
   }
   unsigned bits = 0;
 #pragma unroll
-  for (int hf = 0; hf < 2; ++hf) bits |= h3s_act<MODE>(h1[0][hf], h1[1][hf], a.sc1, mask >> (8 * hf), bh[hf], bl[hf]) << (8 * hf);
-  if (MODE == NET_FWD_SAVE && PASS == 0 && c.wok) a.mask1[(c.wblk * NF + fi) * 64 + lane] = (unsigned short)bits;
+  for (int hf = 0; hf < 2; ++hf) bits |= h3s_act<(MODE & 7)>(h1[0][hf], h1[1][hf], a.sc1, mask >> (8 * hf), bh[hf], bl[hf]) << (8 * hf);
+  if ((MODE & 7) == NET_FWD_SAVE && PASS == 0 && c.wok) a.mask1[(c.wblk * NF + fi) * 64 + lane] = (unsigned short)bits;
 }
 
 // Y: conv2 contribution of one hidden block (one k-step of 32) to the pass's NRB x 2 accumulator tiles; same pipelining and
@@ -1199,7 +1215,7 @@ __device__ __forceinline__ void h3s_Y(const float4* slot, const h8 (&bh)[2], con
     acc2[o0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1], bh[1], acc2[o0][1], 0, 0, 0);
     acc2[o1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[3], bh[0], acc2[o1][0], 0, 0, 0);
     acc2[o1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[3], bh[1], acc2[o1][1], 0, 0, 0);
-    if (MODE != NET_FWD2) {
+    if ((MODE & 7) != NET_FWD2) {
       acc2[o0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bl[0], acc2[o0][0], 0, 0, 0);
       acc2[o0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bl[1], acc2[o0][1], 0, 0, 0);
       acc2[o1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2], bl[0], acc2[o1][0], 0, 0, 0);
@@ -1245,28 +1261,32 @@ __device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const fl
       const int ml = mt % 6;                             // this row block's accumulator within its group
       if (ml == 0) {
         unsigned mask = 0, bits = 0;
-        if (MODE == NET_BWD) mask = c.mkl[((size_t)(threadIdx.x >> 6) * NF + PASS * NFH + fo) * 64 + lane];   // mask1: the ReLU after conv1
+        if ((MODE & 7) == NET_BWD) mask = c.mkl[((size_t)(threadIdx.x >> 6) * NF + PASS * NFH + fo) * 64 + lane];   // mask1: the ReLU after conv1
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
-          bits |= h3s_act<MODE>(acc2[2 * fo][hf], acc2[2 * fo + 1][hf], a.sc2, mask >> (8 * hf), bh[hf], bl[hf]) << (8 * hf);
-        if (MODE == NET_FWD_SAVE && t < NFH * G::G0N && c.wok) a.mask2[(c.wblk * NF + PASS * NFH + fo) * 64 + lane] = (unsigned short)bits;
+          bits |= h3s_act<(MODE & 7)>(acc2[2 * fo][hf], acc2[2 * fo + 1][hf], a.sc2, mask >> (8 * hf), bh[hf], bl[hf]) << (8 * hf);
+        if ((MODE & 7) == NET_FWD_SAVE && t < NFH * G::G0N && c.wok) a.mask2[(c.wblk * NF + PASS * NFH + fo) * 64 + lane] = (unsigned short)bits;
       }
       if (fo == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { acc3[ml][0][r] = 0.0f; acc3[ml][1][r] = 0.0f; }
       }
       const h8 ah = buf[(tp * 2 + 0) * 64], al = buf[(tp * 2 + 1) * 64];
-      acc3[ml][0] = mfma3s<MODE == NET_FWD2>(ah, al, bh[0], bl[0], acc3[ml][0]);
-      acc3[ml][1] = mfma3s<MODE == NET_FWD2>(ah, al, bh[1], bl[1], acc3[ml][1]);
+      acc3[ml][0] = mfma3s<(MODE & 7) == NET_FWD2>(ah, al, bh[0], bl[0], acc3[ml][0]);
+      acc3[ml][1] = mfma3s<(MODE & 7) == NET_FWD2>(ah, al, bh[1], bl[1], acc3[ml][1]);
       if (fo == NFH - 1) {
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = mt * 16 + 4 * kq + r;
-            const float val = MODE == NET_BWD ? acc3[ml][hf][r] * (a.sc3 * c.ub[hf])
+            const float val = (MODE & 7) == NET_BWD ? acc3[ml][hf][r] * (a.sc3 * c.ub[hf])
                               : PASS == 0 ? fmaf(acc3[ml][hf][r], a.sc3, pb[m]) : acc3[ml][hf][r] * a.sc3;
             if (MERGE && PASS == 0) { keep[ml][hf][r] = val; continue; }     // pass 1 adds it and stores once
+            if constexpr (G::FUSE) {      // the per-tap outputs stay in the workgroup: LDS row m, pixel = wave * 32 + 16 hf + lane % 16
+              if (m < M3) c.pl[m * FUSE_PSTR + (int)(threadIdx.x >> 6) * 32 + 16 * hf + (lane & 15)] = val + keep[ml][hf][r];
+              continue;
+            }
 #ifdef GLOWK_EXP_NOSTORE   // (diagnostic build, wrong results: only one row tile of P is written -- what do the P stores cost?)
             if (mt == 0)
 #endif
@@ -1298,7 +1318,7 @@ __device__ __forceinline__ void h3s_pass(const NetArgs& a, const H3Ctx& c, const
   for (int ob = 0; ob < NRB; ++ob)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float b = MODE == NET_BWD ? 0.0f : epl[f2base + ob * 16 + 4 * kq + r];   // conv2 bias (scaled)
+      const float b = (MODE & 7) == NET_BWD ? 0.0f : epl[f2base + ob * 16 + 4 * kq + r];   // conv2 bias (scaled)
       acc2[ob][0][r] = b;
       acc2[ob][1][r] = b;
     }
@@ -1331,11 +1351,105 @@ __device__ __forceinline__ void h3s_passes(const NetArgs& a, const H3Ctx& c, con
   if constexpr (PASS + 1 < NP) h3s_passes<KIN, MOUT, NF, MODE, NP, PASS + 1, (RingS<KIN, MOUT, NF, MODE, NP>::NCH + 1 + P0) & 1>(a, c, epl, xh, xl, g, q, qok, lane, kq, keep);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Coupling fused into the network kernel (4-channel level, both passes in one workgroup: RingS::MERGE).  The workgroup's per-tap
+// conv3 outputs P [36][256 px] never go to HBM: the closing Z ops write them to LDS, and after the last phase every pixel whose
+// 3 x 3 neighbourhood lies inside the workgroup (or outside the image: zero padding) is finished here -- gather of the nine taps,
+// conv3 bias, tanh / exp, the affine coupling (flow_tfp_bijectors.py:134-148), the next step's ActNorm + 1x1, the store of the
+// NHWC output, and its share of sum log_s (:150-153).  A workgroup holds 256 / w whole image rows; the pixels of its first / last
+// row that have a neighbour row in ANOTHER workgroup cannot be finished: for them the kernel leaves (a) their partial sums over the
+// taps it holds and (b) what its own first / last row contributes to the rows above / below (8 floats per edge pixel in all, instead
+// of 36 floats of P per pixel), and k_couple_edge -- one small workgroup per sample -- completes those rows and adds the log-det.
+// Two threads per pixel: lane half k = lane >> 5 owns channel pair (k, 2 + k) = (pre-tanh log_s_k, t_k).
+// Requires: w a power of two <= 64, h w a multiple of 256 or a power of two in [32, 256) (the host checks: glowk.hip).
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool fz_not_finite(float v) { return !(fabsf(v) <= 3.0e38f); }
+
+__device__ __forceinline__ void fused_couple(const NetArgs& a, const float* pl, const float4* vst, int tid) {
+  const int wave = tid >> 6, lane = tid & 63;
+  const int px = wave * 32 + (lane & 31), k = lane >> 5;
+  const int q = (int)blockIdx.x * 256 + px;
+  const bool qok = q < a.Q;
+  const int w = a.w, hw = a.h * a.w, nrows = 256 / w;
+  const int pp = (qok ? q : 0) % hw;
+  const int i = pp / w, j = pp % w, r = px / w;
+  float ols = 0.0f, ot = 0.0f;
+  bool missing = false;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const int ii = i + dy, jj = j + dx;
+    if (ii < 0 || ii >= a.h || jj < 0 || jj >= w) continue;      // zero padding
+    const int rr = r + dy;
+    if (rr < 0 || rr >= nrows) { missing = true; continue; }      // that row belongs to another workgroup
+    const int spx = px + dy * w + dx;
+    ols += pl[(tap * 4 + k) * FUSE_PSTR + spx];
+    ot += pl[(tap * 4 + 2 + k) * FUSE_PSTR + spx];
+  }
+  ols += a.fz_b3[k];
+  ot += a.fz_b3[2 + k];
+  float lsum = 0.0f;
+  // (the partner lane l ^ 32 holds the other channel pair of the SAME pixel: the two take identical branches)
+  const float4 v4 = vst[px];          // the pixel's four input channels, parked in LDS by the prologue (a global load here would be
+                                      // a full memory latency on the workgroup's serial tail: nothing else runs on this CU)
+  const float vk = k ? v4.y : v4.x;
+  const float log_s = tanhf(ols);
+  const float sc = expf(log_s);
+  const float yk = a.fz_inverse ? (vk - ot) / sc : sc * vk + ot;
+  const float yo = __shfl_xor(yk, 32, 64);                        // the other transformed channel
+  const float y[4] = {k ? yo : yk, k ? yk : yo, v4.z, v4.w};
+  if (qok && !missing) {
+    lsum = log_s;
+    bool bad = fz_not_finite(ols) | fz_not_finite(ot) | fz_not_finite(yk);
+    if (bad && a.flag) *a.flag = 1;
+    // this lane stores output channels 2k, 2k + 1: the same fma chain over the input channels as k_couple's affine_cc
+    float z0, z1;
+    if (a.fz_A) {
+      z0 = a.fz_b[2 * k]; z1 = a.fz_b[2 * k + 1];
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) {
+        z0 = fmaf(y[ci], a.fz_A[ci * 4 + 2 * k], z0);
+        z1 = fmaf(y[ci], a.fz_A[ci * 4 + 2 * k + 1], z1);
+      }
+    } else {
+      z0 = y[2 * k]; z1 = y[2 * k + 1];
+    }
+    *reinterpret_cast<float2*>(a.fz_out + (size_t)q * a.fz_out_stride + a.fz_out_off + 2 * k) = float2{z0, z1};
+  } else if (qok) {
+    // edge pixel: partial sums (bias included) of the taps this workgroup holds; slot 0 = its first row, 1 = its last row
+    float* e = a.fz_edge + (((size_t)blockIdx.x * 4 + (r == 0 ? 0 : 1)) * FUSE_EW + j) * 4;
+    e[k] = ols;
+    e[2 + k] = ot;
+  }
+  // what the first row contributes to the row above (slot 2: taps dy = +1 seen from there) and the last row to the row below
+  // (slot 3: taps dy = -1): 2 w targets x 4 channels, one thread each
+  if (tid < 2 * w * 4) {
+    const int which = tid / (4 * w), jt = (tid / 4) % w, ch = tid & 3;
+    float hsum = 0.0f;
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int js = jt + dx;
+      if (js < 0 || js >= w) continue;
+      const int tap = (which ? 0 : 6) + dx + 1;
+      hsum += pl[(tap * 4 + ch) * FUSE_PSTR + (which ? (nrows - 1) * w : 0) + js];
+    }
+    a.fz_edge[(((size_t)blockIdx.x * 4 + 2 + which) * FUSE_EW + jt) * 4 + ch] = hsum;
+  }
+  // log-det share of the pixels finished here: one fp64 partial per wave (32 pixels: h w >= 32, so a wave never straddles two
+  // samples), lanes added in a fixed order; k_couple_edge adds a sample's partials in order (no barrier on this serial tail)
+  if (a.fz_ldpart) {
+    double d = (double)lsum;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o, 64);
+    if (lane == 0) a.fz_ldpart[(size_t)blockIdx.x * 8 + wave] = d;
+  }
+}
+
 template <int KIN, int MOUT, int NF, int MODE, int NP, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
   using G = RingS<KIN, MOUT, NF, MODE, NP>;
   constexpr int KS = G::KS;
-  constexpr int SGN = (MODE == NET_BWD) ? -1 : 1;   // backward gathers at q - d(tap)
+  constexpr int SGN = ((MODE & 7) == NET_BWD) ? -1 : 1;   // backward gathers at q - d(tap)
   static_assert(G::FITS, "shape");
 
   __shared__ float4 slotA[G::MAIN4];
@@ -1345,6 +1459,9 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
   __shared__ float4 k1slot1[G::K14];
   __shared__ float epl[G::EPN];
   __shared__ __attribute__((aligned(16))) unsigned short mkl[G::MASK2B / 2 + 8];
+  __shared__ float plds[G::FUSE ? 36 * FUSE_PSTR : 1];   // fused coupling: the workgroup's per-tap outputs
+  __shared__ float4 vstash[G::FUSE ? 256 : 1];           // ... and its pixels' four input channels (coupling input)
+  static_assert(!G::FUSE || (G::MERGE && !SPLIT && MOUT == 36), "the fused coupling needs both passes in one workgroup and a 4-channel level");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1362,6 +1479,7 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
   c.k1img = a.RSp;
   c.img = a.RSp;
   c.mkl = mkl;
+  c.pl = plds;
   c.wblk = (size_t)blockIdx.x * 8 + wave;
   c.wok = (long)c.wblk * 32 < a.Q;
   c.w4 = wave & 3;
@@ -1371,12 +1489,12 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
   if (!g) {
     stage4<G::MAINP, 60>(G::main_chunk(c.img, solo_pass, 0), slotA, c.w4, c.voff);
     stage4<G::MAINP, 61>(G::out_chunk(c.img, solo_pass, 0), slotD, c.w4, c.voff);
-    if (MODE == NET_BWD)   // the forward pass's ReLU decisions of this workgroup's 8 column blocks: [mask1 | mask2][wave][block][lane]
+    if ((MODE & 7) == NET_BWD)   // the forward pass's ReLU decisions of this workgroup's 8 column blocks: [mask1 | mask2][wave][block][lane]
       stage4<NF, 64>(reinterpret_cast<const float4*>(a.mask1 + (size_t)blockIdx.x * 8 * NF * 64), reinterpret_cast<float4*>(mkl), c.w4, c.voff);
   } else {
     stage4<G::K1P, 62>(c.k1img, k1slot0, c.w4, c.voff);
     stage4<G::K1P, 63>(c.k1img + G::K14, k1slot1, c.w4, c.voff);
-    if (MODE == NET_BWD)
+    if ((MODE & 7) == NET_BWD)
       stage4<NF, 65>(reinterpret_cast<const float4*>(a.mask2 + (size_t)blockIdx.x * 8 * NF * 64), reinterpret_cast<float4*>(mkl + 8 * NF * 64), c.w4, c.voff);
   }
   // im2col fragments of this lane's two pixels: k-step s holds k = 32 s + 8 kq + j (natural order), scaled and split
@@ -1390,7 +1508,7 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
       const int rem = qq % hw;
       const int i = rem / a.w, j0 = rem % a.w;
       const float* base = a.vin + (long)qq * a.in_stride + a.in_off;
-      if constexpr (MODE == NET_BWD) {
+      if constexpr ((MODE & 7) == NET_BWD) {
         // linear network: the pixel's gradient vector (held by its four lanes kq = 0..3) is normalised by a power of two
         float v[KS][8];
         float pm = 0.0f;
@@ -1420,10 +1538,16 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
       }
     }
   }
-  if (MODE != NET_BWD)
+  if constexpr (G::FUSE) {
+    if (tid < 256) {
+      const int qv = (int)blockIdx.x * 256 + tid;
+      vstash[tid] = qv < a.Q ? *reinterpret_cast<const float4*>(a.vin + (size_t)qv * 4) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  if ((MODE & 7) != NET_BWD)
     for (int i = tid; i < G::EPN; i += 512) epl[i] = a.eph[i];   // RingS::EPN <= RingH::EPN, same content
   // forward: the static bound; backward (normalised per pixel): only a non-finite gradient can leave the range
-  if ((MODE == NET_BWD ? !(xmax <= 3.0e38f) : xmax > a.xlim) && a.flag) *a.flag = 1;
+  if (((MODE & 7) == NET_BWD ? !(xmax <= 3.0e38f) : xmax > a.xlim) && a.flag) *a.flag = 1;
   if (a.xmax_out) range_probe(a.xmax_out, xmax);           // (diagnostic runs only: how far below the limit do the inputs stay?)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -1441,5 +1565,9 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
     h3s_passes<KIN, MOUT, NF, MODE, NP, 0, 0>(a, c, epl, xh, xl, g, q, qok, lane, kq, keep);
   }
   if (!g) h3_barrier();
+  if constexpr (G::FUSE) {
+    __syncthreads();       // every wave's LDS writes of P are complete and visible (lgkmcnt(0) + barrier)
+    fused_couple(a, plds, vstash, tid);
+  }
 }
 

@@ -259,6 +259,77 @@ __global__ __launch_bounds__(1024) void k_couple(CoupleArgs a) {   // 256 .. 102
   }
 }
 
+// the rows the fused kernel could not finish (see fused_couple): one workgroup per sample.  Also adds the sample's log-det:
+// the partial sums of the fused workgroups plus the edge pixels' own log_s.
+struct EdgeArgs {
+  const float* vin;      // [Q][4]
+  const float* edge;     // [workgroup][4][FUSE_EW][4]
+  const double* ldpart;
+  const float *A, *b;
+  float* out;
+  int out_stride, out_off, inverse;
+  double* logdet;        // [N] += (may be null)
+  int h, w;
+  int* flag;
+};
+
+__global__ __launch_bounds__(256) void k_couple_edge(EdgeArgs a) {
+  __shared__ double red[4];
+  const int n = blockIdx.x, w = a.w, hw = a.h * a.w;
+  const int nb = hw >= 256 ? hw / 256 : 1, rows = 256 / w;
+  float lsum = 0.0f;
+  const int nedge = hw > 256 ? 2 * w * (nb - 1) : 0;
+  for (int t = threadIdx.x; t < nedge; t += 256) {
+    const int b = 1 + t / (2 * w), lower = (t / w) & 1, j = t % w;
+    const size_t wgA = (size_t)n * nb + b - 1, wgB = wgA + 1;         // the workgroups above and below the boundary
+    // upper row = last row of A: its partial sums (slot 1) + B's contribution upwards (slot 2); lower row = first row of B: slot 0 + A's slot 3
+    const float4 part = *reinterpret_cast<const float4*>(a.edge + (((lower ? wgB : wgA) * 4 + (lower ? 0 : 1)) * FUSE_EW + j) * 4);
+    const float4 halo = *reinterpret_cast<const float4*>(a.edge + (((lower ? wgA : wgB) * 4 + (lower ? 3 : 2)) * FUSE_EW + j) * 4);
+    const size_t q = (size_t)n * hw + (size_t)(b * rows - 1 + lower) * w + j;
+    const float o[4] = {part.x + halo.x, part.y + halo.y, part.z + halo.z, part.w + halo.w};
+    const float4 v4 = *reinterpret_cast<const float4*>(a.vin + q * 4);
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    float y[4];
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float log_s = tanhf(o[k]), sc = expf(log_s), tt = o[2 + k];
+      y[k] = a.inverse ? (v[k] - tt) / sc : sc * v[k] + tt;
+      y[2 + k] = v[2 + k];
+      lsum += log_s;
+      bad |= fz_not_finite(o[k]) | fz_not_finite(tt) | fz_not_finite(y[k]);
+    }
+    if (bad && a.flag) *a.flag = 1;
+    float z[4];
+    if (a.A) {
+#pragma unroll
+      for (int co = 0; co < 4; ++co) z[co] = a.b[co];
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int co = 0; co < 4; ++co) z[co] = fmaf(y[ci], a.A[ci * 4 + co], z[co]);
+    } else {
+#pragma unroll
+      for (int co = 0; co < 4; ++co) z[co] = y[co];
+    }
+    *reinterpret_cast<float4*>(a.out + q * a.out_stride + a.out_off) = float4{z[0], z[1], z[2], z[3]};
+  }
+  if (a.logdet) {
+    double d = (double)lsum;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tot = red[0] + red[1] + red[2] + red[3];
+      // the fused workgroups' per-wave partials (32 pixels each) of this sample, in pixel order
+      const size_t i0 = (size_t)n * (hw / 32);
+      for (int x = 0; x < hw / 32; ++x) tot += a.ldpart[i0 + x];
+      a.logdet[n] += tot;
+    }
+  }
+}
+
 // plain per-pixel affine (ActNorm+1x1 of a step applied to a materialised tensor): test entry / first steps
 template <int C>
 __global__ __launch_bounds__(256) void k_affine(const float* __restrict__ in, int Q, const float* __restrict__ A,

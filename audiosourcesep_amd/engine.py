@@ -216,6 +216,11 @@ class GlowEngine:
     def workspace_bytes(self, n, with_grad=False):
         return int(self.lib.glowk_workspace_bytes(self.h, int(n), int(with_grad)))
 
+    @property
+    def fused_steps(self):
+        """Flow steps so far that ran as one fused network + coupling kernel (``glowk_fused_steps``)."""
+        return int(self.lib.glowk_fused_steps(self.h))
+
     def profile_begin(self):
         _lib.check(self.lib.glowk_profile_begin(self.h))
 

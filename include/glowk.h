@@ -206,6 +206,9 @@ typedef struct glowk_profile {
   int64_t net_launches[4];
 } glowk_profile;
 int glowk_profile_begin(glowk_handle* h);
+/* number of flow steps so far that ran as ONE kernel -- coupling network + affine coupling + next step's ActNorm / 1x1 fused
+ * (flow_glow.py:21-22 as a single launch) -- rather than as network kernel + coupling kernel */
+int64_t glowk_fused_steps(const glowk_handle* h);
 int glowk_profile_end(glowk_handle* h, glowk_profile* out);
 
 /* --- sub-bijectors, as exercised one by one by unittest_flow_models.py:124-186 --------------------- */

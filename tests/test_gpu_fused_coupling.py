@@ -1,0 +1,81 @@
+"""The coupling fused into the network kernel (k_net_h3s<..., MODE | 16> + k_couple_edge): one flow step =
+ONE heavy kernel at the 4-channel level.  Checked against the unfused launch form of the same arithmetic (k_net + k_couple, selected
+with GLOWK_NO_FUSE=1: the only difference is the order in which the nine taps of the edge rows and the log-det are added up) to a few
+units of fp32 rounding, against the fp64 oracle, and through inverse(forward(x)); over the geometries that exercise every branch:
+workgroups inside a tile (edge rows, halo exchange), a tile per workgroup, several tiles per workgroup, a ragged last workgroup."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from audiosourcesep_amd import _lib
+from audiosourcesep_amd.config import GlowConfig
+from audiosourcesep_amd.synthetic import synthetic_mel_tiles, calibrated_engine
+from oracle import glowref as R
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # name: (cfg, tiles) -- the batch is large enough for the one-workgroup-two-passes launch form (2 * workgroups > compute units)
+    "64x64_edges_4_wgs_per_tile": (GlowConfig(H=64, W=64, C=1, L=3, K=2, F=512), 160),
+    "96x64_edges_6_wgs_per_tile": (GlowConfig(H=96, W=64, C=1, L=3, K=2, F=512), 96),
+    "32x32_one_tile_per_wg": (GlowConfig(H=32, W=32, C=1, L=2, K=3, F=512), 300),
+    "16x16_four_tiles_per_wg_ragged": (GlowConfig(H=16, W=16, C=1, L=2, K=2, F=128), 1031),
+    "16x32_two_tiles_per_wg": (GlowConfig(H=16, W=32, C=1, L=2, K=2, F=256), 771),
+    "64x32_w16_edges": (GlowConfig(H=64, W=32, C=1, L=3, K=2, F=128), 301),
+}
+
+
+def _run(eng, x, fuse):
+    if fuse:
+        os.environ.pop("GLOWK_NO_FUSE", None)
+    else:
+        os.environ["GLOWK_NO_FUSE"] = "1"
+    try:
+        before = eng.fused_steps
+        lp, z = eng.log_prob(x, return_latent=True)
+        xr = eng.inverse(z)
+        torch.cuda.synchronize()
+        return lp, z, xr, eng.fused_steps - before
+    finally:
+        os.environ.pop("GLOWK_NO_FUSE", None)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("precision", ["f16x3", "f16x2"])
+def test_fused_step_equals_network_plus_coupling(name, precision):
+    cfg, n = CASES[name]
+    eng, params = calibrated_engine(cfg, device=0, init_tiles=32)
+    eng.set_precision({"f16x3": _lib.PREC_F16X3, "f16x2": _lib.PREC_F16X2}[precision])
+    eng.set_range_policy("error")
+    x = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=5)).cuda()
+    lp_f, z_f, xr_f, steps_f = _run(eng, x, True)
+    lp_u, z_u, xr_u, steps_u = _run(eng, x, False)
+    # the fused form ran: every step of the 4-channel level, in both directions; the unfused one did not
+    assert steps_f == 2 * cfg.K and steps_u == 0, (steps_f, steps_u)
+    assert torch.isfinite(lp_f).all()
+    # same arithmetic, different summation order in the edge rows and the log-det: fp32 rounding apart
+    rel = float(((lp_f - lp_u).abs() / lp_u.abs()).max())
+    dz = float((z_f - z_u).abs().max())
+    dx = float((xr_f - xr_u).abs().max())
+    print(name, precision, "fused vs unfused: log_prob rel %.1e, |dz| %.1e, |dx| %.1e dB" % (rel, dz, dx))
+    assert rel < 2e-6 and dz < (2e-4 if precision == "f16x3" else 1e-3) and dx < (5e-3 if precision == "f16x3" else 2e-2)
+    # inverse(forward(x)) = x through the fused kernels (f16x2 rounds activations to fp16: DESIGN section 5)
+    assert float((xr_f - x).abs().max()) < (0.02 if precision == "f16x3" else 0.3)
+    # repeatable bit for bit
+    lp2, z2, xr2, _ = _run(eng, x, True)
+    assert torch.equal(lp2, lp_f) and torch.equal(z2, z_f) and torch.equal(xr2, xr_f)
+    # batch independence: a window of the batch evaluated alone in the fused form gives the same tiles' results (workgroup
+    # boundaries fall elsewhere for the small tiles; to rounding only, because the DEEPER levels pick their launch form -- passes
+    # as workgroups or not -- by the grid size)
+    m = max(n * 3 // 4, 1)
+    lp_w, z_w, _, steps_w = _run(eng, x[:m].contiguous(), True)
+    assert steps_w == 2 * cfg.K
+    assert float(((lp_w - lp_f[:m]).abs() / lp_f[:m].abs()).max()) < 2e-6 and float((z_w - z_f[:m]).abs().max()) < 2e-4
+    if precision == "f16x3":
+        # against the fp64 oracle on a few tiles (the bar of the north star: 1e-4; fp32-class here)
+        idx = [0, n // 2, n - 1]
+        ref = R.log_prob(x[idx].cpu().numpy().astype(np.float64), R.cast_params(params, np.float64), cfg.as_dict())
+        np.testing.assert_allclose(lp_f[idx].cpu().numpy(), ref, rtol=2e-6)
+    assert eng.range_status() == (False, 0)
