@@ -81,6 +81,7 @@ struct glowk_handle {
   float *bufA = nullptr, *bufB = nullptr, *bufP = nullptr, *bufZ = nullptr, *bufC = nullptr;   // bufP: 4 partials, pstride apart
   size_t pstride = 0;
   double* bufLd = nullptr;
+  double* bufLdSlot = nullptr;  // [min(wsN, 2 CUs)][ld_slots_per_sample]
   double* bufStat = nullptr;    // [STAT_BLOCKS][32] partial sums + [32] means
   // input-gradient path: per-step saves of the forward pass (v, P, ReLU masks) and gradient scratch
   int saveN = 0;
@@ -227,8 +228,31 @@ int launch_net(glowk_handle* h, int level, int c, int F, const NetArgs& a, hipSt
     default: return fail("unsupported channel count " + std::to_string(c));                    \
   }
 
-int launch_couple(int c, const CoupleArgs& a, int N, hipStream_t s) {
+// light backward kernel of one step: 16 lanes per pixel where the batch is small and the level deep (few pixels, many channels and
+// partial buffers: the gathers' dependent loads are what the launch waits for), else 4
+int launch_bwd_light(int c, const BwdArgs& a, int N, hipStream_t s) {
+  const bool wide = c >= 8 && (a.Q + 15) / 16 <= 8 * num_cus() && !getenv("GLOWK_BWD_LIGHT_4");
+  if (wide) { CDISPATCH(c, hipLaunchKernelGGL((k_bwd_light<CC, 16>), dim3((a.Q + 15) / 16), dim3(256), 0, s, a)); }
+  else { CDISPATCH(c, hipLaunchKernelGGL((k_bwd_light<CC, 4>), dim3((a.Q + 63) / 64), dim3(256), 0, s, a)); }
+  LAUNCHCHK("k_bwd_light");
+  return 0;
+}
+
+// log-det slots of the flat-grid coupling kernel (k_couple_flat): slot[n * stride + base + workgroup within the sample]
+struct FlatLd { double* slot; int stride, base; };
+
+int launch_couple(int c, const CoupleArgs& a, int N, hipStream_t s, const FlatLd* fl = nullptr, bool* flat_used = nullptr) {
   const int hw = a.h * a.w;
+  if (N < 2 * num_cus() && hw % 64 == 0 && (!a.logdet || (fl && fl->slot)) && !getenv("GLOWK_COUPLE_PER_SAMPLE")) {
+    // few samples: a flat grid over the pixels instead of one workgroup per sample (30 tiles: 30 workgroups on 256 CUs)
+    CoupleArgs b = a;
+    b.logdet = nullptr;
+    CDISPATCH(c, hipLaunchKernelGGL((k_couple_flat<CC>), dim3((a.Q + 63) / 64), dim3(256), 0, s, b, a.logdet ? fl->slot : (double*)nullptr, hw / 64,
+                                    fl ? fl->stride : 0, fl ? fl->base : 0));
+    LAUNCHCHK("k_couple_flat");
+    if (flat_used && a.logdet) *flat_used = true;
+    return 0;
+  }
   if (N >= 2 * num_cus()) {   // enough per-sample workgroups to fill the chip: one lane per pixel
     CDISPATCH(c, hipLaunchKernelGGL((k_couple<CC, false>), dim3(N), dim3(256), 0, s, a));
   } else {                    // four lanes per pixel, up to 256 pixels in flight per sample
@@ -250,7 +274,8 @@ bool fuse_geometry_ok(int h, int w) {
   return hw >= 32 && hw < 256 && (hw & (hw - 1)) == 0;
 }
 
-int net_and_couple(glowk_handle* h, int lvl, int c, int F, NetArgs na, CoupleArgs ca, int N, hipStream_t s, int mode) {
+int net_and_couple(glowk_handle* h, int lvl, int c, int F, NetArgs na, CoupleArgs ca, int N, hipStream_t s, int mode, const FlatLd* fl = nullptr,
+                   bool* flat_used = nullptr) {
   const bool no_fuse = getenv("GLOWK_NO_FUSE") != nullptr;     // (A/B timing and the fused-vs-unfused parity test: read per call)
   const int hw = ca.h * ca.w;
   if (!no_fuse && c == 4 && (mode == 3 || mode == 6) && na.RSp && ca.vin && !ca.log_s_out && ca.out && na.in_stride == 4 &&
@@ -270,7 +295,7 @@ int net_and_couple(glowk_handle* h, int lvl, int c, int F, NetArgs na, CoupleArg
   if (int rc = launch_net(h, lvl, c, F, na, s, mode, &np)) return rc;
   if (np != 100) {
     ca.P = na.P; ca.np = np; ca.pstride = na.pstride;
-    return launch_couple(c, ca, N, s);
+    return launch_couple(c, ca, N, s, fl, flat_used);
   }
   ++h->fused_steps;
   if (hw > 256 || ca.logdet) {
@@ -292,12 +317,28 @@ PreArgs pre_args(const glowk_config& cfg) {
 // ---- device memory of a handle: ONE description of every buffer, used by the allocators and by glowk_workspace_bytes ----
 struct WsSizes {      // forward / inverse workspace for N tiles (bytes)
   size_t act, P, ld;  // bufA, bufB, bufZ (each) | bufP (4 partial per-tap buffers) | bufLd
-  size_t total() const { return 3 * act + P + ld; }
+  size_t slots;       // bufLdSlot: per-sample log-det slots of the flat-grid coupling kernel (small batches only)
+  size_t total() const { return 3 * act + P + ld + slots; }
 };
+// log-det slots per sample: one per flow step and 64 pixels of its level
+int ld_slots_per_sample(const glowk_handle* h) {
+  int n = 0;
+  for (const Level& lv : h->levels) n += h->cfg.K * ((lv.h * lv.w + 63) / 64);
+  return n;
+}
 WsSizes ws_sizes(const glowk_handle* h, size_t N) {
   const size_t E = (size_t)h->cfg.H * h->cfg.W * h->cfg.C;
-  return WsSizes{N * E * 4, 4 * 9 * N * E * 4, N * 8};
+  return WsSizes{N * E * 4, 4 * 9 * N * E * 4, N * 8, std::min(N, (size_t)2 * num_cus()) * ld_slots_per_sample(h) * 8};
 }
+// pixel blocks of the ReLU-mask arrays of a level with Q pixels (one 16-bit entry per lane, hidden block and pixel block of a wave):
+// 32-pixel blocks of whole 256-pixel workgroups -- or 16-pixel blocks of 128-pixel workgroups where the launch policy may pick the
+// half-wave form of the 16x16x32 family (glowk_launch.h: use_half -- small grids, and the 32-channel level at any size)
+size_t mask_blocks(const Level& lv, size_t Q) {
+  const size_t b256 = ((Q + 255) / 256) * 8;
+  if (lv.c == 32 || (Q + 255) / 256 * 8 <= (size_t)num_cus()) return std::max(b256, ((Q + 127) / 128) * 8);
+  return b256;
+}
+
 struct SaveSizes {    // input-gradient path for N tiles: per-step saves + scratch
   size_t v, p, m;     // floats of saveV, floats of ONE partial of saveP, shorts of saveM
   int np;             // partials of saveP
@@ -313,7 +354,7 @@ SaveSizes save_sizes(const glowk_handle* h, size_t N, std::vector<size_t>* offV 
   for (int lvl = 0; lvl < L; ++lvl) {
     const Level& lv = h->levels[lvl];
     const size_t Q = N * lv.h * lv.w;
-    const size_t blocks = ((Q + 255) / 256) * 8;
+    const size_t blocks = mask_blocks(lv, Q);
     for (int j = 0; j < K; ++j) {
       const size_t sidx = (size_t)lvl * K + j;
       if (offV) { (*offV)[sidx] = S.v; (*offP)[sidx] = S.p; (*offM)[sidx] = S.m; }
@@ -352,8 +393,8 @@ int ensure_ws(glowk_handle* h, int N) {
   if (int rc = ensure_flag(h)) return rc;
   if (N <= h->wsN) return 0;
   HIPCHK(hipDeviceSynchronize());
-  if (h->bufA) { hipFree(h->bufA); hipFree(h->bufB); hipFree(h->bufP); hipFree(h->bufZ); hipFree(h->bufLd); }
-  h->bufA = h->bufB = h->bufP = h->bufZ = nullptr; h->bufLd = nullptr; h->wsN = 0;
+  if (h->bufA) { hipFree(h->bufA); hipFree(h->bufB); hipFree(h->bufP); hipFree(h->bufZ); hipFree(h->bufLd); hipFree(h->bufLdSlot); }
+  h->bufA = h->bufB = h->bufP = h->bufZ = nullptr; h->bufLd = nullptr; h->bufLdSlot = nullptr; h->wsN = 0;
   const WsSizes W = ws_sizes(h, (size_t)N);
   HIPCHK(hipMalloc(&h->bufA, W.act));
   HIPCHK(hipMalloc(&h->bufB, W.act));
@@ -361,6 +402,7 @@ int ensure_ws(glowk_handle* h, int N) {
   HIPCHK(hipMalloc(&h->bufP, W.P));
   HIPCHK(hipMalloc(&h->bufZ, W.act));
   HIPCHK(hipMalloc(&h->bufLd, W.ld));
+  HIPCHK(hipMalloc(&h->bufLdSlot, W.slots));
   h->wsN = N;
   return 0;
 }
@@ -445,6 +487,12 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
   const int K = cfg.K, L = cfg.L, NF = cfg.F / 32;
   float* cur = save ? h->saveV + h->offV[0] : h->bufA;
   float* oth = h->bufB;
+  // small batches: the coupling kernels run on a flat pixel grid and leave their log-det shares in per-workgroup slots (k_couple_flat)
+  const int nslots = ld_slots_per_sample(h);
+  const bool flat_ok = N < 2 * num_cus() && h->bufLdSlot;
+  bool flat_used = false;
+  int slot_base = 0;
+  if (flat_ok) HIPCHK(hipMemsetAsync(h->bufLdSlot, 0, (size_t)N * nslots * 8, s));
   {
     const Level& lv = h->levels[0];
     const StepDev& first = lv.dev[K - 1];
@@ -455,7 +503,7 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
   for (int lvl = 0; lvl < L; ++lvl) {
     const Level& lv = h->levels[lvl];
     const size_t Q = (size_t)N * lv.h * lv.w;
-    const size_t blocks = ((Q + 255) / 256) * 8;
+    const size_t blocks = mask_blocks(lv, Q);
     for (int k = K - 1; k >= 0; --k) {   // tfb.Chain applies right to left: step K-1 first (flow_glow.py:51-52)
       const StepDev& sd = lv.dev[k];
       const size_t sidx = (size_t)lvl * K + (K - 1 - k);
@@ -490,8 +538,10 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
       } else {
         ca.A = nullptr; ca.b = nullptr; ca.out = z_dst; ca.out_stride = h->Cl; ca.out_off = lv.z_off;
       }
-      if (plain) { if (int rc = net_and_couple(h, lvl, lv.c, cfg.F, na, ca, N, s, fwd_mode(h))) return rc; }
-      else if (int rc = launch_couple(lv.c, ca, N, s)) return rc;
+      const FlatLd fl{flat_ok ? h->bufLdSlot : nullptr, nslots, slot_base};
+      slot_base += (lv.h * lv.w + 63) / 64;
+      if (plain) { if (int rc = net_and_couple(h, lvl, lv.c, cfg.F, na, ca, N, s, fwd_mode(h), &fl, &flat_used)) return rc; }
+      else if (int rc = launch_couple(lv.c, ca, N, s, &fl, &flat_used)) return rc;
       if (k > 0) {
         if (save) cur = next; else std::swap(cur, oth);
       } else if (lvl < L - 1) {
@@ -505,6 +555,10 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
         if (!save) oth = (cur == h->bufA) ? h->bufB : h->bufA;
       }
     }
+  }
+  if (flat_used) {
+    hipLaunchKernelGGL(k_ld_fold, dim3(N), dim3(64), 0, s, h->bufLd, (const double*)h->bufLdSlot, nslots);
+    LAUNCHCHK("k_ld_fold");
   }
   return 0;
 }
@@ -779,7 +833,7 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
   for (int lvl = L - 1; lvl >= 0; --lvl) {
     const Level& lv = h->levels[lvl];
     const int Q = N * lv.h * lv.w;
-    const size_t blocks = (((size_t)Q + 255) / 256) * 8;
+    const size_t blocks = mask_blocks(lv, (size_t)Q);
     int npg = 1;                    // partials of Pg the previous network launch of this level left in bufP
     // split training sweep: g_o (and with it everything linear in it: the backward network, its stored hiddens, the im2col of g_o,
     // the weight-gradient GEMMs) is carried times a power of two sized on the previous sweep's gradient magnitudes
@@ -808,8 +862,7 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
         ba.A = lv.dev[k - 1].Afwd;
       }
       ba.gv_out = (tc && k > 0) ? h->trGv + (size_t)(k - 1) * go_slot : nullptr;
-      CDISPATCH(lv.c, hipLaunchKernelGGL((k_bwd_light<CC>), dim3((Q + 63) / 64), dim3(256), 0, s, ba));
-      LAUNCHCHK("k_bwd_light");
+      if (int rc = launch_bwd_light(lv.c, ba, N, s)) return rc;
       if (tc && k > 0 && !level_batch)   // g_v of step k-1 is complete: its ActNorm + 1x1 gradient sums
         if (int rc = train_affine_sums(h, lvl, k - 1, 1, h->saveV + h->offV[sidx + 1], 0, h->trGv, 0, N, s)) return rc;
       std::swap(gh_a, gh_b);   // gh_a now holds this step's [g_va, g_yb]
@@ -817,7 +870,7 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       na.K1p = sd.K3bp; na.R0p = sd.RBp; na.P = Pg;
       na.mask1 = h->saveM + h->offM[sidx];
       na.mask2 = na.mask1 + blocks * NF * 64;
-      const bool h3b = (tc ? tc->split : h->precision != GLOWK_PREC_F32) && sd.RHBp;
+      const bool h3b = (tc ? tc->split : h->precision != GLOWK_PREC_F32) && (sd.RHBp || (!tc && sd.RSBp));   // (c = 32: 16x16x32 image only)
       if (h3b) {
         na.RHp = sd.RHBp; na.RSp = sd.RSBp; na.eph = nullptr; na.sc1 = sd.scb1; na.sc2 = sd.scb2; na.sc3 = sd.scb3; na.xlim = sd.xlim_b;
         // the backward network is linear, so the kernels normalise every pixel's gradient vector to [T, 2T) (a power of two, exact;
@@ -855,8 +908,7 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       ba.A = lv.dev[K - 1].Afwd;
       ba.v = nullptr; ba.P = nullptr; ba.np = 1; ba.pstride = 0; ba.b3 = nullptr; ba.g_o = nullptr; ba.ghalf_out = nullptr; ba.gu_out = g_o;   // reuse g_o as g_u
       ba.gv_out = tc ? h->trGv + (size_t)(K - 1) * go_slot : nullptr;
-      CDISPATCH(lv.c, hipLaunchKernelGGL((k_bwd_light<CC>), dim3((Q + 63) / 64), dim3(256), 0, s, ba));
-      LAUNCHCHK("k_bwd_light");
+      if (int rc = launch_bwd_light(lv.c, ba, N, s)) return rc;
       if (tc && !level_batch)
         if (int rc = train_affine_sums(h, lvl, K - 1, 1, h->saveV + h->offV[(size_t)lvl * K], 0, h->trGv, 0, N, s)) return rc;
     }
@@ -1200,7 +1252,7 @@ int glowk_destroy(glowk_handle* h) {
     for (int* m : h->tr_map) if (m) hipFree(m);
     for (int* m : h->tr_map16) if (m) hipFree(m);
   }
-  if (h->bufA) { hipFree(h->bufA); hipFree(h->bufB); hipFree(h->bufP); hipFree(h->bufZ); hipFree(h->bufLd); }
+  if (h->bufA) { hipFree(h->bufA); hipFree(h->bufB); hipFree(h->bufP); hipFree(h->bufZ); hipFree(h->bufLd); hipFree(h->bufLdSlot); }
   if (h->bufC) hipFree(h->bufC);
   if (h->bufStat) hipFree(h->bufStat);
   if (h->saveV) { hipFree(h->saveV); hipFree(h->saveP); hipFree(h->saveM); hipFree(h->bufGz); }

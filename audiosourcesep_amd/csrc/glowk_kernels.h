@@ -1038,6 +1038,10 @@ template <int KIN, int MOUT, int NF, int MODE, int NP>
 struct RingS {
   static constexpr bool BWD = (MODE & 7) == NET_BWD;
   static constexpr bool FUSE = (MODE & 16) != 0;                   // coupling fused into the kernel (see fused_couple); plain forward modes only
+  static constexpr int PXH = (MODE & 32) ? 1 : 2;                  // 16-pixel halves per wave.  MODE | 32: ONE half -- a workgroup of 128 pixels with
+                                                                   // half the MFMAs and half the epilogue work per phase: for grids that leave CUs
+                                                                   // idle (latency per launch is what counts there) and for shapes whose small-conv
+                                                                   // fragments (KS k-steps x PXH halves x 2 registers x 4) need the room
   static constexpr int NFH = NF / NP;                             // hidden 32-channel blocks per pass
   static constexpr int NRB = 2 * NFH;                             // 16-row blocks per pass
   static constexpr int K1 = 9 * KIN;
@@ -1058,9 +1062,9 @@ struct RingS {
   static constexpr int EPN = (NF * 32 + 16 * NMT + 3) & ~3;       // conv2 accumulator init (F) | per-row constants of P
   static constexpr int MASK2B = BWD ? 2 * NF * 512 * 2 : 0;       // backward: both ReLU masks of the workgroup's 8 column blocks
   static constexpr size_t LDS_BYTES = (size_t)3 * MAIN4 * 16 + (size_t)2 * K14 * 16 + (size_t)EPN * 4 + MASK2B;
-  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && NFH >= 2 && KS <= (NP == 2 ? 3 : 5) && NGRP <= 3 &&
+  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NF % 4 == 0 && NFH >= 2 && KS <= (PXH == 1 ? (NP == 2 ? 5 : 9) : NP == 2 ? 3 : 5) && NGRP <= 3 &&
                                (NGRP == 1 || GT % TPC == 0) &&   // (chunks do not straddle groups)
-                               (!FUSE || (MOUT == 36 && NP == 2 && LDS_BYTES + (size_t)36 * FUSE_PSTR * 4 + 4096 + 128 <= 160 * 1024));
+                               (!FUSE || (MOUT == 36 && NP == 2 && PXH == 2 && LDS_BYTES + (size_t)36 * FUSE_PSTR * 4 + 4096 + 128 <= 160 * 1024));
   // image (one for every NP, laid out for NP = 2): conv1 operands of all blocks, then per half of the hidden width the main
   // chunks (NF row blocks) and the conv3 tiles of NF/2 hidden blocks, 16 tiles per chunk; a pass of NP = 4 reads its half
   static constexpr int K1TOT4 = NF * K14;
@@ -1090,7 +1094,7 @@ struct RingS {
 #ifdef GLOWK_NO_MERGE   // (A/B builds only, scripts/ab.py)
   static constexpr bool MERGE = false;
 #else
-  static constexpr bool MERGE = NP == 2 && NGRP == 1 && NMT <= 3 && ((MODE & 7) == NET_FWD || (MODE & 7) == NET_FWD2);
+  static constexpr bool MERGE = PXH == 2 && NP == 2 && NGRP == 1 && NMT <= 3 && ((MODE & 7) == NET_FWD || (MODE & 7) == NET_FWD2);
 #endif
 };
 
@@ -1152,7 +1156,7 @@ __device__ __forceinline__ void h3s_X(const NetArgs& a, const H3Ctx& c, int fi, 
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
+        for (int hf = 0; hf < G::PXH; ++hf)
           h1[rb][hf] = mfma3s<(MODE & 7) == NET_FWD2>(kf[(s * 2 + rb) * 2 + 0], kf[(s * 2 + rb) * 2 + 1], xh[s][hf], xl[s][hf], h1[rb][hf]);
   } else {
 #pragma unroll
@@ -1161,12 +1165,12 @@ __device__ __forceinline__ void h3s_X(const NetArgs& a, const H3Ctx& c, int fi, 
       for (int rb = 0; rb < 2; ++rb) {
         const h8 ah = k1[((s * 2 + rb) * 2 + 0) * 64], al = k1[((s * 2 + rb) * 2 + 1) * 64];
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) h1[rb][hf] = mfma3s<(MODE & 7) == NET_FWD2>(ah, al, xh[s][hf], xl[s][hf], h1[rb][hf]);
+        for (int hf = 0; hf < G::PXH; ++hf) h1[rb][hf] = mfma3s<(MODE & 7) == NET_FWD2>(ah, al, xh[s][hf], xl[s][hf], h1[rb][hf]);
       }
   }
   unsigned bits = 0;
 #pragma unroll
-  for (int hf = 0; hf < 2; ++hf) bits |= h3s_act<(MODE & 7)>(h1[0][hf], h1[1][hf], a.sc1, mask >> (8 * hf), bh[hf], bl[hf]) << (8 * hf);
+  for (int hf = 0; hf < G::PXH; ++hf) bits |= h3s_act<(MODE & 7)>(h1[0][hf], h1[1][hf], a.sc1, mask >> (8 * hf), bh[hf], bl[hf]) << (8 * hf);
   if ((MODE & 7) == NET_FWD_SAVE && PASS == 0 && c.wok) a.mask1[(c.wblk * NF + fi) * 64 + lane] = (unsigned short)bits;
 }
 
@@ -1212,19 +1216,19 @@ __device__ __forceinline__ void h3s_Y(const float4* slot, const h8 (&bh)[2], con
     __builtin_amdgcn_sched_barrier(0);
     const h8 (&af)[4] = A[gi & 1];
     acc2[o0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1], bh[0], acc2[o0][0], 0, 0, 0);
-    acc2[o0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1], bh[1], acc2[o0][1], 0, 0, 0);
+    if constexpr (G::PXH == 2) acc2[o0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1], bh[1], acc2[o0][1], 0, 0, 0);
     acc2[o1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[3], bh[0], acc2[o1][0], 0, 0, 0);
-    acc2[o1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[3], bh[1], acc2[o1][1], 0, 0, 0);
+    if constexpr (G::PXH == 2) acc2[o1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[3], bh[1], acc2[o1][1], 0, 0, 0);
     if ((MODE & 7) != NET_FWD2) {
       acc2[o0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bl[0], acc2[o0][0], 0, 0, 0);
-      acc2[o0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bl[1], acc2[o0][1], 0, 0, 0);
+      if constexpr (G::PXH == 2) acc2[o0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bl[1], acc2[o0][1], 0, 0, 0);
       acc2[o1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2], bl[0], acc2[o1][0], 0, 0, 0);
-      acc2[o1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2], bl[1], acc2[o1][1], 0, 0, 0);
+      if constexpr (G::PXH == 2) acc2[o1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2], bl[1], acc2[o1][1], 0, 0, 0);
     }
     acc2[o0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bh[0], acc2[o0][0], 0, 0, 0);
-    acc2[o0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bh[1], acc2[o0][1], 0, 0, 0);
+    if constexpr (G::PXH == 2) acc2[o0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bh[1], acc2[o0][1], 0, 0, 0);
     acc2[o1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2], bh[0], acc2[o1][0], 0, 0, 0);
-    acc2[o1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2], bh[1], acc2[o1][1], 0, 0, 0);
+    if constexpr (G::PXH == 2) acc2[o1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2], bh[1], acc2[o1][1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -1263,7 +1267,7 @@ __device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const fl
         unsigned mask = 0, bits = 0;
         if ((MODE & 7) == NET_BWD) mask = c.mkl[((size_t)(threadIdx.x >> 6) * NF + PASS * NFH + fo) * 64 + lane];   // mask1: the ReLU after conv1
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
+        for (int hf = 0; hf < G::PXH; ++hf)
           bits |= h3s_act<(MODE & 7)>(acc2[2 * fo][hf], acc2[2 * fo + 1][hf], a.sc2, mask >> (8 * hf), bh[hf], bl[hf]) << (8 * hf);
         if ((MODE & 7) == NET_FWD_SAVE && t < NFH * G::G0N && c.wok) a.mask2[(c.wblk * NF + PASS * NFH + fo) * 64 + lane] = (unsigned short)bits;
       }
@@ -1273,10 +1277,10 @@ __device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const fl
       }
       const h8 ah = buf[(tp * 2 + 0) * 64], al = buf[(tp * 2 + 1) * 64];
       acc3[ml][0] = mfma3s<(MODE & 7) == NET_FWD2>(ah, al, bh[0], bl[0], acc3[ml][0]);
-      acc3[ml][1] = mfma3s<(MODE & 7) == NET_FWD2>(ah, al, bh[1], bl[1], acc3[ml][1]);
+      if constexpr (G::PXH == 2) acc3[ml][1] = mfma3s<(MODE & 7) == NET_FWD2>(ah, al, bh[1], bl[1], acc3[ml][1]);
       if (fo == NFH - 1) {
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
+        for (int hf = 0; hf < G::PXH; ++hf)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = mt * 16 + 4 * kq + r;
@@ -1469,9 +1473,9 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
   const int g = wave >> 2;
   const int n16 = lane & 15;
   const int kq = lane >> 4;
-  const int qbase = (blockIdx.x * 8 + (tid >> 6)) * 32;
-  const int q[2] = {qbase + n16, qbase + 16 + n16};
-  const bool qok[2] = {q[0] < a.Q, q[1] < a.Q};
+  const int qbase = (blockIdx.x * 8 + (tid >> 6)) * (16 * G::PXH);
+  const int q[2] = {qbase + n16, G::PXH == 2 ? qbase + 16 + n16 : qbase + n16};
+  const bool qok[2] = {q[0] < a.Q, G::PXH == 2 && q[1] < a.Q};
 
   H3Ctx c;
   c.sA = slotA; c.sB = slotB; c.sD = slotD; c.k1s0 = k1slot0; c.k1s1 = k1slot1;
@@ -1480,8 +1484,8 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
   c.img = a.RSp;
   c.mkl = mkl;
   c.pl = plds;
-  c.wblk = (size_t)blockIdx.x * 8 + wave;
-  c.wok = (long)c.wblk * 32 < a.Q;
+  c.wblk = (size_t)blockIdx.x * 8 + wave;      // this wave's pixel block (16 PXH pixels): the unit of the ReLU-mask arrays
+  c.wok = (long)c.wblk * (16 * G::PXH) < a.Q;
   c.w4 = wave & 3;
   c.voff = (unsigned)lane * 16u;
   c.ub[0] = c.ub[1] = 1.0f;
@@ -1503,7 +1507,7 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
   {
     const int hw = a.h * a.w;
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
+    for (int hf = 0; hf < G::PXH; ++hf) {
       const int qq = qok[hf] ? q[hf] : 0;
       const int rem = qq % hw;
       const int i = rem / a.w, j0 = rem % a.w;

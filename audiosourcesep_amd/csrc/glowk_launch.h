@@ -5,6 +5,7 @@
 #pragma once
 #include "glowk_kernels.h"
 
+#include <cstdlib>
 #include <string>
 
 namespace glowk_detail {
@@ -77,6 +78,47 @@ int launch_h3s(const NetArgs& a, hipStream_t s, bool dry) {
   return 0;
 }
 
+// The 16x16x32 family with ONE 16-pixel half per wave (MODE | 32: 128-pixel workgroups, always four passes).  Twice the
+// workgroups at half the work per phase: chosen where the 256-pixel workgroups with their passes as workgroups of their own
+// still leave half the CUs idle (latency-bound grids: the deeper levels at the reference's batch sizes of 30 / 32 tiles), and for
+// shapes whose small-conv fragments only fit the registers at one half per wave (the 32-channel level's backward network: K = 288).
+inline bool half_wave_grid(const NetArgs& a) {
+  if (getenv("GLOWK_HALF_OFF")) return false;       // (A/B timing and diagnostics; read per launch decision)
+  return 8 * ((a.Q + 255) / 256) <= num_cus();
+}
+
+template <int KIN, int MOUT, int NF, int MODE>
+int launch_h3s_half(const NetArgs& a, hipStream_t s, bool dry) {
+  if constexpr (RingS<KIN, MOUT, NF, MODE | 32, 4>::FITS) {
+    if (a.max_np < 4) return 0;
+    const int wgs = (a.Q + 127) / 128;
+    if (!dry) {
+      if (4 * wgs <= num_cus()) hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE | 32, 4, true>), dim3(wgs, 4), dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE | 32, 4, false>), dim3(wgs), dim3(512), 0, s, a);
+    }
+    return 4;
+  }
+  return 0;
+}
+
+// the saving forward pass and the backward pass of a level must agree on the form (their ReLU-mask layouts differ: one entry per
+// pixel block of a wave): both have a half-wave instance
+template <int CI, int NF>
+constexpr bool half_ok() {
+  return RingS<CI, 18 * CI, NF, NET_FWD_SAVE | 32, 4>::FITS && RingS<2 * CI, 9 * CI, NF, NET_BWD | 32, 4>::FITS;
+}
+// ... and for this level the half-wave form is the ONLY split form of the gradient path (no 256-pixel instance of the backward network)
+template <int CI, int NF>
+constexpr bool half_only() {
+  return half_ok<CI, NF>() && !(RingS<2 * CI, 9 * CI, NF, NET_BWD, 2>::FITS || RingS<2 * CI, 9 * CI, NF, NET_BWD, 4>::FITS) &&
+         !(RingH<2 * CI, 9 * CI, NF, NET_BWD, 2>::FITS || RingH<2 * CI, 9 * CI, NF, NET_BWD, 4>::FITS);
+}
+template <int CI, int NF>
+inline bool use_half(const NetArgs& a) {
+  if constexpr (!half_ok<CI, NF>()) return false;
+  return a.fam16 && h3_shape16() && a.max_np >= 4 && (half_only<CI, NF>() || half_wave_grid(a));
+}
+
 // a level's saving forward pass and its backward pass run in ONE kernel family (their ReLU-mask layouts differ): the
 // 16x16x32 family if both have an instance that works whatever the batch size (NP = 4 if NP = 2 does not fit needs room
 // for four partial buffers, which the save buffers may not have)
@@ -112,7 +154,8 @@ int launch_net_t(const NetArgs& a, int mode, hipStream_t s, bool dry) {
       break;
     case 9:            if (!dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE, true>), dim3(ntiles), dim3(256), 0, s, a); break;   // saving forward pass that keeps its hiddens
     case 3:   // f16x3 arithmetic: forward / forward with saves / backward; shapes without an instance run the exact fp32 kernel
-      if (a.RSp && h3_shape16()) np = launch_h3s<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
+      if (a.RSp && h3_shape16() && half_wave_grid(a) && !a.fuse) np = launch_h3s_half<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
+      if (!np && a.RSp && h3_shape16()) np = launch_h3s<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
       if (!np && a.RHp) np = launch_h3<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
       if (!np && !dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a);
       break;
@@ -123,15 +166,17 @@ int launch_net_t(const NetArgs& a, int mode, hipStream_t s, bool dry) {
       if (!np && !dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a);
       break;
     case 4:
+      if (use_half<CI, NF>(a)) np = launch_h3s_half<CI, 18 * CI, NF, NET_FWD_SAVE>(a, s, dry);
       if constexpr (fam16_ok<CI, NF>()) {
-        if (a.fam16 && h3_shape16() && big_grid(a)) np = launch_h3s<CI, 18 * CI, NF, NET_FWD_SAVE>(a, s, dry);
+        if (!np && a.fam16 && h3_shape16() && big_grid(a)) np = launch_h3s<CI, 18 * CI, NF, NET_FWD_SAVE>(a, s, dry);
       }
       if (!np && a.RHp) np = launch_h3<CI, 18 * CI, NF, NET_FWD_SAVE>(a, s, dry);
       if (!np && !dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE>), dim3(ntiles), dim3(256), 0, s, a);
       break;
     case 5:
+      if (use_half<CI, NF>(a)) np = launch_h3s_half<2 * CI, 9 * CI, NF, NET_BWD>(a, s, dry);
       if constexpr (fam16_ok<CI, NF>()) {
-        if (a.fam16 && h3_shape16() && big_grid(a)) np = launch_h3s<2 * CI, 9 * CI, NF, NET_BWD>(a, s, dry);
+        if (!np && a.fam16 && h3_shape16() && big_grid(a)) np = launch_h3s<2 * CI, 9 * CI, NF, NET_BWD>(a, s, dry);
       }
       if (!np && a.RHp) np = launch_h3<2 * CI, 9 * CI, NF, NET_BWD>(a, s, dry);
       if (!np && !dry) hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD>), dim3(ntiles), dim3(256), 0, s, a);

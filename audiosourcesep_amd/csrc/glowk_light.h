@@ -166,10 +166,87 @@ __device__ __forceinline__ bool not_finite(float v) { return !(fabsf(v) <= 3.0e3
 // (flow_tfp_bijectors.py:134-148), per-sample log-det (:150-153), then the following per-pixel affine
 // QUAD: four lanes per pixel (small batches: the per-sample workgroups cannot fill the chip, so parallelism has to come from
 // inside the pixel); otherwise one lane per pixel (large batches: fewer, fully used lanes -- 47 vs 80 us at 1024 tiles)
+// one pixel of k_couple: gather the nine taps (QUAD: this lane's three, then the quad sum), bias, tanh / exp, coupling, the
+// following affine, store.  Returns the pixel's sum of log_s on the lane that finished it (lane 0 of a quad), 0 elsewhere.
+template <int C, bool QUAD>
+__device__ __forceinline__ float couple_pixel(const CoupleArgs& a, int q, int i, int j, bool live, int r4) {
+  constexpr int CI = C / 2;
+  float v[C], o[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) o[c] = 0.0f;
+#pragma unroll
+  for (int u = 0; u < (QUAD ? 3 : 9); ++u) {
+    const int tap = QUAD ? r4 + 4 * u : u;
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const int ii = i + dy, jj = j + dx;
+    if (tap < 9 && ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) {
+      const size_t off = (size_t)(tap * C) * a.Q + (q + dy * a.w + dx);
+#pragma unroll
+      for (int part = 0; part < 4; ++part)      // all partials' loads in flight together
+        if (part < a.np) {
+          const float* src = a.P + (size_t)part * a.pstride + off;
+#pragma unroll
+          for (int c = 0; c < C; ++c) o[c] += src[(size_t)c * a.Q];
+        }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    if (QUAD) {
+      o[c] += __shfl_xor(o[c], 1, 64);
+      o[c] += __shfl_xor(o[c], 2, 64);
+    }
+    o[c] += a.b3[c];
+  }
+  if (r4 != 0 || !live) return 0.0f;
+  if (a.flag) {
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < C; ++c) bad |= not_finite(o[c]);
+    if (bad) *a.flag = 1;
+  }
+  if (a.vin) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] = a.vin[(size_t)q * C + c];
+  }
+  float y[C];
+  float lsum = 0.0f;
+#pragma unroll
+  for (int k = 0; k < CI; ++k) {
+    const float log_s = tanhf(o[k]);
+    const float t = o[CI + k];
+    if (a.log_s_out) { a.log_s_out[(size_t)q * CI + k] = log_s; a.t_out[(size_t)q * CI + k] = t; }
+    if (a.vin) {
+      const float s = expf(log_s);
+      y[k] = a.inverse ? (v[k] - t) / s : s * v[k] + t;
+      y[CI + k] = v[CI + k];
+    }
+    lsum += log_s;
+  }
+  if (a.flag && a.vin) {
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < C; ++c) bad |= not_finite(y[c]);
+    if (bad) *a.flag = 1;
+  }
+  if (a.out) {
+    float* dst = a.out + (size_t)q * a.out_stride + a.out_off;
+    if (a.A) {
+      float z[C];
+      affine_cc<C>(a.A, a.b, y, z);
+#pragma unroll
+      for (int c = 0; c < C; ++c) dst[c] = z[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) dst[c] = y[c];
+    }
+  }
+  return lsum;
+}
+
 template <int C, bool QUAD>
 __global__ __launch_bounds__(1024) void k_couple(CoupleArgs a) {   // 256 .. 1024 threads
   __shared__ double red[16];
-  constexpr int CI = C / 2;
   const int n = blockIdx.x;
   const int hw = a.h * a.w;
   float lsum = 0.0f;
@@ -181,82 +258,41 @@ __global__ __launch_bounds__(1024) void k_couple(CoupleArgs a) {   // 256 .. 102
   for (int pp0 = QUAD ? threadIdx.x >> 2 : threadIdx.x; pp0 < (hw + qpb - 1) / qpb * qpb; pp0 += qpb) {
     const bool live = pp0 < hw;
     const int pp = live ? pp0 : hw - 1;
-    const int q = n * hw + pp;
-    const int i = pp / a.w, j = pp % a.w;
-    float v[C], o[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) o[c] = 0.0f;
-#pragma unroll
-    for (int u = 0; u < (QUAD ? 3 : 9); ++u) {
-      const int tap = QUAD ? r4 + 4 * u : u;
-      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-      const int ii = i + dy, jj = j + dx;
-      if (tap < 9 && ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) {
-        const size_t off = (size_t)(tap * C) * a.Q + (q + dy * a.w + dx);
-#pragma unroll
-        for (int part = 0; part < 4; ++part)      // all partials' loads in flight together
-          if (part < a.np) {
-            const float* src = a.P + (size_t)part * a.pstride + off;
-#pragma unroll
-            for (int c = 0; c < C; ++c) o[c] += src[(size_t)c * a.Q];
-          }
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      if (QUAD) {
-        o[c] += __shfl_xor(o[c], 1, 64);
-        o[c] += __shfl_xor(o[c], 2, 64);
-      }
-      o[c] += a.b3[c];
-    }
-    if (r4 != 0 || !live) continue;
-    if (a.flag) {
-      bool bad = false;
-#pragma unroll
-      for (int c = 0; c < C; ++c) bad |= not_finite(o[c]);
-      if (bad) *a.flag = 1;
-    }
-    if (a.vin) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) v[c] = a.vin[(size_t)q * C + c];
-    }
-    float y[C];
-#pragma unroll
-    for (int k = 0; k < CI; ++k) {
-      const float log_s = tanhf(o[k]);
-      const float t = o[CI + k];
-      if (a.log_s_out) { a.log_s_out[(size_t)q * CI + k] = log_s; a.t_out[(size_t)q * CI + k] = t; }
-      if (a.vin) {
-        const float s = expf(log_s);
-        y[k] = a.inverse ? (v[k] - t) / s : s * v[k] + t;
-        y[CI + k] = v[CI + k];
-      }
-      lsum += log_s;
-    }
-    if (a.flag && a.vin) {
-      bool bad = false;
-#pragma unroll
-      for (int c = 0; c < C; ++c) bad |= not_finite(y[c]);
-      if (bad) *a.flag = 1;
-    }
-    if (a.out) {
-      float* dst = a.out + (size_t)q * a.out_stride + a.out_off;
-      if (a.A) {
-        float z[C];
-        affine_cc<C>(a.A, a.b, y, z);
-#pragma unroll
-        for (int c = 0; c < C; ++c) dst[c] = z[c];
-      } else {
-#pragma unroll
-        for (int c = 0; c < C; ++c) dst[c] = y[c];
-      }
-    }
+    lsum += couple_pixel<C, QUAD>(a, n * hw + pp, pp / a.w, pp % a.w, live, r4);
   }
   if (a.logdet) {
     const double tot = block_sum_any((double)lsum, red);
     if (threadIdx.x == 0) a.logdet[n] += tot;
   }
+}
+
+// The same on a FLAT grid over the pixels (64 per workgroup, four lanes per pixel) for batches whose per-sample workgroups would
+// leave most CUs idle (the reference's 30 / 32 tiles): needs h w a multiple of 64, so that a workgroup's pixels belong to one
+// sample.  Its share of the sample's log-det goes to a slot of its own -- slot[n * sample_stride + slot_base + workgroup within the
+// sample]: no two workgroups add to one address, the order of the final sum (k_ld_fold) is fixed.
+template <int C>
+__global__ __launch_bounds__(256) void k_couple_flat(CoupleArgs a, double* slot, int wg_per_sample, int sample_stride, int slot_base) {
+  __shared__ double red[4];
+  const int hw = a.h * a.w;
+  const int q0 = (int)blockIdx.x * 64 + ((int)threadIdx.x >> 2);
+  const bool live = q0 < a.Q;
+  const int q = live ? q0 : a.Q - 1;
+  const int pp = q % hw;
+  const float lsum = couple_pixel<C, true>(a, q, pp / a.w, pp % a.w, live, threadIdx.x & 3);
+  if (slot) {
+    const double tot = block_sum_256((double)lsum, red);
+    if (threadIdx.x == 0) slot[(size_t)(blockIdx.x / wg_per_sample) * sample_stride + slot_base + blockIdx.x % wg_per_sample] = tot;
+  }
+}
+
+// logdet[n] += the sample's slots, in slot order (k_couple_flat)
+__global__ __launch_bounds__(64) void k_ld_fold(double* __restrict__ logdet, const double* __restrict__ slot, int nslots) {
+  const int n = blockIdx.x;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nslots; i += 64) acc += slot[(size_t)n * nslots + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if (threadIdx.x == 0) logdet[n] += acc;
 }
 
 // the rows the fused kernel could not finish (see fused_couple): one workgroup per sample.  Also adds the sample's log-det:
@@ -524,15 +560,18 @@ struct BwdArgs {
   unsigned* gmax;
 };
 
-template <int C>
+// LPP lanes per pixel: 4 (lane r gathers taps r, r + 4, r + 8 of every partial) or 16 -- the (tap, partial) pairs dealt round
+// robin -- for the deep levels at small batches: 64 pixels x 8 or 16 channels per sample leave a 4-lane kernel with ~200 dependent
+// loads per lane on a few dozen workgroups (15-16 us per launch at 30 tiles against a ~5 us floor)
+template <int C, int LPP>
 __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
   constexpr int CI = C / 2;
+  constexpr int PPB = 256 / LPP;     // pixels per workgroup
   const int hw = a.h * a.w;
-  // four lanes per pixel, as in k_couple: lane r of the quad gathers taps r, r + 4, r + 8 of both per-tap buffers (all their
-  // partials), the quad adds up, lane 0 does the per-pixel algebra.  Flat grid over the Q pixels (nothing is reduced per sample).
-  const int r4 = threadIdx.x & 3;
+  // Flat grid over the Q pixels (nothing is reduced per sample); lane 0 of a pixel's group does the per-pixel algebra.
+  const int r4 = threadIdx.x & (LPP - 1);
   {
-    const int q0 = (int)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int q0 = (int)blockIdx.x * PPB + ((int)threadIdx.x / LPP);
     const bool live = q0 < a.Q;
     const int q = live ? q0 : a.Q - 1;
     const int pp = q % hw;
@@ -540,6 +579,7 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
     float gsum[CI], o[CI];   // merged network gradient (second half of g_v); log_s half of the saved network output
 #pragma unroll
     for (int c = 0; c < CI; ++c) { gsum[c] = 0.0f; o[c] = 0.0f; }
+    if constexpr (LPP == 4) {
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int tap = r4 + 4 * u;
@@ -569,12 +609,37 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
         }
       }
     }
+    } else {
+      // (tap, partial) pairs dealt round robin over the pixel's LPP lanes: 9 * max(np, npg) pairs
+      const int npm = a.np > a.npg ? a.np : a.npg;
+      for (int idx = r4; idx < 9 * npm; idx += LPP) {
+        const int tap = idx / npm, part = idx % npm;
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        if (a.Pg && part < a.npg) {
+          const int ii = i - dy, jj = j - dx;
+          if (ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) {
+            const float* src = a.Pg + (size_t)part * a.pgstride + (size_t)(tap * CI) * a.Q + (q - dy * a.w - dx);
+#pragma unroll
+            for (int c = 0; c < CI; ++c) gsum[c] += src[(size_t)c * a.Q];
+          }
+        }
+        if (a.v && part < a.np) {
+          const int ii = i + dy, jj = j + dx;
+          if (ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) {
+            const float* src = a.P + (size_t)part * a.pstride + (size_t)(tap * C) * a.Q + (q + dy * a.w + dx);
+#pragma unroll
+            for (int c = 0; c < CI; ++c) o[c] += src[(size_t)c * a.Q];
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int c = 0; c < CI; ++c) {
-      gsum[c] += __shfl_xor(gsum[c], 1, 64);
-      gsum[c] += __shfl_xor(gsum[c], 2, 64);
-      o[c] += __shfl_xor(o[c], 1, 64);
-      o[c] += __shfl_xor(o[c], 2, 64);
+#pragma unroll
+      for (int m = 1; m < LPP; m <<= 1) {
+        gsum[c] += __shfl_xor(gsum[c], m, 64);
+        o[c] += __shfl_xor(o[c], m, 64);
+      }
     }
     float gomax = 0.0f;      // largest |g_o| this lane writes (unscaled)
     if (r4 == 0 && live) {

@@ -194,7 +194,7 @@ StepLayout step_layout(int c, int F) {
       L.RSp = o; o += fitsS ? (size_t)NF * KSS * 1024 + (size_t)2 * (NF + NCH) * NFH * 1024 : 0;
       // RingS<c, 9 CI, NF, bwd>: K = 9c in k-steps of 32, 9 CI output rows in blocks of 16
       const int KSSB = (9 * c + 31) / 32, NMSB = (9 * CI + 15) / 16, NCHB = (NFH * NMSB + 2 * NFH - 1) / (2 * NFH);
-      const bool fitsSB = fitsS && KSSB <= 5 && NMSB <= 12;
+      const bool fitsSB = fitsS && KSSB <= 9 && NMSB <= 12;     // (KSSB in 6..9: the half-wave form only, RingS<.., MODE | 32, 4>)
       L.slotSB = fitsSB ? (size_t)NFH * 1024 : 0;
       L.RSBp = o; o += fitsSB ? (size_t)NF * KSSB * 1024 + (size_t)2 * (NF + NCHB) * NFH * 1024 : 0;
     }
