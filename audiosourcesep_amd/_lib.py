@@ -86,6 +86,7 @@ SYMBOLS = {
     "glowk_sample": (_i, [_vp, _vp, _i, _vp, _vp]),
     "glowk_prior_log_prob": (_i, [_vp, _vp, _i, _vp, _vp]),
     "glowk_fused_steps": (ctypes.c_int64, [_vp]),
+    "glowk_kernel_families": (_i, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     "glowk_profile_begin": (_i, [_vp]),
     "glowk_profile_end": (_i, [_vp, ctypes.POINTER(GlowkProfile)]),
     "glowk_squeeze": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),

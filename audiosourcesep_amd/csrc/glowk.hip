@@ -62,6 +62,7 @@ struct glowk_handle {
   int precision = GLOWK_PREC_F32;
   int range_policy = GLOWK_RANGE_ERROR;
   int64_t range_fallbacks = 0;
+  int64_t family_launches[5] = {0, 0, 0, 0, 0};   // coupling-network launches by kernel family (glowk_launch.h: note_family)
   int64_t fused_steps = 0;      // flow steps that ran as ONE network + coupling kernel (net_and_couple)
   int* d_flag = nullptr;        // sticky range flag (device), written by k_couple / k_bwd_light
   int* h_flag = nullptr;        // pinned host word it is read back into
@@ -156,6 +157,8 @@ bool h3_shape16() {
   return v == 1;
 }
 void launch_fail(const std::string& m) { fail(m); }
+thread_local int g_family = 0;
+void note_family(int family) { g_family = family; }
 // instantiated in glowk_net_inst.hip, one translation unit per (CI, NF)
 #define GLOWK_EXTERN_NET(CI_, NF_) extern template int launch_net_t<CI_, NF_>(const NetArgs&, int, hipStream_t, bool);
 GLOWK_EXTERN_NET(2, 16) GLOWK_EXTERN_NET(4, 16) GLOWK_EXTERN_NET(8, 16) GLOWK_EXTERN_NET(16, 16)
@@ -187,6 +190,7 @@ float bwd_norm_target(float xlim_b) {
 }
 
 int launch_net_raw(int c, int F, const NetArgs& a, int mode, hipStream_t s, bool dry = false) {
+  glowk_detail::g_family = 0;     // (the fp32 kernels do not announce themselves)
 #define NETCASE(CI_, NF_) if (c == 2 * CI_ && F == 32 * NF_) return launch_net_t<CI_, NF_>(a, mode, s, dry);
   NETCASE(2, 16) NETCASE(4, 16) NETCASE(8, 16) NETCASE(16, 16)
   NETCASE(2, 12) NETCASE(4, 12) NETCASE(8, 12) NETCASE(16, 12)
@@ -201,6 +205,7 @@ int launch_net_raw(int c, int F, const NetArgs& a, int mode, hipStream_t s, bool
 int launch_net(glowk_handle* h, int level, int c, int F, const NetArgs& a, hipStream_t s, int mode = NET_FWD, int* np_out = nullptr) {
   if (!h->profiling) {
     const int np = launch_net_raw(c, F, a, mode, s);
+    if (np >= 0) ++h->family_launches[glowk_detail::g_family];
     if (np_out) *np_out = np;
     return np < 0 ? 1 : 0;
   }
@@ -212,6 +217,7 @@ int launch_net(glowk_handle* h, int level, int c, int F, const NetArgs& a, hipSt
   hipEvent_t e0 = h->ev_pool[h->ev_used], e1 = h->ev_pool[h->ev_used + 1];
   HIPCHK(hipEventRecord(e0, s));
   const int np = launch_net_raw(c, F, a, mode, s);
+  if (np >= 0) ++h->family_launches[glowk_detail::g_family];
   HIPCHK(hipEventRecord(e1, s));
   h->ev_used += 2;
   h->ev_level.push_back(level);
@@ -1716,6 +1722,12 @@ int glowk_prior_log_prob(glowk_handle* h, const float* z_dev, int N, float* logp
 }
 
 int64_t glowk_fused_steps(const glowk_handle* h) { return h ? h->fused_steps : -1; }
+
+int glowk_kernel_families(const glowk_handle* h, int64_t* out5) {
+  if (!h || !out5) return fail("null argument");
+  for (int i = 0; i < 5; ++i) out5[i] = h->family_launches[i];
+  return 0;
+}
 
 int glowk_profile_begin(glowk_handle* h) {
   if (!h) return fail("null handle");

@@ -11,6 +11,8 @@
 namespace glowk_detail {
 
 int num_cus();                          // compute units of the current device (queried once); glowk.hip
+void note_family(int family);           // which kernel family a (non-dry) launch took: 0 k_net_f32, 1 k_net_h3 (32x32x16), 2 k_net_h3s
+                                        // (16x16x32), 3 its half-wave form, 4 the fused network + coupling kernel; glowk.hip
 bool h3_shape16();                      // GLOWK_H3_SHAPE=32 keeps the forward pass on the 32x32x16 kernel (A/B timing); glowk.hip
 void launch_fail(const std::string&);   // sets glowk_last_error(); glowk.hip
 
@@ -28,6 +30,7 @@ int launch_h3(const NetArgs& a, hipStream_t s, bool dry) {
       if (!dry) {
         if (split) hipLaunchKernelGGL((k_net_h3<KIN, MOUT, NF, MODE, 4, true>), dim3(wgs, 4), dim3(512), 0, s, a);
         else hipLaunchKernelGGL((k_net_h3<KIN, MOUT, NF, MODE, 4, false>), dim3(wgs), dim3(512), 0, s, a);
+        note_family(1);
       }
       return 4;
     }
@@ -36,6 +39,7 @@ int launch_h3(const NetArgs& a, hipStream_t s, bool dry) {
     if (!dry) {
       if (2 * wgs <= cus) hipLaunchKernelGGL((k_net_h3<KIN, MOUT, NF, MODE, 2, true>), dim3(wgs, 2), dim3(512), 0, s, a);
       else hipLaunchKernelGGL((k_net_h3<KIN, MOUT, NF, MODE, 2, false>), dim3(wgs), dim3(512), 0, s, a);
+      note_family(1);
     }
     return 2;
   }
@@ -52,6 +56,7 @@ int launch_h3s(const NetArgs& a, hipStream_t s, bool dry) {
       if (!dry) {
         if (split) hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE, 4, true>), dim3(wgs, 4), dim3(512), 0, s, a);
         else hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE, 4, false>), dim3(wgs), dim3(512), 0, s, a);
+        note_family(2);
       }
       return 4;
     }
@@ -64,7 +69,7 @@ int launch_h3s(const NetArgs& a, hipStream_t s, bool dry) {
     if constexpr ((MODE == NET_FWD || MODE == NET_FWD2) && MOUT == 36) {
       if constexpr (RingS<KIN, MOUT, NF, MODE | 16, 2>::FITS && RingS<KIN, MOUT, NF, MODE | 16, 2>::MERGE) {
         if (a.fuse && !split) {
-          if (!dry) hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE | 16, 2, false>), dim3(wgs), dim3(512), 0, s, a);
+          if (!dry) { hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE | 16, 2, false>), dim3(wgs), dim3(512), 0, s, a); note_family(4); }
           return 100;
         }
       }
@@ -72,6 +77,7 @@ int launch_h3s(const NetArgs& a, hipStream_t s, bool dry) {
     if (!dry) {
       if (split) hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE, 2, true>), dim3(wgs, 2), dim3(512), 0, s, a);
       else hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE, 2, false>), dim3(wgs), dim3(512), 0, s, a);
+      note_family(2);
     }
     return (!split && RingS<KIN, MOUT, NF, MODE, 2>::MERGE) ? 1 : 2;     // (merged: the two passes' sums leave the kernel as one buffer)
   }
@@ -95,6 +101,7 @@ int launch_h3s_half(const NetArgs& a, hipStream_t s, bool dry) {
     if (!dry) {
       if (4 * wgs <= num_cus()) hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE | 32, 4, true>), dim3(wgs, 4), dim3(512), 0, s, a);
       else hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE | 32, 4, false>), dim3(wgs), dim3(512), 0, s, a);
+      note_family(3);
     }
     return 4;
   }

@@ -285,9 +285,30 @@ def test_input_gradient_four_levels_full_width():
     scale = np.abs(g_ref).max()
     for prec in (_lib.PREC_F32, _lib.PREC_F16X3):
         eng.set_precision(prec)
+        before = eng.kernel_families()
         lp, g = eng.log_prob_grad(dev(x))
+        fam = {k: v - before[k] for k, v in eng.kernel_families().items()}
         np.testing.assert_allclose(lp.cpu().numpy(), lp_ref, rtol=1e-6)
         assert float(np.abs(g.cpu().numpy() - g_ref).max() / scale) < 1e-3
+        if prec == _lib.PREC_F16X3:
+            # round 3: EVERY level of the gradient path on the split kernels -- the 32-channel level's saving forward pass and
+            # its K = 288 backward network through the half-wave form of the 16x16x32 family (one 16-pixel half per wave: nine
+            # k-steps of fragments fit the registers); not one launch of the exact fp32 kernel (4 levels x 2 steps x 2 directions)
+            assert fam["f32"] == 0 and sum(fam.values()) == 4 * 2 * 2 and fam["h3s_half"] >= 4, fam
+        else:
+            assert fam["f32"] == 16 and sum(fam.values()) == 16, fam
+    # a larger batch: the 32-channel level still has only its half-wave instances (whatever the grid), the others their usual forms
+    eng.set_precision(_lib.PREC_F16X3)
+    xm = dev(synthetic_mel_tiles(600, cfg, seed=22))
+    before = eng.kernel_families()
+    lpm, gm = eng.log_prob_grad(xm)
+    fam = {k: v - before[k] for k, v in eng.kernel_families().items()}
+    assert fam["f32"] == 0 and fam["h3s_half"] >= 4, fam
+    eng.set_precision(_lib.PREC_F32)
+    lpm32, gm32 = eng.log_prob_grad(xm)
+    np.testing.assert_allclose(lpm.cpu().numpy(), lpm32.cpu().numpy(), rtol=2e-6)
+    dgm = (gm - gm32).abs() / gm32.abs().max()
+    assert float(dgm.max()) < 2e-2 and float((dgm > 1e-3).float().mean()) < 5e-4       # (isolated ReLU flips tolerated, as in the fuzz)
     # plain forward: the last level (c = 32) on the 16x16x32 split kernel (four passes, three fused output groups), as
     # workgroups of their own (small grids) and inside one workgroup (4 x workgroups > CUs: more than 4096 of these tiles)
     eng.set_precision(_lib.PREC_F32)
