@@ -116,7 +116,7 @@ struct glowk_handle {
   std::vector<hipEvent_t> tr_events;     // [0] fork, [1 + lvl] join
   std::vector<float> tr_bfac;    // per level: power of two the split training sweep scales g_o by (BwdArgs::go_scale), adapted after every
                                  // sweep from the largest |g_o| it saw (dynamic gradient scaling); 1 until the first sweep has run
-  unsigned* tr_gmax = nullptr;   // [L] device: that maximum (float bits), per level
+  unsigned* tr_gmax = nullptr;   // [L][16] device: that maximum (float bits), per level, spread over 16 words
   float* h_gmax = nullptr;       // pinned host copy (read back with the sweep's one synchronisation)
   int trN = 0;
   float *trR1 = nullptr, *trR2 = nullptr, *trM1 = nullptr, *trM2 = nullptr, *trXcol = nullptr, *trGcol = nullptr, *trCpart = nullptr;
@@ -853,7 +853,7 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       const size_t sidx = (size_t)lvl * K + (K - 1 - k);
       BwdArgs ba;
       ba.Q = Q; ba.h = lv.h; ba.w = lv.w; ba.flag = flagp(h);
-      ba.go_scale = bfac; ba.pg_scale = 1.0f / bfac; ba.gmax = (tc && h->tr_gmax) ? h->tr_gmax + lvl : nullptr;
+      ba.go_scale = bfac; ba.pg_scale = 1.0f / bfac; ba.gmax = (tc && h->tr_gmax) ? h->tr_gmax + 16 * lvl : nullptr;
       ba.v = h->saveV + h->offV[sidx]; ba.P = h->saveP + h->offP[sidx]; ba.np = h->save_parts[sidx]; ba.pstride = h->save_pstride; ba.b3 = sd.b3;
       float* go_k = tc ? h->trGo + (size_t)k * go_slot : g_o;
       ba.g_o = go_k; ba.ghalf_out = gh_b; ba.gu_out = nullptr;
@@ -876,7 +876,7 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       na.K1p = sd.K3bp; na.R0p = sd.RBp; na.P = Pg;
       na.mask1 = h->saveM + h->offM[sidx];
       na.mask2 = na.mask1 + blocks * NF * 64;
-      const bool h3b = (tc ? tc->split : h->precision != GLOWK_PREC_F32) && (sd.RHBp || (!tc && sd.RSBp));   // (c = 32: 16x16x32 image only)
+      const bool h3b = (tc ? tc->split : h->precision != GLOWK_PREC_F32) && (sd.RHBp || sd.RSBp);   // (c = 32: 16x16x32 image only)
       if (h3b) {
         na.RHp = sd.RHBp; na.RSp = sd.RSBp; na.eph = nullptr; na.sc1 = sd.scb1; na.sc2 = sd.scb2; na.sc3 = sd.scb3; na.xlim = sd.xlim_b;
         // the backward network is linear, so the kernels normalise every pixel's gradient vector to [T, 2T) (a power of two, exact;
@@ -1581,7 +1581,7 @@ int glowk_range_probe_end(glowk_handle* h, float* fwd_ratio, float* bwd_ratio, v
       if (sd.xlim_f > 0.f) rf = std::max(rf, v[i] / sd.xlim_f);
       // (the backward kernels normalise their inputs per pixel: what can fail is the STATIC requirement 2 * 2^-4 <= xlim_b;
       //  reported as that ratio -- the recorded gradient magnitudes v[LK + i] no longer matter for the range)
-      if (sd.xlim_b > 0.f && v[LK + i] > 0.f) rb = std::max(rb, 0.125f / sd.xlim_b);
+      if (sd.xlim_b > 0.f && v[LK + i] > 0.f) rb = std::max(rb, getenv("GLOWK_PROBE_RAW_BWD") ? v[LK + i] / sd.xlim_b : 0.125f / sd.xlim_b);   // (raw: the training sweep's uniformly scaled inputs)
     }
   if (fwd_ratio) *fwd_ratio = rf;
   if (bwd_ratio) *bwd_ratio = rb;
@@ -1913,10 +1913,10 @@ static int param_grad_impl(glowk_handle* h, const float* x_dev, int N, float sca
   for (const Level& lv : h->levels) {
     if (!split) break;
     const StepDev& sd = lv.dev[0];
-    split = sd.RHp && sd.RHBp;
+    split = (sd.RHp && sd.RHBp) || (sd.RSp && sd.RSBp);
     if (split) {      // ... and the launch policy has an instance of both storing kernels for this level at this batch size
       NetArgs pf = net_args(h, lv, sd, nullptr, lv.c, lv.c / 2, N), pb = net_args(h, lv, sd, nullptr, lv.c, 0, N);
-      pb.RHp = sd.RHBp;
+      pb.RHp = sd.RHBp; pb.RSp = sd.RSBp;
       split = launch_net_raw(lv.c, h->cfg.F, pf, 10, nullptr, true) > 0 && launch_net_raw(lv.c, h->cfg.F, pb, 11, nullptr, true) > 0;
     }
   }
@@ -1938,11 +1938,11 @@ static int param_grad_impl(glowk_handle* h, const float* x_dev, int N, float sca
     LAUNCHCHK("k_prior_wgrad");
   }
   if (!h->tr_gmax) {
-    HIPCHK(hipMalloc(&h->tr_gmax, sizeof(unsigned) * 4));
-    HIPCHK(hipHostMalloc(&h->h_gmax, sizeof(float) * 4));
+    HIPCHK(hipMalloc(&h->tr_gmax, sizeof(unsigned) * 64));
+    HIPCHK(hipHostMalloc(&h->h_gmax, sizeof(float) * 64));
     h->tr_bfac.assign(4, 1.0f);
   }
-  HIPCHK(hipMemsetAsync(h->tr_gmax, 0, sizeof(unsigned) * 4, s));
+  HIPCHK(hipMemsetAsync(h->tr_gmax, 0, sizeof(unsigned) * 64, s));
   TrainCtx tc{grad_dev, scale, split};
   // (the input gradient falls out of the sweep as well; the trainer has no use for it: it lands in the block-level scratch,
   //  which is free again by the time the last kernel of the sweep writes it)
@@ -1952,7 +1952,7 @@ static int param_grad_impl(glowk_handle* h, const float* x_dev, int N, float sca
   std::vector<double> sums(steps * AFF_NOUT_MAX);
   HIPCHK(hipMemcpyAsync(sums.data(), h->trAffSum, sums.size() * 8, hipMemcpyDeviceToHost, s));
   if (split) HIPCHK(hipMemcpyAsync(h->h_flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(h->h_gmax, h->tr_gmax, sizeof(float) * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(h->h_gmax, h->tr_gmax, sizeof(float) * 64, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   if (split && h->h_flag[0]) {       // the range guard of the split arithmetic fired somewhere in the sweep: its gradients are not usable
     h->h_flag[0] = 0;
@@ -1962,15 +1962,18 @@ static int param_grad_impl(glowk_handle* h, const float* x_dev, int N, float sca
   }
   {
     // dynamic gradient scaling of the NEXT split sweep: per level, the power of two that puts this sweep's largest |g_o| a factor
-    // 16 below what the static bound of the level's backward networks admits (xlim_b, in units of GLOWK_ACT_SCALE * g_o) -- room
-    // for the gradients to grow 16x from one step to the next before a sweep has to be repeated on the exact kernels
-    const float* gm = h->h_gmax;
+    // 256 below what the static bound of the level's backward networks admits (xlim_b, in units of GLOWK_ACT_SCALE * g_o) -- room
+    // for the largest gradient entry (a heavy-tailed quantity: it moved 44x between two early Adamax steps of the benchmark model)
+    // to grow 256x from one step to the next before a sweep has to be repeated on the exact kernels
+    float gm[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int lvl = 0; lvl < cfg.L; ++lvl)
+      for (int i = 0; i < 16; ++i) gm[lvl] = h->h_gmax[16 * lvl + i] > gm[lvl] || !(h->h_gmax[16 * lvl + i] == h->h_gmax[16 * lvl + i]) ? h->h_gmax[16 * lvl + i] : gm[lvl];
     for (int lvl = 0; lvl < cfg.L; ++lvl) {
       float xl = 0.f;
       for (const StepDev& sd : h->levels[lvl].dev) xl = xl == 0.f ? sd.xlim_b : std::min(xl, sd.xlim_b);
       if (!(gm[lvl] > 0.f) || !(gm[lvl] < 3.0e38f) || !(xl > 0.f)) continue;
       int e = 0;
-      std::frexp(xl / 16.0f / ((float)GLOWK_ACT_SCALE * gm[lvl]), &e);
+      std::frexp(xl / 256.0f / ((float)GLOWK_ACT_SCALE * gm[lvl]), &e);
       h->tr_bfac[lvl] = std::ldexp(1.0f, std::max(-100, std::min(100, e - 1)));
     }
   }

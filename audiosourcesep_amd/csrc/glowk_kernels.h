@@ -636,7 +636,7 @@ __device__ __forceinline__ void h3_wait_barrier() {
 }
 
 struct H3Ctx;
-template <int MODE, int PASS> __device__ __forceinline__ void h3_x_end(const H3Ctx& c);
+template <int MODE, int PASS, int NSTV = 16> __device__ __forceinline__ void h3_x_end(const H3Ctx& c);
 
 struct H3Ctx {                      // wave-uniform pointers of the kernel (LDS arrays are distinct statics: see ring_slot)
   float4 *sA, *sB, *sD, *k1s0, *k1s1;
@@ -694,9 +694,9 @@ __device__ __forceinline__ unsigned h3_act(const f32x16& acc, float sc, unsigned
 // launch (MODE & 8) the block itself (16 planar stores): the wave's YOUNGEST memory operations -- everything the phase has to wait
 // for (the DMA requested during the previous Y) is older, and vmcnt counts in issue order, so the stores stay in flight instead of
 // exposing their write latency at every one of the 16 X phases
-template <int MODE, int PASS>
+template <int MODE, int PASS, int NSTV>
 __device__ __forceinline__ void h3_x_end(const H3Ctx& c) {
-  constexpr int NST = ((MODE & 8) ? 16 : 0) + (((MODE & 7) == NET_FWD_SAVE) ? 1 : 0);
+  constexpr int NST = ((MODE & 8) ? NSTV : 0) + (((MODE & 7) == NET_FWD_SAVE) ? 1 : 0);   // (NSTV: value stores of a training launch per X phase)
   if constexpr (NST != 0 && PASS == 0) {
     if (c.wok) {      // (a wave without a valid pixel issues no store: its youngest operations are the DMA)
       __builtin_amdgcn_s_waitcnt((NST & 15) | 0x0F70 | ((NST >> 4) << 14));   // vmcnt(NST)
@@ -1108,8 +1108,11 @@ __device__ __forceinline__ f32x4 mfma3s(const h8& ahi, const h8& alo, const h8& 
 
 // activation + split of one hidden block (two row blocks) of one pixel half -> the B fragment of the next contraction.
 // Forward: ReLU (returns the 8 decisions as bits j = 4 * row block + r); backward: pass where the forward ReLU was open.
-template <int MODE>
-__device__ __forceinline__ unsigned h3s_act(const f32x4& r0, const f32x4& r1, float sc, unsigned mask8, h8& bh, h8& bl) {
+// (ST: training -- the 8 values, in the scaled units they are split in, also go to a planar [F][Q] array: rows 4 kq + r of the two
+//  16-row blocks of the hidden block whose base is st_blk; st_lane = byte offset of (row 4 kq, this lane's pixel), st_row = bytes per row)
+template <int MODE, bool ST = false>
+__device__ __forceinline__ unsigned h3s_act(const f32x4& r0, const f32x4& r1, float sc, unsigned mask8, h8& bh, h8& bl, bool do_st = false,
+                                            float* st_blk = nullptr, unsigned st_lane = 0, unsigned st_row = 0) {
   float v[8];
   unsigned bits = 0;
 #pragma unroll
@@ -1123,6 +1126,16 @@ __device__ __forceinline__ unsigned h3s_act(const f32x4& r0, const f32x4& r1, fl
       else {
         v[j + e] = fmaxf(t[e], 0.0f);
         if (MODE == NET_FWD_SAVE) bits |= (av[e] > 0.0f ? 1u : 0u) << (j + e);
+      }
+    }
+  }
+  if constexpr (ST) {
+    if (do_st) {
+      const unsigned long long st_base = reinterpret_cast<unsigned long long>(st_blk);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned off = st_lane + (unsigned)((j >> 2) * 16 + (j & 3)) * st_row;
+        asm volatile("global_store_dword %0, %1, %2" GLOWK_ST_MOD ::"v"(off), "v"(v[j]), "s"(st_base) : "memory");
       }
     }
   }
@@ -1170,7 +1183,12 @@ __device__ __forceinline__ void h3s_X(const NetArgs& a, const H3Ctx& c, int fi, 
   }
   unsigned bits = 0;
 #pragma unroll
-  for (int hf = 0; hf < G::PXH; ++hf) bits |= h3s_act<(MODE & 7)>(h1[0][hf], h1[1][hf], a.sc1, mask >> (8 * hf), bh[hf], bl[hf]) << (8 * hf);
+  for (int hf = 0; hf < G::PXH; ++hf) {
+    const int stq = (int)c.wblk * (16 * G::PXH) + 16 * hf + (lane & 15);
+    bits |= h3s_act<(MODE & 7), (MODE & 8) != 0>(h1[0][hf], h1[1][hf], a.sc1, mask >> (8 * hf), bh[hf], bl[hf], (MODE & 8) && PASS == 0 && stq < a.Q,
+                                                 (MODE & 8) ? uniform_fptr(a.st1 + (size_t)fi * 32 * a.Q) : nullptr,
+                                                 ((unsigned)(4 * (lane >> 4)) * (unsigned)a.Q + (unsigned)stq) * 4u, (unsigned)a.Q * 4u) << (8 * hf);
+  }
   if ((MODE & 7) == NET_FWD_SAVE && PASS == 0 && c.wok) a.mask1[(c.wblk * NF + fi) * 64 + lane] = (unsigned short)bits;
 }
 
@@ -1268,7 +1286,9 @@ __device__ __forceinline__ void h3s_Z(const NetArgs& a, const H3Ctx& c, const fl
         if ((MODE & 7) == NET_BWD) mask = c.mkl[((size_t)(threadIdx.x >> 6) * NF + PASS * NFH + fo) * 64 + lane];   // mask1: the ReLU after conv1
 #pragma unroll
         for (int hf = 0; hf < G::PXH; ++hf)
-          bits |= h3s_act<(MODE & 7)>(acc2[2 * fo][hf], acc2[2 * fo + 1][hf], a.sc2, mask >> (8 * hf), bh[hf], bl[hf]) << (8 * hf);
+          bits |= h3s_act<(MODE & 7), (MODE & 8) != 0>(acc2[2 * fo][hf], acc2[2 * fo + 1][hf], a.sc2, mask >> (8 * hf), bh[hf], bl[hf], (MODE & 8) && qok[hf],
+                                                       (MODE & 8) ? uniform_fptr(a.st2 + (size_t)(PASS * NFH + fo) * 32 * a.Q) : nullptr,
+                                                       ((unsigned)(4 * kq) * (unsigned)a.Q + (unsigned)q[hf]) * 4u, (unsigned)a.Q * 4u) << (8 * hf);
         if ((MODE & 7) == NET_FWD_SAVE && t < NFH * G::G0N && c.wok) a.mask2[(c.wblk * NF + PASS * NFH + fo) * 64 + lane] = (unsigned short)bits;
       }
       if (fo == 0) {
@@ -1330,14 +1350,14 @@ __device__ __forceinline__ void h3s_pass(const NetArgs& a, const H3Ctx& c, const
 #pragma nounroll
   for (int i0 = 0; i0 < NF; i0 += 2) {
     h3s_X<KIN, MOUT, NF, MODE, NP, 0, PASS>(a, c, i0, xh, xl, lane, bh, bl);
-    h3_x_end<MODE, PASS>(c);
+    h3_x_end<MODE, PASS, 8 * G::PXH>(c);
     if (PASS >= 1 && !SOLO && G::NCH == 1 && i0 == 0 && !g)   // single output chunk: slot D of the previous pass is read until the phase before this one
       stage4<G::MAINP, 50>(G::out_chunk(c.img, PASS, 0), c.sD, c.w4, c.voff);
     h3s_Y<KIN, MOUT, NF, MODE, NP, 1>(P0 ? c.sB : c.sA, bh, bl, acc2, lane, g, true, G::main_chunk(c.img, PASS, i0 + 1), P0 ? c.sA : c.sB,
                          c.k1img + (size_t)((i0 + 2) % NF) * G::K14, c.k1s0, c.w4, c.voff);
     h3_barrier();
     h3s_X<KIN, MOUT, NF, MODE, NP, 1, PASS>(a, c, i0 + 1, xh, xl, lane, bh, bl);
-    h3_x_end<MODE, PASS>(c);
+    h3_x_end<MODE, PASS, 8 * G::PXH>(c);
     h3s_Y<KIN, MOUT, NF, MODE, NP, 2>(P0 ? c.sA : c.sB, bh, bl, acc2, lane, g, i0 + 2 < NF || G::NCH >= 2,
                          i0 + 2 < NF ? G::main_chunk(c.img, PASS, i0 + 2) : G::out_chunk(c.img, PASS, 1),
                          P0 ? c.sB : c.sA, c.k1img + (size_t)((i0 + 3) % NF) * G::K14, c.k1s1, c.w4, c.voff);
@@ -1466,6 +1486,8 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
   __shared__ float plds[G::FUSE ? 36 * FUSE_PSTR : 1];   // fused coupling: the workgroup's per-tap outputs
   __shared__ float4 vstash[G::FUSE ? 256 : 1];           // ... and its pixels' four input channels (coupling input)
   static_assert(!G::FUSE || (G::MERGE && !SPLIT && MOUT == 36), "the fused coupling needs both passes in one workgroup and a 4-channel level");
+  static_assert(!(MODE & 8) || G::PXH == 1, "hidden stores (training): half-wave form only -- with two pixel halves a wave whose second half lies "
+                                            "beyond Q would issue fewer stores than h3_x_end's counted wait assumes");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1524,7 +1546,7 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
         pm = fmaxf(pm, __shfl_xor(pm, 16, 64));
         pm = fmaxf(pm, __shfl_xor(pm, 32, 64));
         xmax = fmaxf(xmax, pm);
-        const float fac = pixel_norm(pm, a.bnorm, c.ub[hf]);
+        const float fac = (MODE & 8) ? 1.0f : pixel_norm(pm, a.bnorm, c.ub[hf]);     // (training: one scale per launch, BwdArgs::go_scale)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
 #pragma unroll
@@ -1551,7 +1573,7 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
   if ((MODE & 7) != NET_BWD)
     for (int i = tid; i < G::EPN; i += 512) epl[i] = a.eph[i];   // RingS::EPN <= RingH::EPN, same content
   // forward: the static bound; backward (normalised per pixel): only a non-finite gradient can leave the range
-  if (((MODE & 7) == NET_BWD ? !(xmax <= 3.0e38f) : xmax > a.xlim) && a.flag) *a.flag = 1;
+  if ((((MODE & 7) == NET_BWD && !(MODE & 8)) ? !(xmax <= 3.0e38f) : !(xmax <= a.xlim)) && a.flag) *a.flag = 1;
   if (a.xmax_out) range_probe(a.xmax_out, xmax);           // (diagnostic runs only: how far below the limit do the inputs stay?)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();

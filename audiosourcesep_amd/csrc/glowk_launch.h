@@ -120,6 +120,22 @@ constexpr bool half_only() {
   return half_ok<CI, NF>() && !(RingS<2 * CI, 9 * CI, NF, NET_BWD, 2>::FITS || RingS<2 * CI, 9 * CI, NF, NET_BWD, 4>::FITS) &&
          !(RingH<2 * CI, 9 * CI, NF, NET_BWD, 2>::FITS || RingH<2 * CI, 9 * CI, NF, NET_BWD, 4>::FITS);
 }
+// the same for the training sweep (MODE | 8: the launches also store their hidden tensors)
+template <int CI, int NF>
+constexpr bool half_train_ok() {
+  return RingS<CI, 18 * CI, NF, (NET_FWD_SAVE | 8) | 32, 4>::FITS && RingS<2 * CI, 9 * CI, NF, (NET_BWD | 8) | 32, 4>::FITS;
+}
+template <int CI, int NF>
+constexpr bool half_train_only() {
+  return half_train_ok<CI, NF>() && !((RingH<CI, 18 * CI, NF, (NET_FWD_SAVE | 8), 2>::FITS || RingH<CI, 18 * CI, NF, (NET_FWD_SAVE | 8), 4>::FITS) &&
+                                      (RingH<2 * CI, 9 * CI, NF, (NET_BWD | 8), 2>::FITS || RingH<2 * CI, 9 * CI, NF, (NET_BWD | 8), 4>::FITS));
+}
+template <int CI, int NF>
+inline bool use_half_train(const NetArgs& a) {
+  if constexpr (!half_train_ok<CI, NF>()) return false;
+  return a.fam16 && h3_shape16() && a.max_np >= 4 && (half_train_only<CI, NF>() || half_wave_grid(a));
+}
+
 template <int CI, int NF>
 inline bool use_half(const NetArgs& a) {
   if constexpr (!half_ok<CI, NF>()) return false;
@@ -152,11 +168,13 @@ int launch_net_t(const NetArgs& a, int mode, hipStream_t s, bool dry) {
     case 8:            if (!dry) hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD, true>), dim3(ntiles), dim3(256), 0, s, a); break;
     // training in the split arithmetic: the 32x32x16 family's saving forward and backward launches, storing their hiddens (MODE | 8)
     case 10:   // (dry: returns 0 when the shape has no instance -- glowk_param_grad asks before it chooses the arithmetic of the sweep)
-      if (a.RHp) np = launch_h3<CI, 18 * CI, NF, (NET_FWD_SAVE | 8)>(a, s, dry);
+      if (use_half_train<CI, NF>(a)) np = launch_h3s_half<CI, 18 * CI, NF, (NET_FWD_SAVE | 8)>(a, s, dry);
+      if (!np && a.RHp) np = launch_h3<CI, 18 * CI, NF, (NET_FWD_SAVE | 8)>(a, s, dry);
       if (!np) { if (dry) return 0; launch_fail("no split-arithmetic training instance for this shape"); return -1; }
       break;
     case 11:
-      if (a.RHp) np = launch_h3<2 * CI, 9 * CI, NF, (NET_BWD | 8)>(a, s, dry);
+      if (use_half_train<CI, NF>(a)) np = launch_h3s_half<2 * CI, 9 * CI, NF, (NET_BWD | 8)>(a, s, dry);
+      if (!np && a.RHp) np = launch_h3<2 * CI, 9 * CI, NF, (NET_BWD | 8)>(a, s, dry);
       if (!np) { if (dry) return 0; launch_fail("no split-arithmetic training instance for this shape"); return -1; }
       break;
     case 9:            if (!dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE, true>), dim3(ntiles), dim3(256), 0, s, a); break;   // saving forward pass that keeps its hiddens

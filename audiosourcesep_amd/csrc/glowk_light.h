@@ -557,7 +557,7 @@ struct BwdArgs {
   // the per-tap network gradients Pg that come back carry it and are multiplied by `pg_scale` = 1 / go_scale here, and the
   // assembly of the weight gradients divides by it.  gmax (optional): atomic maximum of |g_o| (unscaled, float bits) per launch.
   float go_scale, pg_scale;
-  unsigned* gmax;
+  unsigned* gmax;          // [16] words per level (the workgroups spread their atomics over them)
 };
 
 // LPP lanes per pixel: 4 (lane r gathers taps r, r + 4, r + 8 of every partial) or 16 -- the (tap, partial) pairs dealt round
@@ -703,11 +703,19 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
       for (int c = 0; c < C; ++c) gu[c] = gy[c];
     }
     }
-    if (a.gmax) {            // (wave-uniform branch; every lane is here: idle ones carry 0)
+    if (a.gmax) {            // (uniform branch; every lane is here: idle ones carry 0)
+      // workgroup maximum first, then ONE atomic per workgroup, spread over 16 words (thousands of waves hammering one address
+      // serialise in the L2: the launch took 3x as long)
+      __shared__ float wmax[4];
       if (!(gomax == gomax)) gomax = __uint_as_float(0x7f800000u);     // NaN counts as "not finite"
 #pragma unroll
       for (int o2 = 32; o2 > 0; o2 >>= 1) gomax = fmaxf(gomax, __shfl_xor(gomax, o2, 64));
-      if ((threadIdx.x & 63) == 0 && gomax > 0.0f) atomicMax(a.gmax, __float_as_uint(gomax));
+      if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = gomax;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        if (m > 0.0f) atomicMax(a.gmax + (blockIdx.x & 15), __float_as_uint(m));
+      }
     }
   }
 }

@@ -226,12 +226,13 @@ def basis_workload(args, K, levels, train_steps, T, steps, warmup, rank, world, 
     from audiosourcesep_amd.flow_models.flow_builder import build_glow
     from audiosourcesep_amd.noise_conditioned import fine_tune_ladder, psnr_db, db_schedule
     f = np.load(os.path.join(ROOT, "tests", "golden", "basis_real_tiles.npz"))
-    gt1, gt2, mixed = (torch.from_numpy(f[k].astype(np.float32))[..., None].cuda() for k in ("gt1", "gt2", "mixed"))
+    crop = getattr(args, "basis_crop", 0) or 96
+    gt1, gt2, mixed = (torch.from_numpy(np.ascontiguousarray(f[k].astype(np.float32)[:, :crop]))[..., None].cuda() for k in ("gt1", "gt2", "mixed"))
     n = mixed.shape[0]
     t0 = time.perf_counter()
     priors, ladders, fb_train = [], [], []
     for i, gt in enumerate((gt1, gt2)):
-        flow = build_glow(gt, [96, 64, 1], L=3, K=K, n_filters=512, learntop=True, seed=100 + i, precision=precision, actnorm_init="runtime",
+        flow = build_glow(gt, [crop, 64, 1], L=3, K=K, n_filters=512, learntop=True, seed=100 + i, precision=precision, actnorm_init="runtime",
                           device=local_rank, data_type="melspec", minval=-100.0, maxval=20.0, use_logit=False)
         flow.engine.set_range_policy("fallback")
         sig_db, delta_db = db_schedule(flow.cfg, sigma1=0.3, sigmaL=0.01, num_classes=levels)
@@ -273,8 +274,8 @@ def basis_workload(args, K, levels, train_steps, T, steps, warmup, rank, world, 
     flop_step = 2 * 2 * cfg.flop_per_tile()     # two priors, forward + data gradient (2x forward FLOPs with stored hiddens)
     out = {
         "value": n * world * steps / el, "unit": "tile-steps/s", "ms_per_step": el / steps * 1e3, "dtype": precision, "steps": steps,
-        "config": {"workload": "BASIS Langevin steps, 2 trained noise-conditioned Glow priors, 96x64x1 real mel tiles (30 per GPU), L=3 K=%d "
-                               "n_filters=512, %d sigma levels x T=%d then %d timed consecutive steps at sigma_L" % (K, levels, T, steps)},
+        "config": {"workload": "BASIS Langevin steps, 2 trained noise-conditioned Glow priors, %dx64x1 real mel tiles (30 per GPU), L=3 K=%d "
+                               "n_filters=512, %d sigma levels x T=%d then %d timed consecutive steps at sigma_L" % (crop, K, levels, T, steps)},
         "roofline": {"bound": "mfma", "achieved": n * steps / el * flop_step / 1e12, "peak": PEAK_F16_MFMA_TFLOPS / 3.0 if precision != "f32" else PEAK_F32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "note": "2 priors x (forward + data gradient = 2x forward FLOP) per tile-step"},
         "range_guard": {"policy": "GLOWK_RANGE_ERROR on every chain step", "trips_or_fallbacks_in_chain": trips,
@@ -284,8 +285,8 @@ def basis_workload(args, K, levels, train_steps, T, steps, warmup, rank, world, 
                    "train_steps_per_level": [3 * train_steps] + [train_steps] * (levels - 1)},
         "chain": {"levels_x_T_s": t_chain, "tile_steps_per_s_whole_ladder": n * len(sig_db) * T / t_chain,
                   "psnr_db_start": start, "psnr_db_end": end,
-                  "psnr_db_reference_shipped_result": (psnr_db(f["x1"].astype(np.float32), f["gt1"].astype(np.float32)),
-                                                       psnr_db(f["x2"].astype(np.float32), f["gt2"].astype(np.float32)))},
+                  "psnr_db_reference_shipped_result": (psnr_db(f["x1"].astype(np.float32)[:, :crop], f["gt1"].astype(np.float32)[:, :crop]),
+                                                       psnr_db(f["x2"].astype(np.float32)[:, :crop], f["gt2"].astype(np.float32)[:, :crop]))},
     }
     out["roofline"]["frac"] = out["roofline"]["achieved"] / out["roofline"]["peak"]
     for e in engines:
@@ -378,6 +379,7 @@ def main():
     ap.add_argument("--basis-levels", type=int, default=4, help="--workload basis: sigma levels of the ladder (reference: 10)")
     ap.add_argument("--basis-train-steps", type=int, default=100, help="--workload basis: training steps per sigma level (3x at the first)")
     ap.add_argument("--basis-T", type=int, default=100, help="--workload basis: Langevin steps per sigma level before the timed region")
+    ap.add_argument("--basis-crop", type=int, default=0, help="--workload basis: use only the first N mel bins of the 96x64 tiles (64: the 64x64 geometry of config B)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the log_prob_grad / train / basis sub-objects of the N=1 default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-shapes", action="store_true", help="skip the config-A line inside the N=1 default run")

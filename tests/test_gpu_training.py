@@ -277,3 +277,34 @@ def test_split_training_steps_refresh_the_f16_images_on_the_device(cfg):
     _, g3 = other.param_grad(x, -1.0 / 24.0)                       # with the same history: bit for bit
     _, g4 = other.param_grad(x, -1.0 / 24.0)
     assert torch.equal(g3, g4)
+
+
+def test_four_level_training_sweep_runs_entirely_on_the_split_kernels():
+    """Round-2 verdict #7: the 32-channel level of 4-level flows (flow_glow.py:228-329; thesis table 3.4 trained an L = 4 flow) used to
+    send the WHOLE parameter-gradient sweep to the exact fp32 kernels -- its K = 288 backward network had no split instance.  Now
+    its saving forward and backward launches (with hidden stores) run the half-wave form of the 16x16x32 family: every gradient
+    tensor against the fp64 autograd of the oracle in f16x3, and not one launch of k_net_f32 (glowk_kernel_families)."""
+    cfg = GlowConfig(H=32, W=32, C=1, L=4, K=2, F=512)
+    eng, params = calibrated_engine(cfg, device=0, init_tiles=8)
+    x = synthetic_mel_tiles(5, cfg, seed=23)
+    scale = -1.0 / 32.0
+    lp_ref, ref = oracle_param_grads(x, params, cfg, scale)
+    eng.set_precision(_lib.PREC_F16X3)
+    eng.set_range_policy("error")
+    before = eng.kernel_families()
+    lp, got, flat = engine_grads(eng, params, x, scale)
+    fam = {k: v - before[k] for k, v in eng.kernel_families().items()}
+    assert fam["f32"] == 0 and sum(fam.values()) == 4 * 2 * 2 and fam["h3s_half"] >= 4, fam
+    np.testing.assert_allclose(lp, lp_ref, rtol=1e-6)
+    worst = 0.0
+    for k, r in ref.items():
+        denom = max(np.abs(r).max(), 1e-12)
+        worst = max(worst, float(np.abs(got[k] - r).max() / denom))
+        np.testing.assert_allclose(got[k], r, atol=2e-4 * denom, rtol=2e-3, err_msg=k)
+    print("L4 f16x3 sweep: worst |g - fp64| / max|g| over all tensors %.1e; launches by family %s" % (worst, fam))
+    # a few optimizer steps: the loss goes down, nothing falls back
+    flow = GlowFlow(eng)
+    xd = dev(x)
+    losses = [float(flow.train_step(xd, lr=2e-4)) for _ in range(6)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    assert eng.kernel_families()["f32"] == before["f32"] and eng.range_status() == (False, 0)
