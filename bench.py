@@ -515,10 +515,10 @@ def main():
             kernel, peak = "k_net_f32<CI=%d,NF=%d> (level 0)" % (c0 // 2, cfg.F // 32), PEAK_F32_MFMA_TFLOPS
             note = "fp32-input MFMA peak"
         elif precision == "f16x2":
-            kernel, peak = "k_net_h3s<CI=%d,NF=%d,two-term> (level 0)" % (c0 // 2, cfg.F // 32), PEAK_F16_MFMA_TFLOPS / 2.0
+            kernel, peak = "k_net_h3s<CI=%d,NF=%d,two-term%s> (level 0)" % (c0 // 2, cfg.F // 32, ", coupling fused in" if c0 == 4 else ""), PEAK_F16_MFMA_TFLOPS / 2.0
             note = "fp16 dense MFMA peak / 2 (two fp16 MFMAs per product)"
         else:
-            kernel, peak = "k_net_h3s<CI=%d,NF=%d> (level 0)" % (c0 // 2, cfg.F // 32), PEAK_F16_MFMA_TFLOPS / 3.0
+            kernel, peak = "k_net_h3s<CI=%d,NF=%d%s> (level 0)" % (c0 // 2, cfg.F // 32, ", coupling fused in" if c0 == 4 else ""), PEAK_F16_MFMA_TFLOPS / 3.0
             note = "fp16 dense MFMA peak / 3 (three fp16 MFMAs per fp32-equivalent product)"
         # HBM bytes per launch and MFMA-pipe busy fraction come from separate rocprofv3 --pmc passes of this same command
         # (scripts/final_run.sh, summarised by scripts/pmc_summary.py), committed under profiles/: NOT measured by this process -- the

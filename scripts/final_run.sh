@@ -1,32 +1,47 @@
 # The round's final measurements, all from ONE gpurun call on the final build (run from the repository root on the GPU box):
 #   bash scripts/final_run.sh <commit>
-# bench lines -> gpurun_out/r02_*.json, rocprofv3 --kernel-trace --stats summaries -> gpurun_out/r02_*_kernel_stats.csv,
-# PMC passes (counters in their own runs, --kernel-trace only) -> gpurun_out/r02_pmc_*/ ; copied into profiles/ afterwards.
+# bench lines -> gpurun_out/r03_*.json, rocprofv3 --kernel-trace --stats summaries -> gpurun_out/r03_*_kernel_stats.csv,
+# PMC passes (counters in their own runs, --kernel-trace only) -> summarised into gpurun_out/r03_*.json ; copied into profiles/ afterwards.
 set -e
 export TMPDIR=/tmp
 C=${1:-unknown}
 O=gpurun_out
 mkdir -p $O
-python bench.py > $O/r02_bench.json 2> $O/r02_bench.err
+python bench.py > $O/r03_bench.json 2> $O/r03_bench.err
 echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/r02_prof -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-shapes > $O/r02_bench_under_rocprof.json 2> $O/r02_prof.err
-cp $(find $O/r02_prof -name "*kernel_stats.csv" | head -1) $O/r02_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/r03_prof -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-shapes --no-secondary > $O/r03_bench_under_rocprof.json 2> $O/r03_prof.err
+cp $(find $O/r03_prof -name "*kernel_stats.csv" | head -1) $O/r03_kernel_stats.csv; rm -rf $O/r03_prof
 echo "kernel trace done"
 for p in f16x3 f32; do
-  python bench.py --workload log_prob_grad --precision $p --no-cpu-baseline > $O/r02_grad_$p.json 2>> $O/r02_bench.err
-  python bench.py --workload basis --batch 30 --steps 20 --warmup 3 --precision $p --no-cpu-baseline > $O/r02_basis_$p.json 2>> $O/r02_bench.err
+  python bench.py --workload log_prob_grad --precision $p --no-cpu-baseline > $O/r03_grad_$p.json 2>> $O/r03_bench.err
+  python bench.py --workload log_prob_grad --precision $p --batch 30 --steps 20 --warmup 3 --no-cpu-baseline > $O/r03_grad30_$p.json 2>> $O/r03_bench.err
+  for b in 32 256; do python bench.py --workload train --precision $p --batch $b --no-cpu-baseline > $O/r03_train_${p}_b$b.json 2>> $O/r03_bench.err; done
   echo "$p done"
 done
-for p in f16x3 f32; do for b in 32 256; do python bench.py --workload train --precision $p --batch $b --no-cpu-baseline > $O/r02_train_${p}_b$b.json 2>> $O/r02_bench.err; done; done
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/r02_prof_train -- python3 bench.py --workload train --precision f16x3 --batch 32 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>> $O/r02_prof.err
-cp $(find $O/r02_prof_train -name "*kernel_stats.csv" | head -1) $O/r02_train_kernel_stats.csv
-echo "train done"
-GLOWK_BENCH_REHEARSAL=1 python bench.py --gpus 2 --steps 3 --warmup 1 --batch 256 > $O/r02_bench_gpus2_rehearsal.json 2>> $O/r02_bench.err
+python bench.py --workload basis --steps 20 --warmup 3 > $O/r03_basis_f16x3.json 2>> $O/r03_bench.err
+python bench.py --workload basis --basis-crop 64 --steps 20 --warmup 3 > $O/r03_basis64_f16x3.json 2>> $O/r03_bench.err
+echo "basis done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/r03_prof_train -- python3 bench.py --workload train --precision f16x3 --batch 32 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>> $O/r03_prof.err
+cp $(find $O/r03_prof_train -name "*kernel_stats.csv" | head -1) $O/r03_train_kernel_stats.csv; rm -rf $O/r03_prof_train
+GLOWK_AB_N=30 GLOWK_GRAD=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r03_prof_small -- python3 scripts/small_batch.py > $O/r03_small_batch.log 2>> $O/r03_prof.err
+cp $(find $O/r03_prof_small -name "*kernel_stats.csv" | head -1) $O/r03_grad30_kernel_stats.csv; rm -rf $O/r03_prof_small
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/r03_prof_basis -- python3 bench.py --workload basis --basis-levels 3 --basis-train-steps 30 --basis-T 20 --steps 10 --warmup 2 > /dev/null 2>> $O/r03_prof.err
+cp $(find $O/r03_prof_basis -name "*kernel_stats.csv" | head -1) $O/r03_basis_kernel_stats.csv; rm -rf $O/r03_prof_basis
+echo "traces done"
+GLOWK_BENCH_REHEARSAL=1 python bench.py --gpus 2 --steps 3 --warmup 1 --batch 256 --no-secondary > $O/r03_bench_gpus2_rehearsal.json 2>> $O/r03_bench.err
+GLOWK_BENCH_FORCE_DIST=1 python bench.py --steps 3 --warmup 1 --batch 256 --no-secondary --no-cpu-baseline --no-other-shapes > $O/r03_bench_rccl_1rank.json 2>> $O/r03_bench.err
 echo "rehearsal done"
-B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-shapes"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/r02_pmc_fetch -- $B > /dev/null 2>> $O/r02_prof.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/r02_pmc_write -- $B > /dev/null 2>> $O/r02_prof.err
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/r02_pmc_mfma -- $B > /dev/null 2>> $O/r02_prof.err
-python scripts/pmc_summary.py traffic $(find $O/r02_pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/r02_pmc_write -name "*counter_collection.csv" | head -1) $C $O/r02_roofline_traffic.json > /dev/null
-python scripts/pmc_summary.py mfma $(find $O/r02_pmc_mfma -name "*counter_collection.csv" | head -1) $C $O/r02_mfma_utilisation.json > /dev/null
+B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-shapes --no-secondary"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/r03_pmc_fetch -- $B > /dev/null 2>> $O/r03_prof.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/r03_pmc_write -- $B > /dev/null 2>> $O/r03_prof.err
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/r03_pmc_mfma -- $B > /dev/null 2>> $O/r03_prof.err
+python scripts/pmc_summary.py traffic $(find $O/r03_pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/r03_pmc_write -name "*counter_collection.csv" | head -1) $C $O/r03_roofline_traffic.json > /dev/null
+python scripts/pmc_summary.py mfma $(find $O/r03_pmc_mfma -name "*counter_collection.csv" | head -1) $C $O/r03_mfma_utilisation.json > /dev/null
+rm -rf $O/r03_pmc_fetch $O/r03_pmc_write $O/r03_pmc_mfma
+export GLOWK_NO_FUSE=1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/r03_pmc_fetch_u -- $B > /dev/null 2>> $O/r03_prof.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/r03_pmc_write_u -- $B > /dev/null 2>> $O/r03_prof.err
+unset GLOWK_NO_FUSE
+python scripts/pmc_summary.py traffic $(find $O/r03_pmc_fetch_u -name "*counter_collection.csv" | head -1) $(find $O/r03_pmc_write_u -name "*counter_collection.csv" | head -1) $C $O/r03_roofline_traffic_unfused.json > /dev/null
+rm -rf $O/r03_pmc_fetch_u $O/r03_pmc_write_u
 echo "pmc done"

@@ -14,8 +14,10 @@ from collections import defaultdict
 
 LEVEL0 = {   # config B, level 0 (32x32x4 tensors, n_filters 512): the kernel each arithmetic runs there
     "k_net_f32": "void k_net_f32<2, 36, 16, 0, false>(NetArgs)",
-    "k_net_h3s": "void k_net_h3s<2, 36, 16, 0, 2, false>(NetArgs)",
-    "k_net_h3s_two_term": "void k_net_h3s<2, 36, 16, 3, 2, false>(NetArgs)",
+    "k_net_h3s": "void k_net_h3s<2, 36, 16, 16, 2, false>(NetArgs)",            # round 3: MODE | 16 = the coupling fused into the kernel
+    "k_net_h3s_two_term": "void k_net_h3s<2, 36, 16, 19, 2, false>(NetArgs)",
+    "k_net_h3s_unfused": "void k_net_h3s<2, 36, 16, 0, 2, false>(NetArgs)",      # (a GLOWK_NO_FUSE=1 pass, when the csv holds one)
+    "k_net_h3s_two_term_unfused": "void k_net_h3s<2, 36, 16, 3, 2, false>(NetArgs)",
 }
 
 
