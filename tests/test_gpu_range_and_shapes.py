@@ -261,3 +261,87 @@ def test_config_B_full_batch_parity():
     e16 = np.max(np.abs(lp16[:8].cpu().numpy() - ref) / np.abs(ref))
     print("config B, 8 tiles vs fp64 oracle: f32 %.2e, f16x3 %.2e" % (e32, e16))
     assert e32 < 1e-6 and e16 < 1e-6
+
+
+def test_backward_kernels_normalise_any_gradient_magnitude():
+    """Round 3: the split backward kernels scale every pixel's gradient vector by a power of two before the fp16
+    split (the backward network is linear), so no gradient MAGNITUDE can leave the range -- the round-2 static backward bound fired on
+    every call of a trained checkpoint.  A prior with tiny / huge scales makes the gradient wrt the latent 1e-8 ... 1e+8 times its
+    usual size: the f16x3 input gradient must agree with the exact fp32 kernels' to fp32 rounding at every magnitude, with no range
+    trip (policy "error"); a non-finite gradient is still reported."""
+    cfg = GlowConfig(H=32, W=32, C=1, L=3, K=2, F=512)
+    eng, params = calibrated_engine(cfg, device=0, init_tiles=16)
+    x = dev(synthetic_mel_tiles(40, cfg, seed=5))
+    base = np.asarray(params["prior/log_scale"], np.float32)
+    eng.set_range_policy("error")
+    for shift in (0.0, 9.0, -9.0, 4.0):        # prior sigma x e^shift: d log p / dz ~ e^(-2 shift) -> gradients 6e-9 ... 6e+7 of the usual
+        eng.set_tensor("prior/log_scale", base + np.float32(shift))
+        eng.finalize()
+        eng.set_precision(_lib.PREC_F32)
+        lp32, g32 = eng.log_prob_grad(x)
+        eng.set_precision(_lib.PREC_F16X3)
+        lp16, g16 = eng.log_prob_grad(x)              # raises GlowkRangeError if the guard fires
+        scale = float(g32.abs().max())
+        d = (g16 - g32).abs() / scale
+        # (a ReLU decided differently by the two arithmetics moves a few dozen entries of ONE tile by a fixed absolute amount -- which
+        #  is ~1e-3 of the maximum at the usual gradient scale and several times that where the prior's share of the gradient is tiny;
+        #  tolerated as everywhere: bounded size, and the typical tile is untouched)
+        assert float(d.max()) < 2e-2, (shift, scale, float(d.max()))
+        per_tile = (g16 - g32).flatten(1).norm(dim=1) / g32.flatten(1).norm(dim=1)
+        assert float(per_tile.median()) < 2e-6 and float((per_tile > 1e-4).float().mean()) < 0.3, (shift, per_tile)   # fp32-class, whatever the magnitude
+        np.testing.assert_allclose(lp16.cpu().numpy(), lp32.cpu().numpy(), rtol=2e-6)
+        print("prior sigma x e^%+.0f: max |g| %.2e, median per-tile |g16 - g32| / |g32| %.1e" % (shift, scale, float(per_tile.median())))
+    assert eng.range_status() == (False, 0)
+    # per-pixel: a batch whose tiles differ by 12 orders of magnitude in gradient size keeps every tile accurate
+    eng.set_tensor("prior/log_scale", base)
+    eng.finalize()
+    xs = x.clone()
+    xs[::2] = xs[::2] * 0.0 - 99.9               # constant tiles at the edge of the data range: very different gradient scale
+    eng.set_precision(_lib.PREC_F32)
+    _, g32 = eng.log_prob_grad(xs)
+    eng.set_precision(_lib.PREC_F16X3)
+    _, g16 = eng.log_prob_grad(xs)
+    per_tile = (g16 - g32).flatten(1).norm(dim=1) / g32.flatten(1).norm(dim=1)
+    assert float(per_tile.max()) < 5e-3 and float(per_tile.median()) < 2e-6, (float(per_tile.max()), float(per_tile.median()))
+    # a NaN input still trips
+    xb = x.clone()
+    xb[3, 5, 5, 0] = float("nan")
+    with pytest.raises(_lib.GlowkRangeError):
+        eng.log_prob_grad(xb)
+
+
+def test_training_sweep_recalibrates_its_gradient_scale():
+    """Dynamic gradient scaling of the split training sweep: the scale of g_o is sized on the previous sweep with a
+    256x headroom.  A jump of the gradient magnitude beyond that (here: the prior's sigma shrunk by e^-6 between two sweeps, gradients
+    ~1.6e5 times larger) makes ONE sweep fall back to the exact kernels -- counted, never silent -- and the next one runs split again
+    with the new scale; every gradient vector matches the exact sweep."""
+    cfg = GlowConfig(H=32, W=32, C=1, L=2, K=2, F=256)
+    eng, params = calibrated_engine(cfg, device=0, init_tiles=16)
+    x = dev(synthetic_mel_tiles(24, cfg, seed=8))
+    eng.set_precision(_lib.PREC_F16X3)
+    eng.set_range_policy("fallback")
+
+    def sweep():
+        fam0, fb0 = eng.kernel_families(), eng.range_status(sync=False)[1]
+        _, g = eng.param_grad(x, -1.0 / 24)
+        fam = eng.kernel_families()
+        return g.clone(), eng.range_status(sync=False)[1] - fb0, fam["f32"] - fam0["f32"]
+
+    g1, fb1, f32_1 = sweep()
+    g2, fb2, f32_2 = sweep()
+    assert fb1 == 0 and fb2 == 0 and f32_1 == 0 and f32_2 == 0
+    eng.set_precision(_lib.PREC_F32)
+    _, gx = eng.param_grad(x, -1.0 / 24)
+    assert float((g2 - gx).abs().max()) <= 5e-6 * float(gx.abs().max())
+    eng.set_tensor("prior/log_scale", np.asarray(params["prior/log_scale"], np.float32) - np.float32(6.0))
+    eng.finalize()
+    eng.set_precision(_lib.PREC_F16X3)
+    with pytest.warns(RuntimeWarning):
+        g3, fb3, f32_3 = sweep()                    # gradients ~1.6e5 x larger than the scale was sized for: repeated on the exact kernels
+    assert fb3 == 1 and f32_3 > 0
+    g4, fb4, f32_4 = sweep()                        # recalibrated: split again
+    assert fb4 == 0 and f32_4 == 0
+    eng.set_precision(_lib.PREC_F32)
+    _, gy = eng.param_grad(x, -1.0 / 24)
+    for g in (g3, g4):
+        assert float((g - gy).abs().max()) <= 5e-6 * float(gy.abs().max())
