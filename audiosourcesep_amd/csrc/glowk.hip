@@ -87,10 +87,8 @@ struct glowk_handle {
   // input-gradient path: per-step saves of the forward pass (v, P, ReLU masks) and gradient scratch
   int saveN = 0;
   size_t cN = 0;                // tiles bufC holds
-  float *saveV = nullptr, *saveP = nullptr, *bufGz = nullptr;   // saveP: save_np partials of every step's P, save_pstride apart
-  size_t save_pstride = 0;
-  int save_np = 1;
-  std::vector<int> save_parts;   // partials actually written per step by the last forward pass with saves
+  float *saveV = nullptr, *saveP = nullptr, *bufGz = nullptr;   // saveP: every step's pre-tanh log_s inputs [Q][c/2] (CoupleArgs::o_save); the per-tap
+                                                                // conv3 outputs P themselves are scratch (bufP) in the saving pass too
   unsigned short* saveM = nullptr;
   std::vector<size_t> offV, offP, offM;   // per forward-order step
   // training (glowk_param_grad / glowk_apply_gradients): device master copy of every parameter, optimizer state, scratch
@@ -346,8 +344,8 @@ size_t mask_blocks(const Level& lv, size_t Q) {
 }
 
 struct SaveSizes {    // input-gradient path for N tiles: per-step saves + scratch
-  size_t v, p, m;     // floats of saveV, floats of ONE partial of saveP, shorts of saveM
-  int np;             // partials of saveP
+  size_t v, p, m;     // floats of saveV, floats of saveP, shorts of saveM
+  int np;             // (1: kept for the size formula)
   size_t gz, c;       // bytes of bufGz, bufC
   size_t total() const { return v * 4 + (size_t)np * p * 4 + m * 2 + gz + c; }
 };
@@ -365,19 +363,8 @@ SaveSizes save_sizes(const glowk_handle* h, size_t N, std::vector<size_t>* offV 
       const size_t sidx = (size_t)lvl * K + j;
       if (offV) { (*offV)[sidx] = S.v; (*offP)[sidx] = S.p; (*offM)[sidx] = S.m; }
       S.v += Q * lv.c;
-      S.p += Q * lv.c * 9;
+      S.p += Q * (lv.c / 2);
       S.m += 2 * blocks * NF * 64;   // mask1 then mask2
-    }
-  }
-  // partial P buffers per step: as many as the saving forward launches of this batch size write in the handle's arithmetic
-  // (exact fp32: one; the split kernels: one per pass over the hidden width -- asked of the launch policy itself, dry)
-  if (h->precision != GLOWK_PREC_F32 && h->finalized) {
-    if (N <= 256) S.np = 4;        // small batches: room for the 4-pass launches whatever batch size below N comes later
-    glowk_handle* hm = const_cast<glowk_handle*>(h);
-    for (const Level& lv : h->levels) {
-      NetArgs probe = net_args(hm, lv, lv.dev[0], nullptr, lv.c, lv.c / 2, (int)N);
-      probe.max_np = 4;
-      S.np = std::max(S.np, launch_net_raw(lv.c, h->cfg.F, probe, 4, nullptr, true));
     }
   }
   const size_t E = (size_t)h->cfg.H * h->cfg.W * h->cfg.C;
@@ -468,18 +455,14 @@ NetArgs net_args(glowk_handle* h, const Level& lv, const StepDev& sd, const floa
 int ensure_save(glowk_handle* h, int N) {
   if (int rc = ensure_c(h, N)) return rc;
   const SaveSizes need = save_sizes(h, (size_t)N);
-  if (N <= h->saveN && need.np <= h->save_np) return 0;
+  if (N <= h->saveN) return 0;
   const int Na = std::max(N, h->saveN);
   HIPCHK(hipDeviceSynchronize());
   if (h->saveV) { hipFree(h->saveV); hipFree(h->saveP); hipFree(h->saveM); hipFree(h->bufGz); }
   h->saveV = h->saveP = h->bufGz = nullptr; h->saveM = nullptr; h->saveN = 0;
   SaveSizes S = save_sizes(h, (size_t)Na, &h->offV, &h->offP, &h->offM);
-  S.np = std::max(S.np, need.np);
   HIPCHK(hipMalloc(&h->saveV, S.v * 4));
-  h->save_np = S.np;
-  h->save_pstride = S.p;
-  h->save_parts.assign((size_t)h->cfg.L * h->cfg.K, 1);
-  HIPCHK(hipMalloc(&h->saveP, (size_t)S.np * S.p * 4));
+  HIPCHK(hipMalloc(&h->saveP, S.p * 4));
   HIPCHK(hipMalloc(&h->saveM, S.m * 2));
   HIPCHK(hipMalloc(&h->bufGz, S.gz));
   h->saveN = Na;
@@ -515,9 +498,6 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
       const size_t sidx = (size_t)lvl * K + (K - 1 - k);
       NetArgs na = net_args(h, lv, sd, cur, lv.c, lv.c / 2, N);
       if (save) {
-        na.P = h->saveP + h->offP[sidx];
-        na.pstride = h->save_pstride;
-        na.max_np = h->save_np;
         na.mask1 = h->saveM + h->offM[sidx];
         na.mask2 = na.mask1 + blocks * NF * 64;
       }
@@ -531,9 +511,9 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
         if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, keep_hidden ? (h->precision == GLOWK_PREC_F32 ? 9 : 10)
                                                               : (h->precision == GLOWK_PREC_F32 ? NET_FWD_SAVE : 4), &np)) return rc;
       }
-      if (save) h->save_parts[sidx] = np;
       CoupleArgs ca;
       ca.vin = cur; ca.P = na.P; ca.np = np; ca.pstride = na.pstride; ca.b3 = sd.b3; ca.logdet = h->bufLd; ca.log_s_out = nullptr; ca.t_out = nullptr;
+      ca.o_save = save ? h->saveP + h->offP[sidx] : nullptr;
       ca.Q = (int)Q; ca.h = lv.h; ca.w = lv.w; ca.inverse = 0; ca.flag = flagp(h);
       float* next = save && k > 0 ? h->saveV + h->offV[sidx + 1] : oth;
       if (k > 0) {
@@ -854,7 +834,7 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       BwdArgs ba;
       ba.Q = Q; ba.h = lv.h; ba.w = lv.w; ba.flag = flagp(h);
       ba.go_scale = bfac; ba.pg_scale = 1.0f / bfac; ba.gmax = (tc && h->tr_gmax) ? h->tr_gmax + 16 * lvl : nullptr;
-      ba.v = h->saveV + h->offV[sidx]; ba.P = h->saveP + h->offP[sidx]; ba.np = h->save_parts[sidx]; ba.pstride = h->save_pstride; ba.b3 = sd.b3;
+      ba.v = h->saveV + h->offV[sidx]; ba.osave = h->saveP + h->offP[sidx];
       float* go_k = tc ? h->trGo + (size_t)k * go_slot : g_o;
       ba.g_o = go_k; ba.ghalf_out = gh_b; ba.gu_out = nullptr;
       if (k == 0) {
@@ -912,7 +892,7 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       ba.go_scale = 1.0f; ba.pg_scale = 1.0f / bfac; ba.gmax = nullptr;
       ba.ghalf_in = gh_a; ba.Pg = Pg; ba.npg = npg; ba.pgstride = h->pstride; ba.gv_direct = nullptr; ba.gvd_stride = 0; ba.gvd_off = 0;
       ba.A = lv.dev[K - 1].Afwd;
-      ba.v = nullptr; ba.P = nullptr; ba.np = 1; ba.pstride = 0; ba.b3 = nullptr; ba.g_o = nullptr; ba.ghalf_out = nullptr; ba.gu_out = g_o;   // reuse g_o as g_u
+      ba.v = nullptr; ba.osave = nullptr; ba.g_o = nullptr; ba.ghalf_out = nullptr; ba.gu_out = g_o;   // reuse g_o as g_u
       ba.gv_out = tc ? h->trGv + (size_t)(K - 1) * go_slot : nullptr;
       if (int rc = launch_bwd_light(lv.c, ba, N, s)) return rc;
       if (tc && !level_batch)
@@ -957,7 +937,7 @@ int run_inverse(glowk_handle* h, const float* z, int N, float* x, hipStream_t s)
     for (int k = 0; k < K; ++k) {   // Chain.inverse: step 0 first
       const StepDev& sd = lv.dev[k];
       CoupleArgs ca;
-      ca.vin = cur; ca.P = h->bufP; ca.np = 1; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
+      ca.vin = cur; ca.P = h->bufP; ca.np = 1; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr; ca.o_save = nullptr;
       ca.Q = N * lv.h * lv.w; ca.h = lv.h; ca.w = lv.w; ca.inverse = 1; ca.flag = flagp(h);
       ca.A = sd.Ainv; ca.b = sd.binv; ca.out = oth; ca.out_stride = lv.c; ca.out_off = 0;
       if (int rc = net_and_couple(h, lvl, lv.c, cfg.F, net_args(h, lv, sd, cur, lv.c, lv.c / 2, N), ca, N, s, fwd_mode(h))) return rc;
@@ -1411,6 +1391,7 @@ int run_step_inplace(glowk_handle* h, int lvl, int k, float* cur, float* tmp, in
   NetArgs na = net_args(h, lv, sd, tmp, lv.c, lv.c / 2, Nl);
   if (int rc = launch_net(h, lvl, lv.c, h->cfg.F, na, s)) return rc;
   CoupleArgs ca;
+  ca.o_save = nullptr;
   ca.vin = tmp; ca.P = h->bufP; ca.np = 1; ca.pstride = 0; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
   ca.out = cur; ca.out_stride = lv.c; ca.out_off = 0;
   ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
@@ -1822,6 +1803,7 @@ int glowk_step_forward(glowk_handle* h, int level, int step, const float* u_dev,
       HIPCHK(hipStreamSynchronize(s));
     }
     CoupleArgs ca;
+    ca.o_save = nullptr;
     ca.vin = h->bufA; ca.P = h->bufP; ca.np = np; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
     ca.out = y_dev; ca.out_stride = lv.c; ca.out_off = 0;
     ca.logdet = logdet_dev ? h->bufLd : nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
@@ -1849,6 +1831,7 @@ int glowk_step_inverse(glowk_handle* h, int level, int step, const float* y_dev,
     int np = 1;
     if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, y_dev, lv.c, lv.c / 2, N), s, fwd_mode(h), &np)) return rc;
     CoupleArgs ca;
+    ca.o_save = nullptr;
     ca.vin = y_dev; ca.P = h->bufP; ca.np = np; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.A = sd.Ainv; ca.b = sd.binv;
     ca.out = u_dev; ca.out_stride = lv.c; ca.out_off = 0;
     ca.logdet = nullptr; ca.log_s_out = nullptr; ca.t_out = nullptr;
@@ -1870,6 +1853,7 @@ int glowk_coupling_net(glowk_handle* h, int level, int step, const float* xb_dev
     int np = 1;
     if (int rc = launch_net(h, level, lv.c, h->cfg.F, net_args(h, lv, sd, xb_dev, lv.c / 2, 0, N), s, fwd_mode(h), &np)) return rc;
     CoupleArgs ca;
+    ca.o_save = nullptr;
     ca.vin = nullptr; ca.P = h->bufP; ca.np = np; ca.pstride = h->pstride; ca.b3 = sd.b3; ca.A = nullptr; ca.b = nullptr;
     ca.out = nullptr; ca.out_stride = 0; ca.out_off = 0;
     ca.logdet = nullptr; ca.log_s_out = log_s_dev; ca.t_out = t_dev;

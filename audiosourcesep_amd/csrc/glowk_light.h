@@ -151,6 +151,8 @@ struct CoupleArgs {
   double* logdet;       // [N] += sum log_s (forward only; may be null)
   float* log_s_out;     // optional [Q][C/2] dumps of the network outputs (glowk_coupling_net)
   float* t_out;
+  float* o_save;        // saving pass (input-gradient / training): [Q][C/2] the pre-tanh log_s inputs (bias included) -- all the backward
+                        // pass needs of the network's output; the per-tap outputs P themselves are scratch and are not kept
   int Q, h, w;
   int inverse;
   int* flag;            // sticky range flag of the handle: set to 1 when a network output is not finite (may be null)
@@ -204,6 +206,10 @@ __device__ __forceinline__ float couple_pixel(const CoupleArgs& a, int q, int i,
 #pragma unroll
     for (int c = 0; c < C; ++c) bad |= not_finite(o[c]);
     if (bad) *a.flag = 1;
+  }
+  if (a.o_save) {
+#pragma unroll
+    for (int k = 0; k < CI; ++k) a.o_save[(size_t)q * CI + k] = o[k];
   }
   if (a.vin) {
 #pragma unroll
@@ -541,10 +547,7 @@ struct BwdArgs {
   const float* A;
   // (3) coupling backward of the step that produced y (forward order: the step before s), or none (v == null)
   const float* v;          // [Q][C] saved coupling input
-  const float* P;          // [9C][Q] saved per-tap conv3 outputs
-  int np;                  // number of partials of P (f16x3 forward kernel), >= 1
-  size_t pstride;
-  const float* b3;
+  const float* osave;      // [Q][C/2] saved pre-tanh log_s inputs of that coupling (CoupleArgs::o_save)
   float* g_o;              // [Q][C] gradient wrt the network output o = [pre-tanh log_s, t]
   float* ghalf_out;        // [Q][C] [g_va, g_yb]
   float* gu_out;           // [Q][C] g_y itself when no coupling follows
@@ -596,22 +599,10 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
             }
         }
       }
-      if (tap < 9 && a.v) {
-        const int ii = i + dy, jj = j + dx;
-        if (ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) {
-          const size_t po = (size_t)(tap * C) * a.Q + (q + dy * a.w + dx);
-#pragma unroll
-          for (int part = 0; part < 4; ++part)
-            if (part < a.np) {
-#pragma unroll
-              for (int c = 0; c < CI; ++c) o[c] += a.P[(size_t)part * a.pstride + po + (size_t)c * a.Q];
-            }
-        }
-      }
     }
     } else {
-      // (tap, partial) pairs dealt round robin over the pixel's LPP lanes: 9 * max(np, npg) pairs
-      const int npm = a.np > a.npg ? a.np : a.npg;
+      // (tap, partial) pairs dealt round robin over the pixel's LPP lanes: 9 * npg pairs
+      const int npm = a.npg;
       for (int idx = r4; idx < 9 * npm; idx += LPP) {
         const int tap = idx / npm, part = idx % npm;
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
@@ -623,23 +614,12 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
             for (int c = 0; c < CI; ++c) gsum[c] += src[(size_t)c * a.Q];
           }
         }
-        if (a.v && part < a.np) {
-          const int ii = i + dy, jj = j + dx;
-          if (ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) {
-            const float* src = a.P + (size_t)part * a.pstride + (size_t)(tap * C) * a.Q + (q + dy * a.w + dx);
-#pragma unroll
-            for (int c = 0; c < CI; ++c) o[c] += src[(size_t)c * a.Q];
-          }
-        }
       }
     }
 #pragma unroll
     for (int c = 0; c < CI; ++c) {
 #pragma unroll
-      for (int m = 1; m < LPP; m <<= 1) {
-        gsum[c] += __shfl_xor(gsum[c], m, 64);
-        o[c] += __shfl_xor(o[c], m, 64);
-      }
+      for (int m = 1; m < LPP; m <<= 1) gsum[c] += __shfl_xor(gsum[c], m, 64);
     }
     float gomax = 0.0f;      // largest |g_o| this lane writes (unscaled)
     if (r4 == 0 && live) {
@@ -680,7 +660,7 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
     }
     if (a.v) {
 #pragma unroll
-      for (int c = 0; c < CI; ++c) o[c] += a.b3[c];   // only the log_s half of the network output is needed
+      for (int c = 0; c < CI; ++c) o[c] = a.osave[(size_t)q * CI + c];   // only the log_s half of the network output is needed
       float* go = a.g_o + (size_t)q * C;
       float* gh = a.ghalf_out + (size_t)q * C;
 #pragma unroll

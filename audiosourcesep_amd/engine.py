@@ -180,9 +180,9 @@ class GlowEngine:
 
     @property
     def grad_max_tiles(self):
-        """Chunk of log_prob_grad.  The pass keeps every step's coupling input, per-tap conv3 outputs (one buffer per pass of
-        the split kernels) and ReLU masks until the backward sweep -- for 64x64, K=32, F=512: ~15 MB per tile in exact fp32,
-        ~23 MB with two partial buffers.  The chunk is the largest batch whose workspace + saves (``glowk_workspace_bytes``,
+        """Chunk of log_prob_grad.  The pass keeps every step's coupling input, the pre-tanh log_s inputs of its coupling and the
+        two ReLU masks of its network until the backward sweep -- for 64x64, K=32, F=512: ~7 MB per tile (until round 3 it kept
+        the per-tap conv3 outputs as well: 15-23 MB).  The chunk is the largest batch whose workspace + saves (``glowk_workspace_bytes``,
         the allocators' own arithmetic) fit a byte budget: min(60 % of the free HBM, GLOWK_GRAD_BUDGET_GB or 64 GiB); kernels
         saturate long before that."""
         if not self._finalized:
