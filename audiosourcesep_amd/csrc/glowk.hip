@@ -282,7 +282,7 @@ int net_and_couple(glowk_handle* h, int lvl, int c, int F, NetArgs na, CoupleArg
                    bool* flat_used = nullptr) {
   const bool no_fuse = getenv("GLOWK_NO_FUSE") != nullptr;     // (A/B timing and the fused-vs-unfused parity test: read per call)
   const int hw = ca.h * ca.w;
-  if (!no_fuse && c == 4 && (mode == 3 || mode == 6) && na.RSp && ca.vin && !ca.log_s_out && ca.out && na.in_stride == 4 &&
+  if (!no_fuse && c == 4 && (mode == 3 || mode == 6 || mode == 4) && na.RSp && ca.vin && !ca.log_s_out && ca.out && na.in_stride == 4 &&
       ca.out_stride % 4 == 0 && ca.out_off % 4 == 0 && fuse_geometry_ok(ca.h, ca.w) && na.P == h->bufP) {
     const size_t wgs = ((size_t)ca.Q + 255) / 256;
     const size_t edge_floats = (wgs * 4 * FUSE_EW * 4 + 3) & ~(size_t)3;
@@ -291,6 +291,7 @@ int net_and_couple(glowk_handle* h, int lvl, int c, int F, NetArgs na, CoupleArg
       na.fuse = 1;
       na.fz_b3 = ca.b3; na.fz_A = ca.A; na.fz_b = ca.b; na.fz_out = ca.out; na.fz_out_stride = ca.out_stride; na.fz_out_off = ca.out_off;
       na.fz_inverse = ca.inverse;
+      na.fz_osave = ca.o_save;
       na.fz_edge = h->bufP;
       na.fz_ldpart = ca.logdet ? reinterpret_cast<double*>(h->bufP + edge_floats) : nullptr;
     }
@@ -305,7 +306,7 @@ int net_and_couple(glowk_handle* h, int lvl, int c, int F, NetArgs na, CoupleArg
   if (hw > 256 || ca.logdet) {
     EdgeArgs ea;
     ea.vin = ca.vin; ea.edge = na.fz_edge; ea.ldpart = na.fz_ldpart; ea.A = ca.A; ea.b = ca.b; ea.out = ca.out; ea.out_stride = ca.out_stride;
-    ea.out_off = ca.out_off; ea.inverse = ca.inverse; ea.logdet = ca.logdet; ea.h = ca.h; ea.w = ca.w; ea.flag = ca.flag;
+    ea.out_off = ca.out_off; ea.inverse = ca.inverse; ea.logdet = ca.logdet; ea.osave = ca.o_save; ea.h = ca.h; ea.w = ca.w; ea.flag = ca.flag;
     hipLaunchKernelGGL(k_couple_edge, dim3(N), dim3(256), 0, s, ea);
     LAUNCHCHK("k_couple_edge");
   }
@@ -445,7 +446,7 @@ NetArgs net_args(glowk_handle* h, const Level& lv, const StepDev& sd, const floa
   a.RHp = sd.RHp; a.RSp = sd.RSp; a.fam16 = (sd.RSp && sd.RSBp) ? 1 : 0; a.eph = sd.epH; a.pstride = h->pstride; a.max_np = 4; a.sc1 = sd.sc1; a.sc2 = sd.sc2; a.sc3 = sd.sc3;
   a.flag = flagp(h); a.xlim = sd.xlim_f; a.st1 = nullptr; a.st2 = nullptr;
   a.bnorm = 1.0f;
-  a.fuse = 0; a.fz_b3 = nullptr; a.fz_A = nullptr; a.fz_b = nullptr; a.fz_out = nullptr; a.fz_out_stride = 0; a.fz_out_off = 0; a.fz_inverse = 0;
+  a.fuse = 0; a.fz_osave = nullptr; a.fz_b3 = nullptr; a.fz_A = nullptr; a.fz_b = nullptr; a.fz_out = nullptr; a.fz_out_stride = 0; a.fz_out_off = 0; a.fz_inverse = 0;
   a.fz_edge = nullptr; a.fz_ldpart = nullptr;
   a.xmax_out = h->d_probe ? h->d_probe + ((&lv - h->levels.data()) * h->cfg.K + (&sd - lv.dev.data())) : nullptr;
   return a;
@@ -506,10 +507,11 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
         na.st1 = h->trKeep + h->trKeepOff[sidx] * (size_t)N;
         na.st2 = na.st1 + (size_t)cfg.F * Q;
       }
-      const bool plain = !keep_hidden && !save;       // the plain forward direction: network + coupling may run as one kernel
+      // the plain forward direction and the saving pass of the split arithmetics: network + coupling may run as one kernel
+      const bool plain = !keep_hidden && (!save || h->precision != GLOWK_PREC_F32);
+      const int plain_mode = save ? 4 : fwd_mode(h);
       if (!plain) {
-        if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, keep_hidden ? (h->precision == GLOWK_PREC_F32 ? 9 : 10)
-                                                              : (h->precision == GLOWK_PREC_F32 ? NET_FWD_SAVE : 4), &np)) return rc;
+        if (int rc = launch_net(h, lvl, lv.c, cfg.F, na, s, keep_hidden ? (h->precision == GLOWK_PREC_F32 ? 9 : 10) : NET_FWD_SAVE, &np)) return rc;
       }
       CoupleArgs ca;
       ca.vin = cur; ca.P = na.P; ca.np = np; ca.pstride = na.pstride; ca.b3 = sd.b3; ca.logdet = h->bufLd; ca.log_s_out = nullptr; ca.t_out = nullptr;
@@ -526,7 +528,7 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
       }
       const FlatLd fl{flat_ok ? h->bufLdSlot : nullptr, nslots, slot_base};
       slot_base += (lv.h * lv.w + 63) / 64;
-      if (plain) { if (int rc = net_and_couple(h, lvl, lv.c, cfg.F, na, ca, N, s, fwd_mode(h), &fl, &flat_used)) return rc; }
+      if (plain) { if (int rc = net_and_couple(h, lvl, lv.c, cfg.F, na, ca, N, s, plain_mode, &fl, &flat_used)) return rc; }
       else if (int rc = launch_couple(lv.c, ca, N, s, &fl, &flat_used)) return rc;
       if (k > 0) {
         if (save) cur = next; else std::swap(cur, oth);

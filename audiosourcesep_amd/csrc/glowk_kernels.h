@@ -63,6 +63,7 @@ struct NetArgs {
   const float* fz_b;     // [C]
   float* fz_out;         // element (q, co) at fz_out[q * fz_out_stride + fz_out_off + co] (stride and offset multiples of 4)
   int fz_out_stride, fz_out_off, fz_inverse;
+  float* fz_osave;       // saving pass: [Q][2] the pre-tanh log_s inputs (CoupleArgs::o_save), or null
   float* fz_edge;        // [workgroup][4][64][4]: partial sums of its first / last pixel row, contributions to the rows above / below
   double* fz_ldpart;     // per workgroup (h w >= 256) or per sample: sum of log_s over the pixels completed in the kernel; or null
   unsigned* xmax_out;    // diagnostic (glowk_range_probe_begin), normally null: the largest gathered |input| (times GLOWK_ACT_SCALE) of
@@ -1094,7 +1095,9 @@ struct RingS {
 #ifdef GLOWK_NO_MERGE   // (A/B builds only, scripts/ab.py)
   static constexpr bool MERGE = false;
 #else
-  static constexpr bool MERGE = PXH == 2 && NP == 2 && NGRP == 1 && NMT <= 3 && ((MODE & 7) == NET_FWD || (MODE & 7) == NET_FWD2);
+  static constexpr bool MERGE = PXH == 2 && NP == 2 && NGRP == 1 && NMT <= 3 &&
+                                ((MODE & 7) == NET_FWD || (MODE & 7) == NET_FWD2 || ((MODE & 7) == NET_FWD_SAVE && FUSE));   // (the saving pass keeps no P
+                                // any more -- the coupling's pre-tanh inputs are what the backward pass reads -- so it can take the fused form too)
 #endif
 };
 
@@ -1422,6 +1425,7 @@ __device__ __forceinline__ void fused_couple(const NetArgs& a, const float* pl, 
   const float yk = a.fz_inverse ? (vk - ot) / sc : sc * vk + ot;
   const float yo = __shfl_xor(yk, 32, 64);                        // the other transformed channel
   const float y[4] = {k ? yo : yk, k ? yk : yo, v4.z, v4.w};
+  if (qok && a.fz_osave) a.fz_osave[(size_t)q * 2 + k] = ols;     // (edge pixels: k_couple_edge overwrites with the complete sums)
   if (qok && !missing) {
     lsum = log_s;
     bool bad = fz_not_finite(ols) | fz_not_finite(ot) | fz_not_finite(yk);

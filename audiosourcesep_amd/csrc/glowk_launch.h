@@ -66,7 +66,7 @@ int launch_h3s(const NetArgs& a, hipStream_t s, bool dry) {
     // the coupling fused into the kernel (glowk_kernels.h: fused_couple) where the caller asks for it (NetArgs::fuse: plain forward
     // direction, geometry checked by the host), the level has four channels and both passes run in one workgroup: answers 100 =
     // "no P was written, the step's output is in place (but for the rows k_couple_edge finishes)"
-    if constexpr ((MODE == NET_FWD || MODE == NET_FWD2) && MOUT == 36) {
+    if constexpr ((MODE == NET_FWD || MODE == NET_FWD2 || MODE == NET_FWD_SAVE) && MOUT == 36) {
       if constexpr (RingS<KIN, MOUT, NF, MODE | 16, 2>::FITS && RingS<KIN, MOUT, NF, MODE | 16, 2>::MERGE) {
         if (a.fuse && !split) {
           if (!dry) { hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE | 16, 2, false>), dim3(wgs), dim3(512), 0, s, a); note_family(4); }

@@ -311,6 +311,7 @@ struct EdgeArgs {
   float* out;
   int out_stride, out_off, inverse;
   double* logdet;        // [N] += (may be null)
+  float* osave;          // saving pass: [Q][2] pre-tanh log_s inputs of the edge pixels (complete sums), or null
   int h, w;
   int* flag;
 };
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(256) void k_couple_edge(EdgeArgs a) {
     const float o[4] = {part.x + halo.x, part.y + halo.y, part.z + halo.z, part.w + halo.w};
     const float4 v4 = *reinterpret_cast<const float4*>(a.vin + q * 4);
     const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    if (a.osave) { a.osave[q * 2] = o[0]; a.osave[q * 2 + 1] = o[1]; }
     float y[4];
     bool bad = false;
 #pragma unroll

@@ -79,3 +79,39 @@ def test_fused_step_equals_network_plus_coupling(name, precision):
         ref = R.log_prob(x[idx].cpu().numpy().astype(np.float64), R.cast_params(params, np.float64), cfg.as_dict())
         np.testing.assert_allclose(lp_f[idx].cpu().numpy(), ref, rtol=2e-6)
     assert eng.range_status() == (False, 0)
+
+
+@pytest.mark.parametrize("name", ["64x64_edges_4_wgs_per_tile", "32x32_one_tile_per_wg", "16x16_four_tiles_per_wg_ragged"])
+def test_fused_saving_pass_feeds_the_backward_sweep(name):
+    """The saving forward pass of log_prob_grad takes the fused form too (MODE NET_FWD_SAVE | 16): it stores the ReLU masks and the
+    coupling's pre-tanh inputs -- the only thing the backward pass needs of the network's output -- and no per-tap buffer at all.
+    Input gradient and log_prob against the unfused form of the same build and against the exact fp32 kernels."""
+    cfg, n = CASES[name]
+    eng, _ = calibrated_engine(cfg, device=0, init_tiles=32)
+    eng.set_precision(_lib.PREC_F16X3)
+    eng.set_range_policy("error")
+    x = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=6)).cuda()
+    before = eng.fused_steps
+    lp_f, g_f = eng.log_prob_grad(x)
+    fused = eng.fused_steps - before
+    os.environ["GLOWK_NO_FUSE"] = "1"
+    try:
+        lp_u, g_u = eng.log_prob_grad(x)
+    finally:
+        os.environ.pop("GLOWK_NO_FUSE", None)
+    assert fused == cfg.K, fused                                   # every forward step of the 4-channel level
+    assert float(((lp_f - lp_u).abs() / lp_u.abs()).max()) < 2e-6
+    d = (g_f - g_u).abs() / g_u.abs().max()
+    assert float(d.max()) < 2e-2 and float((d > 1e-3).float().mean()) < 5e-4, float(d.max())     # (isolated ReLU flips at most)
+    per_tile = (g_f - g_u).flatten(1).norm(dim=1) / g_u.flatten(1).norm(dim=1)
+    assert float(per_tile.median()) < 2e-6
+    eng.set_precision(_lib.PREC_F32)
+    lp32, g32 = eng.log_prob_grad(x)
+    np.testing.assert_allclose(lp_f.cpu().numpy(), lp32.cpu().numpy(), rtol=2e-6)
+    per_tile = (g_f - g32).flatten(1).norm(dim=1) / g32.flatten(1).norm(dim=1)
+    assert float(per_tile.median()) < 3e-6
+    lp2, g2 = None, None
+    eng.set_precision(_lib.PREC_F16X3)
+    lp2, g2 = eng.log_prob_grad(x)
+    assert torch.equal(lp2, lp_f) and torch.equal(g2, g_f)          # repeatable bit for bit
+    assert eng.range_status() == (False, 0)
