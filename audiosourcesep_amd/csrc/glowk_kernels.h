@@ -1096,8 +1096,10 @@ struct RingS {
   static constexpr bool MERGE = false;
 #else
   static constexpr bool MERGE = PXH == 2 && NP == 2 && NGRP == 1 && NMT <= 3 &&
-                                ((MODE & 7) == NET_FWD || (MODE & 7) == NET_FWD2 || ((MODE & 7) == NET_FWD_SAVE && FUSE));   // (the saving pass keeps no P
-                                // any more -- the coupling's pre-tanh inputs are what the backward pass reads -- so it can take the fused form too)
+                                ((MODE & 7) == NET_FWD || (MODE & 7) == NET_FWD2 || ((MODE & 7) == NET_BWD && NMT <= 2) || ((MODE & 7) == NET_FWD_SAVE && FUSE));   // (the saving pass keeps no P
+                                // any more -- the coupling's pre-tanh inputs are what the backward pass reads -- so it can take the fused form too;
+                                // the 4-channel level's backward network (18 output rows: 16 registers) merges its two passes as well, the 8-channel
+                                // one (36 rows: 24 registers) spills 18 registers if it does)
 #endif
 };
 
