@@ -37,6 +37,26 @@ def test_db_mixing_and_its_gradient():
     np.testing.assert_allclose(num, r1, rtol=1e-5, atol=1e-8)
 
 
+def test_db_schedule_and_psnr():
+    """The reference's BASIS schedule (sigma 1.0 -> 0.01 on tiles normalised to [0, 1], delta 2e-5; run_basis_sep.py:152-161,352-356,
+    465-468) carried to the dB units the melspec flows live in: sigma x 120, delta x 120^2; eta(sigma_L) = delta either way."""
+    from audiosourcesep_amd.config import CONFIG_YAML
+    from audiosourcesep_amd.noise_conditioned import db_schedule, psnr_db
+    sig, delta = db_schedule(CONFIG_YAML)
+    np.testing.assert_allclose(sig, basis.get_sigmas(1.0, 0.01, 10) * 120.0, rtol=1e-6)
+    assert sig.dtype == np.float32 and abs(delta - 2e-5 * 120.0 ** 2) < 1e-12
+    # the Langevin step sizes in the two unit systems correspond: eta_dB = 120^2 eta_normalised at every level
+    eta_n = 2e-5 * (basis.get_sigmas(1.0, 0.01, 10) / 0.01) ** 2
+    eta_db = delta * (sig / sig[-1]) ** 2
+    np.testing.assert_allclose(eta_db, eta_n * 120.0 ** 2, rtol=1e-5)
+    sig4, _ = db_schedule(CONFIG_YAML, sigma1=0.3, sigmaL=0.01, num_classes=4)
+    np.testing.assert_allclose(sig4[[0, -1]], [36.0, 1.2], rtol=1e-6)
+    # PSNR with the 120 dB range as peak: identical tiles -> inf, a constant offset of 12 dB -> 20 dB
+    a = np.random.default_rng(0).uniform(-100, 20, (3, 8, 8, 1)).astype(np.float32)
+    assert psnr_db(a, a) == float("inf")
+    assert abs(psnr_db(a + 12.0, a) - 20.0) < 1e-4
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", ["16x16_L2_K3_F128", "configB_geometry_K2", "configB_geometry_K2_f16x3"])
 def test_basis_inner_loop_matches_oracle(shape):

@@ -13,7 +13,7 @@ from oracle import glowref as R
 from oracle import glowref_torch as RT
 
 FILES = sorted(f for f in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz"))
-               if not os.path.basename(f).startswith("real_"))
+               if not os.path.basename(f).startswith(("real_", "basis_real_")))   # (those two hold tiles, not oracle vectors)
 
 
 def load(path):
