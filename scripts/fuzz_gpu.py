@@ -116,6 +116,27 @@ while time.time() < t_end:
         bad = [j for j, e in enumerate(per) if e > 2e-5]
         note = "; per tile: %d of %d above 2e-5 (max %.1e, median %.1e)" % (len(bad), n, max(per), float(np.median(per)))
         ok = len(bad) <= 3 and max(per) < 5e-2 and float(np.median(per)) < 2e-6
+    if same and not ok:
+        # who is right?  Both sweeps against the fp64 autograd of the oracle on (at most 6 of) the same tiles, before the optimizer step:
+        # a ReLU decided differently from fp64 by EITHER arithmetic moves that step's gradients by ~1e-4 and everything downstream of it by
+        # ~1e-5 of the vector (round 3: seen at an L = 4 shape once its sweep ran split -- fp32 had flipped at level 1, f16x3 at level 2)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+        from test_gpu_training import oracle_param_grads
+        chk, _ = calibrated_engine(cfg, device=0, init_tiles=16, seed=eseed)
+        xs = x[:6]
+        _, ref = oracle_param_grads(xs.cpu().numpy(), params, cfg, -1.0 / n)
+        errs = {}
+        for prec, tag in ((_lib.PREC_F32, "f32"), (_lib.PREC_F16X3, "f16x3")):
+            chk.set_precision(prec)
+            gg = chk.param_grad(xs, -1.0 / n)[1].cpu().numpy()
+            num = den = 0.0
+            for key, r in ref.items():
+                off, cnt = chk.param_slice(key)
+                num += float(np.sum((gg[off:off + cnt] - r.ravel()) ** 2)); den += float(np.sum(r ** 2))
+            errs[tag] = (num / den) ** 0.5
+        chk.close()
+        note += "; vs fp64 autograd: fp32 %.1e, f16x3 %.1e" % (errs["f32"], errs["f16x3"])
+        ok = errs["f16x3"] < 3.0 * errs["f32"] + 2e-5 and errs["f16x3"] < 5e-3
     print("%s train: H%d W%d L%d K%d F%d N%d  |g16 - g32| / |g32| %.1e, device-refreshed images == host-packed: %s, fp32 fallbacks %d%s"
           % ("ok  " if ok else "FAIL", H, W, L, K, F, n, e_pg, same, fb, note), flush=True)
     if not ok:
