@@ -73,8 +73,9 @@ enum glowk_tensor_id {
 };
 
 /* Arithmetic of the coupling-network contractions (the >95 % of the FLOPs), for every compute entry point of the handle
- * (forward, inverse, log_prob, log_prob_grad, sample, the per-step calls).  Shapes without a split-kernel instance
- * (the gradient path of the c = 32 level of 4-level models) run the exact kernels in every mode. */
+ * (forward, inverse, log_prob, log_prob_grad, param_grad, sample, the per-step calls).  Shapes without a split-kernel instance
+ * run the exact kernels in every mode (at the supported widths: the 32-channel level of 4-level models at n_filters 128;
+ * glowk_kernel_families tells which family every launch took). */
 enum glowk_precision {
   GLOWK_PREC_F32 = 0,     /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (default) */
   GLOWK_PREC_F16X3 = 1,   /* error-compensated split: x = hi + lo in fp16, 3 fp16 MFMAs per product, fp32 accumulate:
