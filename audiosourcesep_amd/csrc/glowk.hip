@@ -248,11 +248,14 @@ struct FlatLd { double* slot; int stride, base; };
 int launch_couple(int c, const CoupleArgs& a, int N, hipStream_t s, const FlatLd* fl = nullptr, bool* flat_used = nullptr) {
   const int hw = a.h * a.w;
   if (N < 2 * num_cus() && hw % 64 == 0 && (!a.logdet || (fl && fl->slot)) && !getenv("GLOWK_COUPLE_PER_SAMPLE")) {
-    // few samples: a flat grid over the pixels instead of one workgroup per sample (30 tiles: 30 workgroups on 256 CUs)
+    // few samples: a flat grid over the pixels instead of one workgroup per sample (30 tiles: 30 workgroups on 256 CUs); sixteen
+    // lanes per pixel where the level is deep (c >= 8) and small
     CoupleArgs b = a;
     b.logdet = nullptr;
-    CDISPATCH(c, hipLaunchKernelGGL((k_couple_flat<CC>), dim3((a.Q + 63) / 64), dim3(256), 0, s, b, a.logdet ? fl->slot : (double*)nullptr, hw / 64,
-                                    fl ? fl->stride : 0, fl ? fl->base : 0));
+    double* slots = a.logdet ? fl->slot : (double*)nullptr;
+    const bool wide = c >= 8 && (a.Q + 15) / 16 <= 8 * num_cus() && !getenv("GLOWK_COUPLE_4");
+    if (wide) { CDISPATCH(c, hipLaunchKernelGGL((k_couple_flat<CC, 16>), dim3((a.Q + 15) / 16), dim3(256), 0, s, b, slots, fl ? fl->stride : 0, fl ? fl->base : 0)); }
+    else { CDISPATCH(c, hipLaunchKernelGGL((k_couple_flat<CC, 4>), dim3((a.Q + 63) / 64), dim3(256), 0, s, b, slots, fl ? fl->stride : 0, fl ? fl->base : 0)); }
     LAUNCHCHK("k_couple_flat");
     if (flat_used && a.logdet) *flat_used = true;
     return 0;
@@ -325,10 +328,10 @@ struct WsSizes {      // forward / inverse workspace for N tiles (bytes)
   size_t slots;       // bufLdSlot: per-sample log-det slots of the flat-grid coupling kernel (small batches only)
   size_t total() const { return 3 * act + P + ld + slots; }
 };
-// log-det slots per sample: one per flow step and 64 pixels of its level
+// log-det slots per sample: one per flow step and 16 pixels of its level
 int ld_slots_per_sample(const glowk_handle* h) {
   int n = 0;
-  for (const Level& lv : h->levels) n += h->cfg.K * ((lv.h * lv.w + 63) / 64);
+  for (const Level& lv : h->levels) n += h->cfg.K * ((lv.h * lv.w + 15) / 16);
   return n;
 }
 WsSizes ws_sizes(const glowk_handle* h, size_t N) {
@@ -527,7 +530,7 @@ int run_forward(glowk_handle* h, const float* x, int N, float* z_dst, hipStream_
         ca.A = nullptr; ca.b = nullptr; ca.out = z_dst; ca.out_stride = h->Cl; ca.out_off = lv.z_off;
       }
       const FlatLd fl{flat_ok ? h->bufLdSlot : nullptr, nslots, slot_base};
-      slot_base += (lv.h * lv.w + 63) / 64;
+      slot_base += (lv.h * lv.w + 15) / 16;
       if (plain) { if (int rc = net_and_couple(h, lvl, lv.c, cfg.F, na, ca, N, s, plain_mode, &fl, &flat_used)) return rc; }
       else if (int rc = launch_couple(lv.c, ca, N, s, &fl, &flat_used)) return rc;
       if (k > 0) {

@@ -170,12 +170,27 @@ __device__ __forceinline__ bool not_finite(float v) { return !(fabsf(v) <= 3.0e3
 // inside the pixel); otherwise one lane per pixel (large batches: fewer, fully used lanes -- 47 vs 80 us at 1024 tiles)
 // one pixel of k_couple: gather the nine taps (QUAD: this lane's three, then the quad sum), bias, tanh / exp, coupling, the
 // following affine, store.  Returns the pixel's sum of log_s on the lane that finished it (lane 0 of a quad), 0 elsewhere.
-template <int C, bool QUAD>
+// LPP lanes per pixel: 1, 4 (lane r: taps r, r + 4, r + 8 of every partial) or 16 (the (tap, partial) pairs dealt round robin: the
+// deep levels at small batches, where 64 pixels x 16 channels x 4 partials are ~200 dependent loads per lane of a 4-lane kernel)
+template <int C, int LPP>
 __device__ __forceinline__ float couple_pixel(const CoupleArgs& a, int q, int i, int j, bool live, int r4) {
   constexpr int CI = C / 2;
+  constexpr bool QUAD = LPP == 4;
   float v[C], o[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) o[c] = 0.0f;
+  if constexpr (LPP == 16) {
+    for (int idx = r4; idx < 9 * a.np; idx += 16) {
+      const int tap = idx / a.np, part = idx % a.np;
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+      const int ii = i + dy, jj = j + dx;
+      if (ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) {
+        const float* src = a.P + (size_t)part * a.pstride + (size_t)(tap * C) * a.Q + (q + dy * a.w + dx);
+#pragma unroll
+        for (int c = 0; c < C; ++c) o[c] += src[(size_t)c * a.Q];
+      }
+    }
+  } else {
 #pragma unroll
   for (int u = 0; u < (QUAD ? 3 : 9); ++u) {
     const int tap = QUAD ? r4 + 4 * u : u;
@@ -192,12 +207,11 @@ __device__ __forceinline__ float couple_pixel(const CoupleArgs& a, int q, int i,
         }
     }
   }
+  }
 #pragma unroll
   for (int c = 0; c < C; ++c) {
-    if (QUAD) {
-      o[c] += __shfl_xor(o[c], 1, 64);
-      o[c] += __shfl_xor(o[c], 2, 64);
-    }
+#pragma unroll
+    for (int m = 1; m < LPP; m <<= 1) o[c] += __shfl_xor(o[c], m, 64);
     o[c] += a.b3[c];
   }
   if (r4 != 0 || !live) return 0.0f;
@@ -264,7 +278,7 @@ __global__ __launch_bounds__(1024) void k_couple(CoupleArgs a) {   // 256 .. 102
   for (int pp0 = QUAD ? threadIdx.x >> 2 : threadIdx.x; pp0 < (hw + qpb - 1) / qpb * qpb; pp0 += qpb) {
     const bool live = pp0 < hw;
     const int pp = live ? pp0 : hw - 1;
-    lsum += couple_pixel<C, QUAD>(a, n * hw + pp, pp / a.w, pp % a.w, live, r4);
+    lsum += couple_pixel<C, QUAD ? 4 : 1>(a, n * hw + pp, pp / a.w, pp % a.w, live, r4);
   }
   if (a.logdet) {
     const double tot = block_sum_any((double)lsum, red);
@@ -272,22 +286,25 @@ __global__ __launch_bounds__(1024) void k_couple(CoupleArgs a) {   // 256 .. 102
   }
 }
 
-// The same on a FLAT grid over the pixels (64 per workgroup, four lanes per pixel) for batches whose per-sample workgroups would
-// leave most CUs idle (the reference's 30 / 32 tiles): needs h w a multiple of 64, so that a workgroup's pixels belong to one
-// sample.  Its share of the sample's log-det goes to a slot of its own -- slot[n * sample_stride + slot_base + workgroup within the
-// sample]: no two workgroups add to one address, the order of the final sum (k_ld_fold) is fixed.
-template <int C>
-__global__ __launch_bounds__(256) void k_couple_flat(CoupleArgs a, double* slot, int wg_per_sample, int sample_stride, int slot_base) {
+// The same on a FLAT grid over the pixels (256 / LPP per workgroup: 64 at four lanes per pixel, 16 at sixteen) for batches whose
+// per-sample workgroups would leave most CUs idle (the reference's 30 / 32 tiles): needs h w a multiple of the workgroup's pixels, so
+// that they belong to one sample.  Its share of the sample's log-det goes to a slot of its own -- one slot per 16 pixels of a level:
+// slot[n * sample_stride + slot_base + first 16-pixel unit of the workgroup]; no two workgroups add to one address, the order of the
+// final sum (k_ld_fold) is fixed.
+template <int C, int LPP>
+__global__ __launch_bounds__(256) void k_couple_flat(CoupleArgs a, double* slot, int sample_stride, int slot_base) {
   __shared__ double red[4];
+  constexpr int PPB = 256 / LPP;
   const int hw = a.h * a.w;
-  const int q0 = (int)blockIdx.x * 64 + ((int)threadIdx.x >> 2);
+  const int q0 = (int)blockIdx.x * PPB + ((int)threadIdx.x / LPP);
   const bool live = q0 < a.Q;
   const int q = live ? q0 : a.Q - 1;
   const int pp = q % hw;
-  const float lsum = couple_pixel<C, true>(a, q, pp / a.w, pp % a.w, live, threadIdx.x & 3);
+  const float lsum = couple_pixel<C, LPP>(a, q, pp / a.w, pp % a.w, live, threadIdx.x & (LPP - 1));
   if (slot) {
     const double tot = block_sum_256((double)lsum, red);
-    if (threadIdx.x == 0) slot[(size_t)(blockIdx.x / wg_per_sample) * sample_stride + slot_base + blockIdx.x % wg_per_sample] = tot;
+    const int first = (int)blockIdx.x * PPB;
+    if (threadIdx.x == 0) slot[(size_t)(first / hw) * sample_stride + slot_base + (first % hw) / 16] = tot;
   }
 }
 
