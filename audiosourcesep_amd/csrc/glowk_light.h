@@ -214,6 +214,65 @@ __device__ __forceinline__ float couple_pixel(const CoupleArgs& a, int q, int i,
     for (int m = 1; m < LPP; m <<= 1) o[c] += __shfl_xor(o[c], m, 64);
     o[c] += a.b3[c];
   }
+  if constexpr (LPP == 16) {
+    // sixteen lanes per pixel: every lane holds the full o[] now (xor butterfly), so the per-pixel algebra is dealt out as well --
+    // lane r owns channels r (and r + 16 at the 32-channel level): its own tanh / exp, an all-gather of the coupled vector over the
+    // pixel's lanes, its own output channel(s) of the following affine, one coalesced store.  (On lane 0 alone this tail was ~700
+    // dependent instructions per pixel at c = 16: 14.5 us per launch at 30 tiles.)
+    constexpr int CPL = (C + 15) / 16;           // channels per lane
+    float yo[CPL], ls_sum = 0.0f;
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) {
+      const int ch = r4 + 16 * e;
+      float oc = 0.0f, ot = 0.0f;                // o[ch], o[CI + ch] by select chains (no dynamic register indexing)
+#pragma unroll
+      for (int c = 0; c < C; ++c) oc = (c == ch) ? o[c] : oc;
+#pragma unroll
+      for (int c = 0; c < CI; ++c) ot = (c == ch) ? o[CI + c] : ot;
+      const bool mine = ch < C, first = ch < CI;
+      const float vch = (a.vin && mine) ? a.vin[(size_t)q * C + ch] : 0.0f;
+      float y = vch;
+      if (first) {
+        const float log_s = tanhf(oc);
+        if (a.log_s_out && live) { a.log_s_out[(size_t)q * CI + ch] = log_s; a.t_out[(size_t)q * CI + ch] = ot; }
+        if (a.o_save && live) a.o_save[(size_t)q * CI + ch] = oc;
+        if (a.vin) {
+          const float sc = expf(log_s);
+          y = a.inverse ? (vch - ot) / sc : sc * vch + ot;
+        }
+        if (live) ls_sum += log_s;
+      }
+      bad |= mine && (not_finite(oc) | not_finite(y));
+      yo[e] = y;
+    }
+    if (bad && live && a.flag) *a.flag = 1;
+    if (a.out) {
+      float z[CPL];
+      const int lane0 = (int)(threadIdx.x & 63) & ~15;          // first lane of this pixel's group within the wave
+      if (a.A) {
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) z[e] = (r4 + 16 * e < C) ? a.b[r4 + 16 * e] : 0.0f;
+#pragma unroll
+        for (int ci = 0; ci < C; ++ci) {
+          const float yc = __shfl(yo[ci / 16], lane0 + (ci & 15), 64);       // the all-gather: every lane of the group executes it
+#pragma unroll
+          for (int e = 0; e < CPL; ++e)
+            if (r4 + 16 * e < C) z[e] = fmaf(yc, a.A[ci * C + r4 + 16 * e], z[e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) z[e] = yo[e];
+      }
+      if (live) {
+        float* dst = a.out + (size_t)q * a.out_stride + a.out_off;
+#pragma unroll
+        for (int e = 0; e < CPL; ++e)
+          if (r4 + 16 * e < C) dst[r4 + 16 * e] = z[e];
+      }
+    }
+    return ls_sum;
+  }
   if (r4 != 0 || !live) return 0.0f;
   if (a.flag) {
     bool bad = false;
