@@ -700,6 +700,73 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
       for (int m = 1; m < LPP; m <<= 1) gsum[c] += __shfl_xor(gsum[c], m, 64);
     }
     float gomax = 0.0f;      // largest |g_o| this lane writes (unscaled)
+    if constexpr (LPP == 16) {
+      // sixteen lanes per pixel: the per-pixel algebra is dealt out too -- lane r owns channel r (r, r + 16 at the 32-channel level):
+      // its entry of the merged g_v, an all-gather over the pixel's lanes, its own row of g_y = g_v . A^T, and for r < c/2 one tanh /
+      // exp of the coupling backward (on lane 0 alone: ~600 dependent instructions per pixel at c = 16)
+      constexpr int CPL = (C + 15) / 16;
+      const int lane0 = (int)(threadIdx.x & 63) & ~15;
+      float gvo[CPL];
+      bool bad = false;
+#pragma unroll
+      for (int e = 0; e < CPL; ++e) {
+        const int ch = r4 + 16 * e;
+        float g = 0.0f;
+        if (ch < C) {
+          if (a.Pg) {
+            float gs = 0.0f;                       // gsum[ch - CI] by a select chain
+#pragma unroll
+            for (int c = 0; c < CI; ++c) gs = (c == ch - CI) ? gsum[c] : gs;
+            g = a.ghalf_in[(size_t)q * C + ch] + (ch >= CI ? gs * a.pg_scale : 0.0f);
+            bad |= ch >= CI && not_finite(gs);
+          } else {
+            g = a.gv_direct[(size_t)q * a.gvd_stride + a.gvd_off + ch];
+          }
+          if (a.gv_out && live) a.gv_out[(size_t)q * C + ch] = g;
+        }
+        gvo[e] = g;
+      }
+      float gyo[CPL];
+      if (a.A) {
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) gyo[e] = 0.0f;
+#pragma unroll
+        for (int co = 0; co < C; ++co) {
+          const float gc = __shfl(gvo[co / 16], lane0 + (co & 15), 64);
+#pragma unroll
+          for (int e = 0; e < CPL; ++e)
+            if (r4 + 16 * e < C) gyo[e] = fmaf(gc, a.A[(r4 + 16 * e) * C + co], gyo[e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) gyo[e] = gvo[e];
+      }
+      if (a.v) {
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) {
+          const int ch = r4 + 16 * e;
+          if (ch < CI) {
+            const float ok_ = a.osave[(size_t)q * CI + ch];
+            const float log_s = tanhf(ok_), sc = expf(log_s), va = a.v[(size_t)q * C + ch], gya = gyo[e];
+            const float g_pre = (gya * sc * va + 1.0f) * (1.0f - log_s * log_s);
+            bad |= not_finite(ok_);
+            if (live) {
+              gomax = fmaxf(gomax, fmaxf(fabsf(g_pre), fabsf(gya)));
+              a.g_o[(size_t)q * C + ch] = g_pre * a.go_scale;
+              a.g_o[(size_t)q * C + CI + ch] = gya * a.go_scale;
+              a.ghalf_out[(size_t)q * C + ch] = gya * sc;
+            }
+          } else if (ch < C && live) {
+            a.ghalf_out[(size_t)q * C + ch] = gyo[e];
+          }
+        }
+      } else if (live) {
+#pragma unroll
+        for (int e = 0; e < CPL; ++e)
+          if (r4 + 16 * e < C) a.gu_out[(size_t)q * C + r4 + 16 * e] = gyo[e];
+      }
+      if (bad && live && a.flag) *a.flag = 1;
+    } else
     if (r4 == 0 && live) {
 #pragma unroll
     for (int c = 0; c < CI; ++c) gsum[c] *= a.pg_scale;
