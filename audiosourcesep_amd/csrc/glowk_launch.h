@@ -181,7 +181,8 @@ int launch_net_t(const NetArgs& a, int mode, hipStream_t s, bool dry) {
       break;
     case 9:            if (!dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE, true>), dim3(ntiles), dim3(256), 0, s, a); break;   // saving forward pass that keeps its hiddens
     case 3:   // f16x3 arithmetic: forward / forward with saves / backward; shapes without an instance run the exact fp32 kernel
-      if (a.RSp && h3_shape16() && half_wave_grid(a) && !a.fuse) np = launch_h3s_half<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
+      // (GLOWK_HALF_FORCE=1: the half-wave form at every grid size -- two 128-pixel workgroups per CU; an experiment)
+      if (a.RSp && h3_shape16() && ((half_wave_grid(a) && !a.fuse) || getenv("GLOWK_HALF_FORCE"))) np = launch_h3s_half<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
       if (!np && a.RSp && h3_shape16()) np = launch_h3s<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
       if (!np && a.RHp) np = launch_h3<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
       if (!np && !dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a);
