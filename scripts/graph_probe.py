@@ -10,9 +10,11 @@ from audiosourcesep_amd.synthetic import synthetic_mel_tiles, calibrated_engine
 reps = int(os.environ.get("REPS", "30"))
 eng, _ = calibrated_engine(CONFIG_B, device=0)
 eng.set_precision(int(os.environ.get("GLOWK_PREC", "1")))
+eng.set_range_policy("ignore")     # (the other policies wait for the stream after every call: not capturable)
 for n in [int(v) for v in os.environ.get("NS", "1,8,30,128").split(",")]:
     x = torch.from_numpy(synthetic_mel_tiles(n, CONFIG_B)).cuda()
     eng.reserve(n)
+    eng.reserve(n, with_grad=True)
     for name, f in (("log_prob", lambda: eng.log_prob(x)), ("log_prob_grad", lambda: eng.log_prob_grad(x))):
         for _ in range(3):
             ref = f()
