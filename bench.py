@@ -122,9 +122,17 @@ def _cpu_baseline_pinned(RT, cfg, params, budget_s, threads):
         # (the same tile count for the deduplicated and the faithful graph: per-tile CPU time depends on the batch --
         #  hidden activations of 64 tiles no longer fit the caches -- and the two variants are meant to be compared)
         tiles = int(max(2, min(32, share / max(1.5 * t1, 1e-3))))
-        t0 = time.perf_counter()                      # (the two-tile probe over-estimates the per-tile time of a larger batch: one
-        RT.log_prob(x[:tiles], p, d)                  #  pass at the first guess, then the tile count that fills the share)
-        tiles = int(max(2, min(32, tiles * share / max(time.perf_counter() - t0, 1e-3))))
+        for _ in range(3):                            # (per-tile CPU time depends on the batch -- caches -- so the tile count that makes ten
+            t0 = time.perf_counter()                  #  passes fit the share is found by measuring: at most three calibration passes)
+            RT.log_prob(x[:tiles], p, d)
+            tp = time.perf_counter() - t0
+            spent += tp
+            new = int(max(2, min(32, tiles * share / max(tp, 1e-3) * 0.85)))
+            if new == tiles or (tp <= 1.1 * share and new >= tiles and tiles == 32):
+                break
+            if tp <= 1.1 * share and new <= tiles:    # already inside the share: keep it
+                break
+            tiles = new
         med, tot = timed(tiles, 1)
         spent += tot
         out = {"value": tiles / med, "unit": "passes/s", "cores": threads, "kind": "port",
