@@ -2062,7 +2062,7 @@ int glowk_apply_gradients(glowk_handle* h, const float* grad_dev, int optimizer,
       hipLaunchKernelGGL(k_f16_absmax, dim3(6, cfg.K), dim3(1024), 0, ls, fp);
       hipLaunchKernelGGL(k_f16_consts, dim3((F + 32 * NMT + 255) / 256, cfg.K), dim3(256), 0, ls, fp, img0 + SL.epH, NMT);
       hipLaunchKernelGGL(k_f16_limits, dim3(2, cfg.K), dim3(512), 0, ls, fp);
-      hipLaunchKernelGGL(k_repack_f16, dim3((unsigned)((h->tr_map16_n[lvl] + 255) / 256), cfg.K), dim3(256), 0, ls, (const int*)h->tr_map16[lvl],
+      hipLaunchKernelGGL(k_repack_f16, dim3((unsigned)((h->tr_map16_n[lvl] + 1023) / 1024), cfg.K), dim3(256), 0, ls, (const int*)h->tr_map16[lvl],
                          h->tr_map16_n[lvl], fp, reinterpret_cast<unsigned short*>(img0 + SL.RHp), SL.total * 2);
       LAUNCHCHK("k_repack_f16");
       HIPCHK(hipMemcpyAsync(pin_sc(lvl), fp.scales, (size_t)cfg.K * 8 * 4, hipMemcpyDeviceToHost, ls));
