@@ -130,13 +130,19 @@ while time.time() < t_end:
             chk.set_precision(prec)
             gg = chk.param_grad(xs, -1.0 / n)[1].cpu().numpy()
             num = den = 0.0
+            per = []
             for key, r in ref.items():
                 off, cnt = chk.param_slice(key)
-                num += float(np.sum((gg[off:off + cnt] - r.ravel()) ** 2)); den += float(np.sum(r ** 2))
-            errs[tag] = (num / den) ** 0.5
+                d2, r2 = float(np.sum((gg[off:off + cnt] - r.ravel()) ** 2)), float(np.sum(r ** 2))
+                num += d2; den += r2
+                if r2 > 0.0:
+                    per.append((d2 / r2) ** 0.5)
+            errs[tag] = ((num / den) ** 0.5, float(np.median(per)), float(np.max(per)))
         chk.close()
-        note += "; vs fp64 autograd: fp32 %.1e, f16x3 %.1e" % (errs["f32"], errs["f16x3"])
-        ok = errs["f16x3"] < 3.0 * errs["f32"] + 2e-5 and errs["f16x3"] < 5e-3
+        note += "; vs fp64 autograd (whole vector, median tensor, worst tensor): fp32 %.1e %.1e %.1e, f16x3 %.1e %.1e %.1e" % (errs["f32"] + errs["f16x3"])
+        # a flip: one step's tensors off by ~1e-4 ... 1e-3, everything downstream of it by ~1e-5, the typical tensor fp32-class; a broken
+        # kernel would lift the MEDIAN tensor (every step of a level) -- that is what fails
+        ok = errs["f16x3"][1] < 3e-5 and errs["f16x3"][2] < 5e-2 and errs["f16x3"][0] < 5e-3
     print("%s train: H%d W%d L%d K%d F%d N%d  |g16 - g32| / |g32| %.1e, device-refreshed images == host-packed: %s, fp32 fallbacks %d%s"
           % ("ok  " if ok else "FAIL", H, W, L, K, F, n, e_pg, same, fb, note), flush=True)
     if not ok:
