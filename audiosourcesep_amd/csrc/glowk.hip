@@ -233,10 +233,15 @@ int launch_net(glowk_handle* h, int level, int c, int F, const NetArgs& a, hipSt
   }
 
 // light backward kernel of one step: 16 lanes per pixel where the batch is small and the level deep (few pixels, many channels and
-// partial buffers: the gathers' dependent loads are what the launch waits for), else 4
+// partial buffers: the gathers' dependent loads are what the launch waits for), one where the grid is large, else 4
 int launch_bwd_light(int c, const BwdArgs& a, int N, hipStream_t s) {
   const bool wide = c >= 8 && (a.Q + 15) / 16 <= 8 * num_cus() && !getenv("GLOWK_BWD_LIGHT_4");
-  if (wide) { CDISPATCH(c, hipLaunchKernelGGL((k_bwd_light<CC, 16>), dim3((a.Q + 15) / 16), dim3(256), 0, s, a)); }
+  // large grids: one lane per pixel (the planar Pg gathers and the 16-byte rows of the [Q][C] arrays are then fully coalesced)
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool one = (a.Q + 255) / 256 >= 2 * num_cus() && al16(a.ghalf_in) && al16(a.v) && al16(a.osave) && al16(a.g_o) && al16(a.ghalf_out) &&
+                   al16(a.gu_out) && al16(a.gv_out) && !getenv("GLOWK_BWD_LIGHT_4");
+  if (one) { CDISPATCH(c, hipLaunchKernelGGL((k_bwd_light<CC, 1>), dim3((a.Q + 255) / 256), dim3(256), 0, s, a)); }
+  else if (wide) { CDISPATCH(c, hipLaunchKernelGGL((k_bwd_light<CC, 16>), dim3((a.Q + 15) / 16), dim3(256), 0, s, a)); }
   else { CDISPATCH(c, hipLaunchKernelGGL((k_bwd_light<CC, 4>), dim3((a.Q + 63) / 64), dim3(256), 0, s, a)); }
   LAUNCHCHK("k_bwd_light");
   return 0;

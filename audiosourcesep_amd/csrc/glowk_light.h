@@ -611,6 +611,28 @@ __global__ __launch_bounds__(256) void k_chan_stats(const float* __restrict__ x,
 // ------------------------------------------------------------------------------------------------------------------
 // input-gradient path (compute_grad_logprob, run_basis_sep.py:73-79; derivation SURVEY appendix A.5)
 // ------------------------------------------------------------------------------------------------------------------
+// one pixel's row of N floats (N = 2 or a multiple of 4) as 8- / 16-byte accesses; the callers guarantee the alignment (host check in
+// launch_bwd_light: every [Q][C] array of the one-lane-per-pixel form starts on a 16-byte boundary)
+template <int N>
+__device__ __forceinline__ void ld_row(const float* __restrict__ p, float (&d)[N]) {
+  if constexpr (N == 2) { const float2 t = *reinterpret_cast<const float2*>(p); d[0] = t.x; d[1] = t.y; }
+  else {
+#pragma unroll
+    for (int e = 0; e < N / 4; ++e) {
+      const float4 t = reinterpret_cast<const float4*>(p)[e];
+      d[4 * e] = t.x; d[4 * e + 1] = t.y; d[4 * e + 2] = t.z; d[4 * e + 3] = t.w;
+    }
+  }
+}
+template <int N>
+__device__ __forceinline__ void st_row(float* __restrict__ p, const float (&d)[N]) {
+  if constexpr (N == 2) *reinterpret_cast<float2*>(p) = make_float2(d[0], d[1]);
+  else {
+#pragma unroll
+    for (int e = 0; e < N / 4; ++e) reinterpret_cast<float4*>(p)[e] = make_float4(d[4 * e], d[4 * e + 1], d[4 * e + 2], d[4 * e + 3]);
+  }
+}
+
 struct BwdArgs {
   // (1) gradient wrt the tensor v_s entering step s's coupling:
   //     merge: g_v = [g_va, g_yb + sum_tap Pg[tap, cin][q - d(tap)]]   (ghalf_in, Pg of step s), or
@@ -641,7 +663,8 @@ struct BwdArgs {
   unsigned* gmax;          // [16] words per level (the workgroups spread their atomics over them)
 };
 
-// LPP lanes per pixel: 4 (lane r gathers taps r, r + 4, r + 8 of every partial) or 16 -- the (tap, partial) pairs dealt round
+// LPP lanes per pixel: 1 (large grids: every load of the planar Pg arrays and every 16-byte row access is fully coalesced),
+// 4 (lane r gathers taps r, r + 4, r + 8 of every partial) or 16 -- the (tap, partial) pairs dealt round
 // robin -- for the deep levels at small batches: 64 pixels x 8 or 16 channels per sample leave a 4-lane kernel with ~200 dependent
 // loads per lane on a few dozen workgroups (15-16 us per launch at 30 tiles against a ~5 us floor)
 template <int C, int LPP>
@@ -660,10 +683,10 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
     float gsum[CI], o[CI];   // merged network gradient (second half of g_v); log_s half of the saved network output
 #pragma unroll
     for (int c = 0; c < CI; ++c) { gsum[c] = 0.0f; o[c] = 0.0f; }
-    if constexpr (LPP == 4) {
+    if constexpr (LPP <= 4) {
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int tap = r4 + 4 * u;
+    for (int u = 0; u < (9 + LPP - 1) / LPP; ++u) {
+      const int tap = r4 + LPP * u;
       const int dy = tap / 3 - 1, dx = tap % 3 - 1;
       if (tap < 9 && a.Pg) {
         const int ii = i - dy, jj = j - dx;   // Pg[q'] contributes at q' + d(tap)
@@ -778,8 +801,11 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
     }
     float gv[C];
     if (a.Pg) {
+      if constexpr (LPP == 1) ld_row<C>(a.ghalf_in + (size_t)q * C, gv);
+      else {
 #pragma unroll
-      for (int c = 0; c < C; ++c) gv[c] = a.ghalf_in[(size_t)q * C + c];
+        for (int c = 0; c < C; ++c) gv[c] = a.ghalf_in[(size_t)q * C + c];
+      }
 #pragma unroll
       for (int c = 0; c < CI; ++c) gv[CI + c] += gsum[c];
     } else {
@@ -787,8 +813,11 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
       for (int c = 0; c < C; ++c) gv[c] = a.gv_direct[(size_t)q * a.gvd_stride + a.gvd_off + c];
     }
     if (a.gv_out) {
+      if constexpr (LPP == 1) st_row<C>(a.gv_out + (size_t)q * C, gv);
+      else {
 #pragma unroll
-      for (int c = 0; c < C; ++c) a.gv_out[(size_t)q * C + c] = gv[c];
+        for (int c = 0; c < C; ++c) a.gv_out[(size_t)q * C + c] = gv[c];
+      }
     }
     float gy[C];
     if (a.A) {
@@ -804,28 +833,40 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
       for (int c = 0; c < C; ++c) gy[c] = gv[c];
     }
     if (a.v) {
+      float va_[CI], go_[C], gh_[C];
+      if constexpr (LPP == 1) { ld_row<CI>(a.osave + (size_t)q * CI, o); ld_row<CI>(a.v + (size_t)q * C, va_); }
+      else {
 #pragma unroll
-      for (int c = 0; c < CI; ++c) o[c] = a.osave[(size_t)q * CI + c];   // only the log_s half of the network output is needed
-      float* go = a.g_o + (size_t)q * C;
-      float* gh = a.ghalf_out + (size_t)q * C;
+        for (int c = 0; c < CI; ++c) { o[c] = a.osave[(size_t)q * CI + c]; va_[c] = a.v[(size_t)q * C + c]; }   // only the log_s half of the network output is needed
+      }
 #pragma unroll
       for (int k = 0; k < CI; ++k) {
         const float log_s = tanhf(o[k]);
         const float sc = expf(log_s);
-        const float va = a.v[(size_t)q * C + k];
+        const float va = va_[k];
         const float gya = gy[k];
         const float g_ls = gya * sc * va + 1.0f;          // + 1: d(sum log_s)/d log_s (flow_tfp_bijectors.py:150-153)
         const float g_pre = g_ls * (1.0f - log_s * log_s); // through tanh
         gomax = fmaxf(gomax, fmaxf(fabsf(g_pre), fabsf(gya)));
-        go[k] = g_pre * a.go_scale;
-        go[CI + k] = gya * a.go_scale;                    // g_t
-        gh[k] = gya * sc;                                 // g_va
-        gh[CI + k] = gy[CI + k];                          // g_yb (the network's contribution is merged by the next call)
+        go_[k] = g_pre * a.go_scale;
+        go_[CI + k] = gya * a.go_scale;                   // g_t
+        gh_[k] = gya * sc;                                // g_va
+        gh_[CI + k] = gy[CI + k];                         // g_yb (the network's contribution is merged by the next call)
+      }
+      if constexpr (LPP == 1) { st_row<C>(a.g_o + (size_t)q * C, go_); st_row<C>(a.ghalf_out + (size_t)q * C, gh_); }
+      else {
+        float* go = a.g_o + (size_t)q * C;
+        float* gh = a.ghalf_out + (size_t)q * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { go[c] = go_[c]; gh[c] = gh_[c]; }
       }
     } else {
-      float* gu = a.gu_out + (size_t)q * C;
+      if constexpr (LPP == 1) st_row<C>(a.gu_out + (size_t)q * C, gy);
+      else {
+        float* gu = a.gu_out + (size_t)q * C;
 #pragma unroll
-      for (int c = 0; c < C; ++c) gu[c] = gy[c];
+        for (int c = 0; c < C; ++c) gu[c] = gy[c];
+      }
     }
     }
     if (a.gmax) {            // (uniform branch; every lane is here: idle ones carry 0)

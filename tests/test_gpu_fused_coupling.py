@@ -115,3 +115,47 @@ def test_fused_saving_pass_feeds_the_backward_sweep(name):
     lp2, g2 = eng.log_prob_grad(x)
     assert torch.equal(lp2, lp_f) and torch.equal(g2, g_f)          # repeatable bit for bit
     assert eng.range_status() == (False, 0)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("shape", ["64x64_L3", "32x32_L2_notop"])
+def test_one_lane_per_pixel_backward_merge_equals_the_four_lane_form(precision, shape):
+    """k_bwd_light<C, 1> (grids of >= 2 x CUs 256-pixel workgroups: coalesced planar gathers, 16-byte row accesses) against the
+    four-lanes-per-pixel form of the same launch (GLOWK_BWD_LIGHT_4=1): the nine taps are added in another order, nothing else
+    differs -- input gradient and parameter gradient to fp32 rounding, and the input gradient against fp64 autograd on a few tiles."""
+    from oracle import glowref_torch as RT
+    cfg, n = {"64x64_L3": (GlowConfig(H=64, W=64, C=1, L=3, K=2, F=512), 600),            # level 0 AND level 1 take the one-lane form
+              "32x32_L2_notop": (GlowConfig(H=32, W=32, C=1, L=2, K=3, F=256, learntop=False), 530)}[shape]
+    eng, params = calibrated_engine(cfg, device=0, init_tiles=32)
+    eng.set_precision({"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3}[precision])
+    eng.set_range_policy("error")
+    x = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=11)).cuda()
+
+    def run(four):
+        if four:
+            os.environ["GLOWK_BWD_LIGHT_4"] = "1"
+        try:
+            lp, dx = eng.log_prob_grad(x)
+            lpp, g = eng.param_grad(x[:300].contiguous(), -1.0 / 300)
+            torch.cuda.synchronize()
+            return lp, dx, g
+        finally:
+            os.environ.pop("GLOWK_BWD_LIGHT_4", None)
+
+    lp1, dx1, g1 = run(False)
+    lp4, dx4, g4 = run(True)
+    assert torch.equal(lp1, lp4) and torch.isfinite(dx1).all() and torch.isfinite(g1).all()
+    ddx = float((dx1 - dx4).abs().max() / dx4.abs().max())
+    dg = float((g1 - g4).abs().max() / g4.abs().max())
+    print(shape, precision, "one lane vs four: dx %.1e, param grad %.1e of the largest entry" % (ddx, dg))
+    assert ddx < 2e-6 and dg < 2e-6
+    lp1b, dx1b, g1b = run(False)
+    assert torch.equal(dx1b, dx1)                                                # repeatable bit for bit
+    # (the split training sweep sizes its gradient scale on the previous sweep: same products at another power of two, DESIGN 5b)
+    assert float((g1b - g1).abs().max() / g1.abs().max()) < 2e-6
+    idx = [0, n // 2, n - 1]
+    _, ref = RT.log_prob_and_grad(x[idx].cpu().numpy().astype(np.float64), params, cfg.as_dict())
+    ref = torch.from_numpy(ref)
+    err = float((dx1[idx].cpu().double() - ref).abs().max() / ref.abs().max())
+    print("   vs fp64 autograd: %.1e" % err)
+    assert err < (2e-4 if precision == "f32" else 1e-3)          # (the bar of the other gradient tests; isolated ReLU flips allowed, DESIGN section 5)
