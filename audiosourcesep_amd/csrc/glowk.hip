@@ -718,7 +718,7 @@ int launch_wgrad(glowk_handle* h, bool split, const float* A, ptrdiff_t bsA, int
   if (split) {
     WgradSplitArgs a;
     a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.kslice = kslice; a.S = S; a.tm = tm; a.tn = tn; a.bsA = bsA; a.bsB = bsB; a.sa = sa; a.sb = sb;
-    a.Cpart = out; a.csz = csz; a.b_sums = b_sums ? 1 : 0;
+    a.Cpart = out; a.csz = csz; a.b_sums = b_sums ? 1 : 0; a.plain = getenv("GLOWK_WGRAD_PLAIN") ? 1 : 0;
     const dim3 grid((unsigned)(tiles * S * nb));
     if (big8 && vec) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 4, 2, true>), grid, dim3(512), 0, s, a);
     else if (big8) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 4, 2, false>), grid, dim3(512), 0, s, a);

@@ -208,6 +208,7 @@ struct WgradSplitArgs {
   float sa, sb;      // powers of two; sa must be 1
   float* Cpart;      // output z = b * S + s starts at Cpart + z * csz
   size_t csz;        // floats between consecutive outputs (>= M * N, or (M + 1) * N with b_sums)
+  int plain;         // 1: the plain round order for every shape (A/B timing: GLOWK_WGRAD_PLAIN)
   int b_sums;        // 1: row M of every output = the row sums of B over the slice (what a row of ones appended to A would give; fp64
                      // accumulation in the workgroups of the first row tile, which stage those rows anyway)
 };
@@ -252,6 +253,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void k_wgrad_h3
   const bool full = VEC && m0 + TM <= a.M && n0 + TN <= a.N && ((k_end - k_begin) & 31) == 0;
   auto load4 = [&](auto full_tag, const float* base, int row, int rows, long k) -> float4 {
     float4 v = {0.f, 0.f, 0.f, 0.f};
+#ifdef WGRAD_EXP_NOLOAD  // (diagnostic build: no global loads)
+    return v;
+#endif
     if constexpr (decltype(full_tag)::value) {
       v = *reinterpret_cast<const float4*>(base + (size_t)row * a.K + k);
     } else if constexpr (VEC) {   // unconditional load from a clamped address, then select (no branch around the load)
@@ -278,6 +282,14 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void k_wgrad_h3
   typedef _Float16 h4v __attribute__((ext_vector_type(4)));
   auto put = [&](auto unit_tag, const float4& v, float sc, _Float16* hi, _Float16* lo, int row) {
     constexpr bool UNIT = decltype(unit_tag)::value;    // scale 1: no multiply
+#ifdef WGRAD_EXP_NOSTAGE // (diagnostic build: no LDS writes at all -- fragment reads, MFMAs and barriers alone)
+    return;
+#endif
+#ifdef WGRAD_EXP_NOCVT   // (diagnostic build, wrong numbers on purpose: what does the conversion cost?  same bytes through the same path)
+    *reinterpret_cast<float2*>(hi + row * LDH + lk) = make_float2(v.x, v.y);
+    *reinterpret_cast<float2*>(lo + row * LDH + lk) = make_float2(v.z, v.w);
+    return;
+#endif
     const f32x2 p0 = {UNIT ? v.x : v.x * sc, UNIT ? v.y : v.y * sc}, p1 = {UNIT ? v.z : v.z * sc, UNIT ? v.w : v.w * sc};
     const h2v h0 = __builtin_convertvector(p0, h2v), h1 = __builtin_convertvector(p1, h2v);
     const f32x2 d0 = p0 - __builtin_convertvector(h0, f32x2), d1 = p1 - __builtin_convertvector(h1, f32x2);
@@ -329,19 +341,85 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void k_wgrad_h3
         for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
     }
   };
+  auto round_interleaved = [&](auto full_tag, auto ub_tag, auto sum_tag, int buf, long kf) {
+    constexpr int NU = EA + EB;
+    h8 fah[2][WTM], fal[2][WTM], fbh[2][WTN], fbl[2][WTN];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) {
+        const int off = ((wm * WTM + i) * 32 + i32) * LDH + ks * 16 + 8 * kh;
+        fah[ks][i] = *reinterpret_cast<const h8*>(Ah[buf] + off);
+        fal[ks][i] = *reinterpret_cast<const h8*>(Al[buf] + off);
+      }
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) {
+        const int off = ((wn * WTN + j) * 32 + i32) * LDH + ks * 16 + 8 * kh;
+        fbh[ks][j] = *reinterpret_cast<const h8*>(Bh[buf] + off);
+        fbl[ks][j] = *reinterpret_cast<const h8*>(Bl[buf] + off);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+      const int ks = g / 3, prod = g % 3;
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(prod == 0 ? fal[ks][i] : fah[ks][i], prod == 1 ? fbl[ks][j] : fbh[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        if ((u * 6) / NU != g) continue;
+        if (u < EA) {
+          const int e = u;
+          put(std::true_type{}, ra[e], 1.0f, Ah[buf ^ 1], Al[buf ^ 1], lr + RPP * e);
+          ra[e] = load4(full_tag, Ab, m0 + lr + RPP * e, a.M, kf + lk);
+        } else {
+          const int e = u - EA;
+          put(ub_tag, rb[e], a.sb, Bh[buf ^ 1], Bl[buf ^ 1], lr + RPP * e);
+          if constexpr (decltype(sum_tag)::value) bsum[e] += ((double)rb[e].x + (double)rb[e].y) + ((double)rb[e].z + (double)rb[e].w);
+          rb[e] = load4(full_tag, Bb, n0 + lr + RPP * e, a.N, kf + lk);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   auto run = [&](auto full_tag, auto ub_tag, auto sum_tag) {
     fetch(full_tag, k_begin);
     stage(ub_tag, sum_tag, 0);
     if (k_begin + 32 < k_end) fetch(full_tag, k_begin + 32);
     __syncthreads();
     int buf = 0;
-    for (long k0 = k_begin; k0 < k_end; k0 += 32, buf ^= 1) {
-      const bool more = k0 + 32 < k_end;
-      if (more) stage(ub_tag, sum_tag, buf ^ 1);  // (buffer buf ^ 1 was last read before the barrier that ended the previous round)
-      if (k0 + 64 < k_end) fetch(full_tag, k0 + 64);
-      compute(buf);
+    if (WTM * WTN != 4 || a.plain) {
+      // the skinny shapes are bound by streaming A: the plain order (whole staging, all loads, then the MFMAs) keeps their loads earliest
+      // (the branch-free, fenced form below: 29 -> 21 TFLOP/s on the conv1 / conv3 shapes)
+      for (long k0 = k_begin; k0 < k_end; k0 += 32, buf ^= 1) {
+        const bool more = k0 + 32 < k_end;
+        if (more) stage(ub_tag, sum_tag, buf ^ 1);  // (buffer buf ^ 1 was last read before the barrier that ended the previous round)
+        if (k0 + 64 < k_end) fetch(full_tag, k0 + 64);
+        compute(buf);
+        gemm_barrier();
+      }
+      return;
+    }
+    long k0 = k_begin;
+    // steady state: a round without a branch in its body, written as six groups -- one product of one k-step (WTM x WTN MFMAs) followed
+    // by a share of the NEXT round's staging (conversion of one loader unit, its two LDS writes) and the global load that refills the
+    // unit's registers for the round after -- fenced so that the compiler keeps the interleave: the matrix pipe works through a group's
+    // MFMAs while the wave issues the group's ~20 VALU instructions.  (With the staging behind an `if (more)` it was a basic block of
+    // its own: ~130 VALU instructions per wave with the matrix pipe idle, both waves of a SIMD in step because of the barrier.)
+    for (; k0 + 64 < k_end; k0 += 32, buf ^= 1) {
+      round_interleaved(full_tag, ub_tag, sum_tag, buf, k0 + 64);
       gemm_barrier();
     }
+    if (k0 + 32 < k_end) {                        // the last round but one: nothing left to fetch
+      stage(ub_tag, sum_tag, buf ^ 1);
+      compute(buf);
+      gemm_barrier();
+      buf ^= 1;
+    }
+    compute(buf);
   };
   const bool sums = a.b_sums && m0 == 0;
   if (k_begin < k_end) {

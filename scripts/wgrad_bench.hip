@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
   const double flop = 2.0 * M * N * (double)K * batch;
   auto report = [&](const char* name, float ms, int reps) { printf("%-28s %8.1f us  %7.1f TFLOP/s (fp32-equivalent)\n", name, ms / reps * 1e3, flop / (ms / reps * 1e-3) / 1e12); };
   {
-    WgradSplitArgs a; a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.kslice = kslice; a.S = S; a.bsA = hA.size(); a.bsB = hB.size(); a.sa = 1.0f; a.sb = sb; a.Cpart = Cp; a.csz = (size_t)M * N; a.b_sums = 0;
+    WgradSplitArgs a; a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.kslice = kslice; a.S = S; a.bsA = hA.size(); a.bsB = hB.size(); a.sa = 1.0f; a.sb = sb; a.Cpart = Cp; a.csz = (size_t)M * N; a.b_sums = 0; a.plain = getenv("PLAIN") ? 1 : 0;
     a.tm = (M + 127) / 128; a.tn = (N + (N >= 256 ? 127 : 63)) / (N >= 256 ? 128 : 64);
     const bool big = N >= 256;
     const bool w8 = getenv("W8") != nullptr;      // 8 waves, 256 x 128 tiles
