@@ -1,12 +1,15 @@
 // Diagnostic (not part of the product): the weight-gradient GEMMs of csrc/glowk_train.h alone, on random planar operands of a
 // level-0 shape, with a row stride (ld) that can differ from K -- what bounds them?
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Iaudiosourcesep_amd/csrc scripts/wgrad_bench.hip -o scripts/wgrad_bench.bin
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Iaudiosourcesep_amd/csrc -Iscripts scripts/wgrad_bench.hip -o scripts/wgrad_bench.bin
+//   DMA=1: also the pre-split / LDS-DMA form of the square GEMM (scripts/wgrad_dma.h, an experiment)
 //   ./scripts/wgrad_bench.bin [M N K S]
 #include "glowk_train.h"
+#include "wgrad_dma.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 #include <cmath>
+#include <cstring>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 int main(int argc, char** argv) {
@@ -59,6 +62,51 @@ int main(int argc, char** argv) {
       worst = std::fmax(worst, std::fabs(r - hC[(size_t)m * N + n])); scale = std::fmax(scale, std::fabs(r));
     }
     printf("   max |C - fp64| / max |C| over 64 entries: %.2e\n", worst / scale);
+  }
+  if (getenv("DMA") && M % 128 == 0 && N % 128 == 0 && K % 32 == 0) {
+    // the pre-split form: hi / lo fp16 planes (what the storing launches write with NetArgs::st1_h16), staged by LDS-DMA
+    std::vector<unsigned short> pA(2 * hA.size()), pB(2 * hB.size());
+    auto splitv = [](const std::vector<float>& v, float sc, std::vector<unsigned short>& o) {
+      for (size_t i = 0; i < v.size(); ++i) {
+        const _Float16 hi = (_Float16)(v[i] * sc), lo = (_Float16)(v[i] * sc - (float)hi);
+        memcpy(&o[i], &hi, 2); memcpy(&o[v.size() + i], &lo, 2);
+      }
+    };
+    splitv(hA, 1.0f, pA); splitv(hB, 1.0f, pB);
+    unsigned short *dA, *dB;
+    CK(hipMalloc(&dA, pA.size() * 2 * batch)); CK(hipMalloc(&dB, pB.size() * 2 * batch));
+    for (int b = 0; b < batch; ++b) {
+      CK(hipMemcpy(dA + (size_t)b * pA.size(), pA.data(), pA.size() * 2, hipMemcpyHostToDevice));
+      CK(hipMemcpy(dB + (size_t)b * pB.size(), pB.data(), pB.size() * 2, hipMemcpyHostToDevice));
+    }
+    WgradDmaArgs a; a.A = dA; a.B = dB; a.loA = hA.size(); a.loB = hB.size(); a.M = M; a.N = N; a.K = K; a.kslice = kslice; a.S = S;
+    a.bsA = 2 * hA.size(); a.bsB = 2 * hB.size(); a.Cpart = Cp; a.csz = (size_t)(M + 1) * N; a.b_sums = 1;
+    const bool big8 = M % 256 == 0;
+    const int TM = big8 ? 256 : 128, TN = 128;
+    a.tm = M / TM; a.tn = N / TN;
+    CK(hipFree(Cp)); CK(hipMalloc(&Cp, (size_t)batch * S * (M + 1) * N * 4)); a.Cpart = Cp;
+    dim3 grid(a.tm * a.tn * S * batch);
+    auto go = [&]() { if (big8) hipLaunchKernelGGL((k_wgrad_h3d<2, 2, 4, 2>), grid, dim3(512), 0, 0, a); else hipLaunchKernelGGL((k_wgrad_h3d<2, 2, 2, 2>), grid, dim3(256), 0, 0, a); };
+    for (int it = 0; it < 3; ++it) go();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int it = 0; it < 20; ++it) go();
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    report("k_wgrad_h3d (pre-split, DMA)", ms, 20);
+    std::vector<float> hC((size_t)S * (M + 1) * N);
+    CK(hipMemcpy(hC.data(), Cp, hC.size() * 4, hipMemcpyDeviceToHost));
+    double worst = 0, scale = 0, wsum = 0, ssum = 0;
+    for (int t = 0; t < 64; ++t) {
+      const int m = (t * 37) % M, n = (t * 101) % N;
+      double r = 0, rs = 0, c = 0, cs = 0;
+      for (int k = 0; k < K; ++k) { r += (double)hA[(size_t)m * K + k] * hB[(size_t)n * K + k]; rs += hB[(size_t)n * K + k]; }
+      for (int sl = 0; sl < S; ++sl) { c += hC[(size_t)sl * (M + 1) * N + (size_t)m * N + n]; cs += hC[(size_t)sl * (M + 1) * N + (size_t)M * N + n]; }
+      worst = std::fmax(worst, std::fabs(r - c)); scale = std::fmax(scale, std::fabs(r));
+      wsum = std::fmax(wsum, std::fabs(rs - cs)); ssum = std::fmax(ssum, std::fabs(rs));
+    }
+    printf("   max |C - fp64| / max |C| over 64 entries: %.2e   row sums of B: %.2e of the largest\n", worst / scale, wsum / ssum);
+    return 0;
   }
   if (batch == 1) {
     WgradArgs a; a.A = A; a.B = B; a.M = M; a.N = N; a.a_ones = 0; a.K = K; a.kslice = kslice; a.Cpart = Cp; a.S = S; a.bsA = 0; a.bsB = 0; a.csz = (size_t)M * N;
