@@ -23,6 +23,8 @@ python bench.py --workload basis --basis-crop 64 --steps 20 --warmup 3 > $O/r03_
 echo "basis done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r03_prof_train -- python3 bench.py --workload train --precision f16x3 --batch 32 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>> $O/r03_prof.err
 cp $(find $O/r03_prof_train -name "*kernel_stats.csv" | head -1) $O/r03_train_kernel_stats.csv; rm -rf $O/r03_prof_train
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/r03_prof_train256 -- python3 bench.py --workload train --precision f16x3 --batch 256 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>> $O/r03_prof.err
+cp $(find $O/r03_prof_train256 -name "*kernel_stats.csv" | head -1) $O/r03_train256_kernel_stats.csv; rm -rf $O/r03_prof_train256
 GLOWK_AB_N=30 GLOWK_GRAD=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r03_prof_small -- python3 scripts/small_batch.py > $O/r03_small_batch.log 2>> $O/r03_prof.err
 cp $(find $O/r03_prof_small -name "*kernel_stats.csv" | head -1) $O/r03_grad30_kernel_stats.csv; rm -rf $O/r03_prof_small
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r03_prof_basis -- python3 bench.py --workload basis --basis-levels 3 --basis-train-steps 30 --basis-T 20 --steps 10 --warmup 2 > /dev/null 2>> $O/r03_prof.err
