@@ -118,14 +118,15 @@ def test_fused_saving_pass_feeds_the_backward_sweep(name):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
-@pytest.mark.parametrize("shape", ["64x64_L3", "32x32_L2_notop"])
+@pytest.mark.parametrize("shape", ["64x64_L3", "32x32_L2_notop", "24x24_L2_ragged"])
 def test_one_lane_per_pixel_backward_merge_equals_the_four_lane_form(precision, shape):
     """k_bwd_light<C, 1> (grids of >= 2 x CUs 256-pixel workgroups: coalesced planar gathers, 16-byte row accesses) against the
     four-lanes-per-pixel form of the same launch (GLOWK_BWD_LIGHT_4=1): the nine taps are added in another order, nothing else
     differs -- input gradient and parameter gradient to fp32 rounding, and the input gradient against fp64 autograd on a few tiles."""
     from oracle import glowref_torch as RT
     cfg, n = {"64x64_L3": (GlowConfig(H=64, W=64, C=1, L=3, K=2, F=512), 600),            # level 0 AND level 1 take the one-lane form
-              "32x32_L2_notop": (GlowConfig(H=32, W=32, C=1, L=2, K=3, F=256, learntop=False), 530)}[shape]
+              "32x32_L2_notop": (GlowConfig(H=32, W=32, C=1, L=2, K=3, F=256, learntop=False), 530),
+              "24x24_L2_ragged": (GlowConfig(H=24, W=24, C=1, L=2, K=2, F=128), 950)}[shape]   # 136 800 pixels: a partial last workgroup
     eng, params = calibrated_engine(cfg, device=0, init_tiles=32)
     eng.set_precision({"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3}[precision])
     eng.set_range_policy("error")
