@@ -156,6 +156,10 @@ CASES = {
     "L4": GlowConfig(H=16, W=16, C=1, L=4, K=2, F=128),
     "notop_logit": GlowConfig(H=8, W=8, C=1, L=2, K=2, F=128, learntop=False, use_logit=True, alpha=1e-4),
     "config_A": CONFIG_A,
+    # more than one input channel (build_glow takes any data_shape, flow_builder.py:60-75): level channel counts 4 C 2^l within {4, .., 32}
+    "C2_L3": GlowConfig(H=16, W=16, C=2, L=3, K=2, F=128),
+    "C4_L2_rect": GlowConfig(H=8, W=16, C=4, L=2, K=2, F=128),
+    "C2_L2_notop": GlowConfig(H=8, W=8, C=2, L=2, K=3, F=256, learntop=False),
 }
 
 
@@ -182,6 +186,34 @@ def test_log_prob_forward_inverse_vs_oracle(gpu, name):
     np.testing.assert_allclose(eng.inverse(dev(z_ref)).cpu().numpy(), R.bijector_inverse(z_ref, pr, cfg.as_dict()), atol=5e-3)
     # prior alone
     np.testing.assert_allclose(eng.prior_log_prob(dev(z_ref)).cpu().numpy(), R.prior_log_prob(z_ref, pr, cfg.as_dict()), rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["C2_L3", "C4_L2_rect"])
+def test_multi_channel_inputs_in_every_arithmetic(gpu, name):
+    """C > 1 (stereo / stacked spectrograms): the split arithmetics and the input gradient (levels of 8, 16, 32 channels from the first
+    block on), against the fp64 oracle and its autograd; parameter gradients against the exact kernels."""
+    from audiosourcesep_amd import _lib
+    from oracle import glowref_torch as RT
+    cfg = CASES[name]
+    eng, params = make_engine(gpu, cfg)
+    x = synthetic_mel_tiles(7, cfg, seed=3)
+    lp_ref, g_ref = RT.log_prob_and_grad(x.astype(np.float64), params, cfg.as_dict())
+    scale = np.abs(g_ref).max()
+    grads = {}
+    for prec, rt, at in (("f32", 1e-6, 2e-5), ("f16x3", 2e-6, 2e-4), ("f16x2", 1e-4, 5e-3)):
+        eng.set_precision({"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3, "f16x2": _lib.PREC_F16X2}[prec])
+        eng.set_range_policy("error")
+        lp, g = eng.log_prob_grad(dev(x))
+        np.testing.assert_allclose(lp.cpu().numpy(), lp_ref, rtol=rt, err_msg=prec)
+        np.testing.assert_allclose(eng.log_prob(dev(x)).cpu().numpy(), lp_ref, rtol=rt, err_msg=prec)
+        np.testing.assert_allclose(g.cpu().numpy(), g_ref, atol=at * scale, rtol=2e-3, err_msg=prec)
+        z = eng.forward(dev(x))[0]
+        np.testing.assert_allclose(eng.inverse(z).cpu().numpy(), x, atol=0.3 if prec == "f16x2" else 2e-2)
+        if prec != "f16x2":
+            grads[prec] = eng.param_grad(dev(x), -1.0 / 7)[1].cpu().numpy()
+    d = np.abs(grads["f16x3"] - grads["f32"]).max() / np.abs(grads["f32"]).max()
+    print(name, "parameter gradient f16x3 vs f32: %.1e of the largest entry" % d)
+    assert d < 2e-4
 
 
 def test_sample_round_trip(gpu):
