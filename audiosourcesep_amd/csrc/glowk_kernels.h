@@ -1208,6 +1208,9 @@ __device__ __forceinline__ void h3s_Y(const float4* slot, const h8 (&bh)[2], con
   const char* mb = uniform_ptr(main_src);
   constexpr int NG = G::NRB / 2;
   constexpr int PPG = G::MAINP / 4 / NG;            // DMA pieces per wave and group
+#ifdef GLOWK_EXP_YPRIO   // (A/B build: the wave in its matrix phase outranks its SIMD partner, which is in the VALU-heavy X phase)
+  __builtin_amdgcn_s_setprio(1);
+#endif
   h8 A[2][4];
   auto load = [&](h8 (&d)[4], int gi) {
     d[0] = buf[((2 * gi) * 2 + 0) * 64];            // row block 2gi hi, lo; row block 2gi+1 hi, lo
@@ -1254,6 +1257,9 @@ __device__ __forceinline__ void h3s_Y(const float4* slot, const h8 (&bh)[2], con
     if constexpr (G::PXH == 2) acc2[o1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2], bh[1], acc2[o1][1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
+#ifdef GLOWK_EXP_YPRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 // Z: conv3 op z of a pass = half a chunk of A tiles (16 rows x one hidden block)
@@ -1585,6 +1591,9 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
   __syncthreads();
 
   f32x4 keep[G::G0N][2];     // pass 0's partial sums of P (RingS::MERGE; otherwise never touched and compiled away)
+#ifdef GLOWK_EXP_STATICPRIO   // (A/B build: the younger half of the workgroup -- group 1 -- outranks its SIMD partners for good)
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
   if (g) h3_barrier();
   if constexpr (SPLIT) {
     if (solo_pass == 0) h3s_pass<KIN, MOUT, NF, MODE, NP, 0, 0, true>(a, c, epl, xh, xl, g, q, qok, lane, kq, keep);
