@@ -67,3 +67,27 @@ def test_trained_noise_conditioned_priors_run_the_basis_ladder_in_f16x3():
     # the chain's own noise makes the state at the smallest sigma a sample, not a point estimate; it must still sit near the mixture
     mix = basis.mixing_db(y1, y2)
     assert float((mix - mixed).abs().mean()) < 6.0
+    # Sharding (BASELINE config 5 on several GPUs: each rank holds a slice of the mixture tiles, no collective inside the loop): a rank
+    # that runs tiles [a, b) with tile_offset = a walks the chain the one-process run walks for those tiles -- the same noise (the
+    # offset is part of the Philox counter) and the same priors; the gradients differ only by the launch forms a smaller batch picks
+    # (another summation order, ~1e-7), which a short chain does not amplify beyond a few thousandths of a dB.
+    sig2 = sig_db[-2:]
+    s1 = -100.0 + 120.0 * basis.device_randn(tuple(mixed.shape), mixed.device, seed=21, which=0, uniform=True)
+    s2 = -100.0 + 120.0 * basis.device_randn(tuple(mixed.shape), mixed.device, seed=21, which=1, uniform=True)
+    w1, w2, _ = basis.basis_outer_loop(mixed, s1.clone(), s2.clone(), priors[0], priors[1], sig2, restore_1=ladders[0], restore_2=ladders[1], T=8,
+                                       delta=delta_db, seed=5)
+    worst, mean = 0.0, 0.0
+    for a, b in ((0, 8), (8, 19), (19, 30)):                       # three ragged "ranks"
+        r1, r2, _ = basis.basis_outer_loop(mixed[a:b].contiguous(), s1[a:b].clone(), s2[a:b].clone(), priors[0], priors[1], sig2,
+                                           restore_1=ladders[0], restore_2=ladders[1], T=8, delta=delta_db, seed=5, tile_offset=a)
+        worst = max(worst, float((r1 - w1[a:b]).abs().max()), float((r2 - w2[a:b]).abs().max()))
+        mean = max(mean, float((r1 - w1[a:b]).abs().mean()), float((r2 - w2[a:b]).abs().mean()))
+    # a shard run WITHOUT its offset draws other noise: sigma_L alone moves the state by ~1 dB per step
+    q1, _, _ = basis.basis_outer_loop(mixed[8:19].contiguous(), s1[8:19].clone(), s2[8:19].clone(), priors[0], priors[1], sig2,
+                                      restore_1=ladders[0], restore_2=ladders[1], T=8, delta=delta_db, seed=5, tile_offset=0)
+    wrong = float((q1 - w1[8:19]).abs().mean())
+    print("sharded chain (3 shards, 2 levels x T = 8) vs the whole batch: |difference| mean %.2e dB, max %.2e dB (an isolated ReLU decision "
+          "that falls differently moves one tile); without the tile offset: mean %.2e dB" % (mean, worst, wrong))
+    assert mean < 2e-3 and worst < 0.5 and wrong > 100 * mean
+    for e in engines:
+        assert e.range_status() == (False, 0)
