@@ -60,6 +60,7 @@ _vp, _i, _fp = ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float)
 SYMBOLS = {
     "glowk_version": (_i, []),
     "glowk_last_error": (ctypes.c_char_p, []),
+    "glowk_reload_env": (None, []),
     "glowk_create": (_i, [ctypes.POINTER(GlowkConfigStruct), _i, ctypes.POINTER(_vp)]),
     "glowk_destroy": (_i, [_vp]),
     "glowk_tensor_size": (ctypes.c_size_t, [_vp, _i, _i]),

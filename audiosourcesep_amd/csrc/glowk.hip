@@ -155,6 +155,14 @@ bool h3_shape16() {
   return v == 1;
 }
 void launch_fail(const std::string& m) { fail(m); }
+static EnvSwitches read_env() {
+  auto on = [](const char* n) { return getenv(n) != nullptr; };
+  return EnvSwitches{on("GLOWK_HALF_OFF"), on("GLOWK_HALF_FORCE"), on("GLOWK_FAM16_SMALL"), on("GLOWK_BWD_LIGHT_4"), on("GLOWK_COUPLE_PER_SAMPLE"),
+                     on("GLOWK_COUPLE_4"), on("GLOWK_NO_FUSE"), on("GLOWK_WGRAD_PLAIN"), on("GLOWK_WGRAD_128"), on("GLOWK_CO_OFF")};
+}
+static EnvSwitches g_env = read_env();
+const EnvSwitches& env() { return g_env; }
+void reload_env() { g_env = read_env(); }
 thread_local int g_family = 0;
 void note_family(int family) { g_family = family; }
 // instantiated in glowk_net_inst.hip, one translation unit per (CI, NF)
@@ -235,11 +243,11 @@ int launch_net(glowk_handle* h, int level, int c, int F, const NetArgs& a, hipSt
 // light backward kernel of one step: 16 lanes per pixel where the batch is small and the level deep (few pixels, many channels and
 // partial buffers: the gathers' dependent loads are what the launch waits for), one where the grid is large, else 4
 int launch_bwd_light(int c, const BwdArgs& a, int N, hipStream_t s) {
-  const bool wide = c >= 8 && (a.Q + 15) / 16 <= 8 * num_cus() && !getenv("GLOWK_BWD_LIGHT_4");
+  const bool wide = c >= 8 && (a.Q + 15) / 16 <= 8 * num_cus() && !glowk_detail::env().bwd_light_4;
   // large grids: one lane per pixel (the planar Pg gathers and the 16-byte rows of the [Q][C] arrays are then fully coalesced)
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool one = (a.Q + 255) / 256 >= 2 * num_cus() && al16(a.ghalf_in) && al16(a.v) && al16(a.osave) && al16(a.g_o) && al16(a.ghalf_out) &&
-                   al16(a.gu_out) && al16(a.gv_out) && !getenv("GLOWK_BWD_LIGHT_4");
+                   al16(a.gu_out) && al16(a.gv_out) && !glowk_detail::env().bwd_light_4;
   if (one) { CDISPATCH(c, hipLaunchKernelGGL((k_bwd_light<CC, 1>), dim3((a.Q + 255) / 256), dim3(256), 0, s, a)); }
   else if (wide) { CDISPATCH(c, hipLaunchKernelGGL((k_bwd_light<CC, 16>), dim3((a.Q + 15) / 16), dim3(256), 0, s, a)); }
   else { CDISPATCH(c, hipLaunchKernelGGL((k_bwd_light<CC, 4>), dim3((a.Q + 63) / 64), dim3(256), 0, s, a)); }
@@ -252,13 +260,13 @@ struct FlatLd { double* slot; int stride, base; };
 
 int launch_couple(int c, const CoupleArgs& a, int N, hipStream_t s, const FlatLd* fl = nullptr, bool* flat_used = nullptr) {
   const int hw = a.h * a.w;
-  if (N < 2 * num_cus() && hw % 64 == 0 && (!a.logdet || (fl && fl->slot)) && !getenv("GLOWK_COUPLE_PER_SAMPLE")) {
+  if (N < 2 * num_cus() && hw % 64 == 0 && (!a.logdet || (fl && fl->slot)) && !glowk_detail::env().couple_per_sample) {
     // few samples: a flat grid over the pixels instead of one workgroup per sample (30 tiles: 30 workgroups on 256 CUs); sixteen
     // lanes per pixel where the level is deep (c >= 8) and small
     CoupleArgs b = a;
     b.logdet = nullptr;
     double* slots = a.logdet ? fl->slot : (double*)nullptr;
-    const bool wide = c >= 8 && (a.Q + 15) / 16 <= 8 * num_cus() && !getenv("GLOWK_COUPLE_4");
+    const bool wide = c >= 8 && (a.Q + 15) / 16 <= 8 * num_cus() && !glowk_detail::env().couple_4;
     if (wide) { CDISPATCH(c, hipLaunchKernelGGL((k_couple_flat<CC, 16>), dim3((a.Q + 15) / 16), dim3(256), 0, s, b, slots, fl ? fl->stride : 0, fl ? fl->base : 0)); }
     else { CDISPATCH(c, hipLaunchKernelGGL((k_couple_flat<CC, 4>), dim3((a.Q + 63) / 64), dim3(256), 0, s, b, slots, fl ? fl->stride : 0, fl ? fl->base : 0)); }
     LAUNCHCHK("k_couple_flat");
@@ -288,7 +296,7 @@ bool fuse_geometry_ok(int h, int w) {
 
 int net_and_couple(glowk_handle* h, int lvl, int c, int F, NetArgs na, CoupleArgs ca, int N, hipStream_t s, int mode, const FlatLd* fl = nullptr,
                    bool* flat_used = nullptr) {
-  const bool no_fuse = getenv("GLOWK_NO_FUSE") != nullptr;     // (A/B timing and the fused-vs-unfused parity test: read per call)
+  const bool no_fuse = glowk_detail::env().no_fuse;            // (A/B timing and the fused-vs-unfused parity test, which calls glowk_reload_env)
   const int hw = ca.h * ca.w;
   if (!no_fuse && c == 4 && (mode == 3 || mode == 6 || mode == 4) && na.RSp && ca.vin && !ca.log_s_out && ca.out && na.in_stride == 4 &&
       ca.out_stride % 4 == 0 && ca.out_off % 4 == 0 && fuse_geometry_ok(ca.h, ca.w) && na.P == h->bufP) {
@@ -346,10 +354,15 @@ WsSizes ws_sizes(const glowk_handle* h, size_t N) {
 // pixel blocks of the ReLU-mask arrays of a level with Q pixels (one 16-bit entry per lane, hidden block and pixel block of a wave):
 // 32-pixel blocks of whole 256-pixel workgroups -- or 16-pixel blocks of 128-pixel workgroups where the launch policy may pick the
 // half-wave form of the 16x16x32 family (glowk_launch.h: use_half -- small grids, and the 32-channel level at any size)
+// MONOTONE in Q (round-3 advisor): the per-step offsets (offM) are laid out once for the largest batch a handle has seen and a later,
+// smaller call computes its own mask2 = mask1 + blocks inside that layout -- so a smaller Q must never need MORE blocks.  The
+// half-wave form needs ceil(Q / 128) * 8 blocks up to the largest Q the policy picks it for (Qh = 256 * floor(CUs / 8) pixels) and
+// the 256-pixel form ceil(Q / 256) * 8 beyond: the bound is the larger of the latter and the former capped at Qh.
 size_t mask_blocks(const Level& lv, size_t Q) {
   const size_t b256 = ((Q + 255) / 256) * 8;
-  if (lv.c == 32 || (Q + 255) / 256 * 8 <= (size_t)num_cus()) return std::max(b256, ((Q + 127) / 128) * 8);
-  return b256;
+  if (lv.c == 32) return ((Q + 127) / 128) * 8;
+  const size_t Qh = (size_t)256 * (size_t)(num_cus() / 8);
+  return std::max(b256, ((std::min(Q, Qh) + 127) / 128) * 8);
 }
 
 struct SaveSizes {    // input-gradient path for N tiles: per-step saves + scratch
@@ -699,7 +712,7 @@ int ensure_train(glowk_handle* h, int N) {
 // the split GEMM, by a k_rowsum pass after the exact one.
 int launch_wgrad(glowk_handle* h, bool split, const float* A, ptrdiff_t bsA, int M, const float* B, ptrdiff_t bsB, int N, int K, int nb, float sa, float sb,
                  float* C, size_t csC, bool b_sums, hipStream_t s) {
-  const bool big = split ? N >= 256 : (M >= 256 && N >= 256 && getenv("GLOWK_WGRAD_128"));   // (fp32: 128 x 128 tiles measured 5 % slower than 64 x 64)
+  const bool big = split ? N >= 256 : (M >= 256 && N >= 256 && glowk_detail::env().wgrad_128);   // (fp32: 128 x 128 tiles measured 5 % slower than 64 x 64)
   const bool big8 = split && big && M % 256 == 0;   // 8 waves, 256 x 128: a quarter less staging per MFMA (254 -> 290 TFLOP/s on the level-0 conv2 batch)
   const int TM = big8 ? 256 : split ? 128 : big ? 128 : 64, TN = split ? (big ? 128 : 64) : TM;
   const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN, tiles = tm * tn;
@@ -718,7 +731,7 @@ int launch_wgrad(glowk_handle* h, bool split, const float* A, ptrdiff_t bsA, int
   if (split) {
     WgradSplitArgs a;
     a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.kslice = kslice; a.S = S; a.tm = tm; a.tn = tn; a.bsA = bsA; a.bsB = bsB; a.sa = sa; a.sb = sb;
-    a.Cpart = out; a.csz = csz; a.b_sums = b_sums ? 1 : 0; a.plain = getenv("GLOWK_WGRAD_PLAIN") ? 1 : 0;
+    a.Cpart = out; a.csz = csz; a.b_sums = b_sums ? 1 : 0; a.plain = glowk_detail::env().wgrad_plain ? 1 : 0;
     const dim3 grid((unsigned)(tiles * S * nb));
     if (big8 && vec) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 4, 2, true>), grid, dim3(512), 0, s, a);
     else if (big8) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 4, 2, false>), grid, dim3(512), 0, s, a);
@@ -1193,6 +1206,7 @@ void affine_chain_rule(const Level& lv, int k, const double* sums, int N, double
 extern "C" {
 
 int glowk_version(void) { return GLOWK_VERSION; }
+void glowk_reload_env(void) { glowk_detail::reload_env(); }
 const char* glowk_last_error(void) { return g_err.c_str(); }
 
 int glowk_create(const glowk_config* cfg, int device, glowk_handle** out) {
@@ -1649,15 +1663,20 @@ int glowk_log_prob_sum(glowk_handle* h, const float* x_dev, int N, float* logp_d
   if (!x_dev || !logp_dev || !sum_dev) return fail("null tensor");
   hipStream_t s = (hipStream_t)stream;
   float* z = z_dev ? z_dev : h->bufZ;
-  return guarded(h, s, [&]() -> int {
+  // The reduction runs AFTER the range guard has accepted the call (round-3 advisor): inside the guarded lambda a tripped call's
+  // rejected partial sum would already sit in *sum_dev when the fp32 re-run of the FALLBACK policy adds its own (accumulate != 0:
+  // double-counted or NaN), and under the ERROR policy *sum_dev would be left modified by a call that reports failure.
+  const int rc = guarded(h, s, [&]() -> int {
     if (int rc = run_forward(h, x_dev, N, z, s)) return rc;
     hipLaunchKernelGGL(k_prior, dim3(N), dim3(256), 0, s, (const float*)z, h->Hl * h->Wl * h->Cl, h->d_loc, h->d_log_scale,
                        (const double*)h->bufLd, logp_dev, (float*)nullptr);
     LAUNCHCHK("k_prior");
-    hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(1024), 0, s, (const float*)logp_dev, (size_t)N, sum_dev, accumulate, 1.0);
-    LAUNCHCHK("k_sum_f64");
     return 0;
   });
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(1024), 0, s, (const float*)logp_dev, (size_t)N, sum_dev, accumulate, 1.0);
+  LAUNCHCHK("k_sum_f64");
+  return 0;
 }
 
 int glowk_sum_f64(const float* v_dev, size_t n, double* out_dev, int accumulate, double scale, void* stream) {

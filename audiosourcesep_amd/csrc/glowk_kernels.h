@@ -531,9 +531,12 @@ __device__ __forceinline__ void stage4(const float4* __restrict__ src, float4* d
 // (glowk.hip: step_range_limits) and hands the kernel the input magnitude `xlim` up to which no split can leave the fp16
 // range; the kernel only checks the inputs it gathers (prologue, once per pixel).  Conservative (a worst-case bound: it may
 // send a legitimate call to the fp32 kernels), never silent.
+// (nan_max: v_max_f32 / fmaxf return the non-NaN operand, which would make a NaN input invisible to the guard -- round-3 advisor;
+//  this maximum keeps a NaN from either side, so `!(xmax <= xlim)` fires on it.  Prologue only: once per gathered value.)
+__device__ __forceinline__ float nan_max(float a, float b) { return (a > b || a != a) ? a : b; }
 __device__ __forceinline__ float range8(float m, const float (&v)[8]) {
 #pragma unroll
-  for (int j = 0; j < 8; j += 2) m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(v[j]), __builtin_fabsf(v[j + 1])));
+  for (int j = 0; j < 8; ++j) m = nan_max(m, __builtin_fabsf(v[j]));
   return m;
 }
 
@@ -974,7 +977,7 @@ __global__ __launch_bounds__(512, 2) void k_net_h3(NetArgs a) {
         gather8<KIN, false, SGN>(base, i, j0, a.h, a.w, a.in_stride, qok, 16 * s + 8 * hh, v[s]);
         xmax = range8(xmax, v[s]);
       }
-      xmax = fmaxf(xmax, __shfl_xor(xmax, 32, 64));
+      xmax = nan_max(xmax, __shfl_xor(xmax, 32, 64));
       // (training, MODE & 8: the hiddens this launch stores feed GEMMs over ALL pixels, so one scale has to serve the whole
       //  launch -- the producer pre-scaled g_o by a host-chosen power of two, BwdArgs::go_scale, and the static bound xlim checks it)
       const float fac = (MODE & 8) ? 1.0f : pixel_norm(xmax, a.bnorm, c.ub[0]);
@@ -1555,9 +1558,9 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
           gather8<KIN, false, SGN>(base, i, j0, a.h, a.w, a.in_stride, qok[hf], 32 * s + 8 * kq, v[s]);
           pm = range8(pm, v[s]);
         }
-        pm = fmaxf(pm, __shfl_xor(pm, 16, 64));
-        pm = fmaxf(pm, __shfl_xor(pm, 32, 64));
-        xmax = fmaxf(xmax, pm);
+        pm = nan_max(pm, __shfl_xor(pm, 16, 64));
+        pm = nan_max(pm, __shfl_xor(pm, 32, 64));
+        xmax = nan_max(xmax, pm);
         const float fac = (MODE & 8) ? 1.0f : pixel_norm(pm, a.bnorm, c.ub[hf]);     // (training: one scale per launch, BwdArgs::go_scale)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {

@@ -16,6 +16,23 @@ void note_family(int family);           // which kernel family a (non-dry) launc
 bool h3_shape16();                      // GLOWK_H3_SHAPE=32 keeps the forward pass on the 32x32x16 kernel (A/B timing); glowk.hip
 void launch_fail(const std::string&);   // sets glowk_last_error(); glowk.hip
 
+// Diagnostic switches (A/B timing, parity tests of one launch form against another): environment variables, read ONCE -- when the
+// library is loaded and again by glowk_reload_env() -- not per launch (round-3 verdict: six getenv() scans per flow step sat on the
+// latency-bound path, ~1 200 per 30-tile gradient call).  glowk.hip owns the instance.
+struct EnvSwitches {
+  bool half_off;            // GLOWK_HALF_OFF: never the half-wave form where another one exists
+  bool half_force;          // GLOWK_HALF_FORCE: the half-wave form of the plain forward network at every grid size
+  bool fam16_small;         // GLOWK_FAM16_SMALL: the 16x16x32 family of the gradient path at every grid size
+  bool bwd_light_4;         // GLOWK_BWD_LIGHT_4: k_bwd_light with four lanes per pixel whatever the grid
+  bool couple_per_sample;   // GLOWK_COUPLE_PER_SAMPLE: k_couple (one workgroup per sample) instead of the flat grid
+  bool couple_4;            // GLOWK_COUPLE_4: k_couple_flat with four lanes per pixel whatever the level
+  bool no_fuse;             // GLOWK_NO_FUSE: network + coupling as two kernels at the 4-channel level
+  bool wgrad_plain;         // GLOWK_WGRAD_PLAIN: the weight-gradient GEMM's plain (not fenced) round
+  bool wgrad_128;           // GLOWK_WGRAD_128: 128 x 128 tiles in the exact weight-gradient GEMM
+  bool co_off;              // GLOWK_CO_OFF: never the co-resident (two workgroups per CU) form of the fused kernel
+};
+const EnvSwitches& env();
+
 // k_net_h3 / k_net_h3s launch forms.  NP = passes over the hidden width (2, or 4 where the shape needs the registers);
 // when NP workgroups per 256 pixels still fit the CUs in one round the passes become workgroups of their own (SPLIT):
 // 1/NP of the latency per launch.  Returns the number of partial P buffers the launch writes (= NP), 0 if no instance fits.
@@ -89,7 +106,7 @@ int launch_h3s(const NetArgs& a, hipStream_t s, bool dry) {
 // still leave half the CUs idle (latency-bound grids: the deeper levels at the reference's batch sizes of 30 / 32 tiles), and for
 // shapes whose small-conv fragments only fit the registers at one half per wave (the 32-channel level's backward network: K = 288).
 inline bool half_wave_grid(const NetArgs& a) {
-  if (getenv("GLOWK_HALF_OFF")) return false;       // (A/B timing and diagnostics; read per launch decision)
+  if (env().half_off) return false;                 // (A/B timing and diagnostics)
   return 8 * ((a.Q + 255) / 256) <= num_cus();
 }
 
@@ -149,7 +166,7 @@ inline bool use_half(const NetArgs& a) {
 // into passes and latency-bound).  Both launches of a level see the same pixel count, so they decide alike.
 // (re-measured in round 3 with GLOWK_FAM16_SMALL=1 -- the 16x16x32 family at every grid size: 8.72 vs 8.72 ms for the gradient of 30
 //  tiles, within +-1 % at 8 ... 128 tiles: no reason to change the rule the fuzz runs validated)
-inline bool big_grid(const NetArgs& a) { return 2 * ((a.Q + 255) / 256) > num_cus() || getenv("GLOWK_FAM16_SMALL"); }
+inline bool big_grid(const NetArgs& a) { return 2 * ((a.Q + 255) / 256) > num_cus() || env().fam16_small; }
 
 template <int CI, int NF>
 constexpr bool fam16_ok() {
@@ -182,7 +199,7 @@ int launch_net_t(const NetArgs& a, int mode, hipStream_t s, bool dry) {
     case 9:            if (!dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE, true>), dim3(ntiles), dim3(256), 0, s, a); break;   // saving forward pass that keeps its hiddens
     case 3:   // f16x3 arithmetic: forward / forward with saves / backward; shapes without an instance run the exact fp32 kernel
       // (GLOWK_HALF_FORCE=1: the half-wave form at every grid size -- two 128-pixel workgroups per CU; an experiment)
-      if (a.RSp && h3_shape16() && ((half_wave_grid(a) && !a.fuse) || getenv("GLOWK_HALF_FORCE"))) np = launch_h3s_half<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
+      if (a.RSp && h3_shape16() && ((half_wave_grid(a) && !a.fuse) || env().half_force)) np = launch_h3s_half<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
       if (!np && a.RSp && h3_shape16()) np = launch_h3s<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
       if (!np && a.RHp) np = launch_h3<CI, 18 * CI, NF, NET_FWD>(a, s, dry);
       if (!np && !dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD>), dim3(ntiles), dim3(256), 0, s, a);

@@ -774,7 +774,7 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
             const float g_pre = (gya * sc * va + 1.0f) * (1.0f - log_s * log_s);
             bad |= not_finite(ok_);
             if (live) {
-              gomax = fmaxf(gomax, fmaxf(fabsf(g_pre), fabsf(gya)));
+              gomax = nan_max(gomax, nan_max(fabsf(g_pre), fabsf(gya)));   // (NaN-keeping: fmaxf would drop it)
               a.g_o[(size_t)q * C + ch] = g_pre * a.go_scale;
               a.g_o[(size_t)q * C + CI + ch] = gya * a.go_scale;
               a.ghalf_out[(size_t)q * C + ch] = gya * sc;
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(256) void k_bwd_light(BwdArgs a) {
         const float gya = gy[k];
         const float g_ls = gya * sc * va + 1.0f;          // + 1: d(sum log_s)/d log_s (flow_tfp_bijectors.py:150-153)
         const float g_pre = g_ls * (1.0f - log_s * log_s); // through tanh
-        gomax = fmaxf(gomax, fmaxf(fabsf(g_pre), fabsf(gya)));
+        gomax = nan_max(gomax, nan_max(fabsf(g_pre), fabsf(gya)));   // (NaN-keeping: fmaxf would drop it)
         go_[k] = g_pre * a.go_scale;
         go_[CI + k] = gya * a.go_scale;                   // g_t
         gh_[k] = gya * sc;                                // g_va

@@ -182,6 +182,23 @@ def _timed_steps(step, steps, warmup, dist, rehearsal):
     return elapsed
 
 
+def logprob_workload(cfg, n, precision, steps, warmup, rank, local_rank, dist, rehearsal):
+    """log_prob over a resident batch of n tiles (n = 32: the reference's batch, configs/melspec_glow.yml:15), under GLOWK_RANGE_ERROR."""
+    from audiosourcesep_amd.synthetic import calibrated_engine
+    eng, _ = calibrated_engine(cfg, device=local_rank, init_tiles=n)
+    eng.set_precision(precision)
+    eng.set_range_policy("error")
+    eng.reserve(n)
+    x = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=1234 + rank)).cuda()
+    lp = torch.empty(n, device="cuda", dtype=torch.float32)
+    total = torch.zeros(1, device="cuda", dtype=torch.float64)
+    el = _timed_steps(lambda: eng.log_prob_sum(x, out=lp, total=total), steps, warmup, dist, rehearsal)
+    assert eng.range_status() == (False, 0), "the range guard fired"
+    assert torch.isfinite(total).all()
+    eng.close()
+    return el
+
+
 def grad_workload(cfg, n, precision, steps, warmup, rank, local_rank, dist, rehearsal):
     """log_prob + d/dx (compute_grad_logprob, run_basis_sep.py:73-79) over a resident batch, under GLOWK_RANGE_ERROR."""
     from audiosourcesep_amd.synthetic import calibrated_engine
@@ -223,7 +240,7 @@ def train_workload(cfg, n, precision, steps, warmup, rank, world, local_rank, di
     return el, fallbacks, pv
 
 
-def basis_workload(args, K, levels, train_steps, T, steps, warmup, rank, world, local_rank, dist, rehearsal, precision):
+def basis_workload(args, K, levels, train_steps, T, steps, warmup, rank, world, local_rank, dist, rehearsal, precision, sigma1=0.3):
     """BASELINE config 5 as it is meant: two noise-conditioned Glow priors (L = 3, n_filters = 512, K steps per level) are trained
     here with the repo's own training step on the reference's 30 real tiles per stem (tests/golden/basis_real_tiles.npz; the ladder
     of train_noisy_glow.py:309-358), kept resident per sigma, and the BASIS chain (run_basis_sep.py:217-260) runs on the 30 mixture
@@ -238,14 +255,15 @@ def basis_workload(args, K, levels, train_steps, T, steps, warmup, rank, world, 
     gt1, gt2, mixed = (torch.from_numpy(np.ascontiguousarray(f[k].astype(np.float32)[:, :crop]))[..., None].cuda() for k in ("gt1", "gt2", "mixed"))
     n = mixed.shape[0]
     t0 = time.perf_counter()
-    priors, ladders, fb_train = [], [], []
+    priors, ladders, fb_train, loss_curves = [], [], [], []
     for i, gt in enumerate((gt1, gt2)):
         flow = build_glow(gt, [crop, 64, 1], L=3, K=K, n_filters=512, learntop=True, seed=100 + i, precision=precision, actnorm_init="runtime",
                           device=local_rank, data_type="melspec", minval=-100.0, maxval=20.0, use_logit=False)
         flow.engine.set_range_policy("fallback")
-        sig_db, delta_db = db_schedule(flow.cfg, sigma1=0.3, sigmaL=0.01, num_classes=levels)
+        sig_db, delta_db = db_schedule(flow.cfg, sigma1=sigma1, sigmaL=0.01, num_classes=levels)
         models, losses = fine_tune_ladder(flow, gt, sig_db, [3 * train_steps] + [train_steps] * (levels - 1), lr=1e-3, seed=7 + i)
         assert all(np.isfinite(losses[float(s)]).all() for s in sig_db), "prior training diverged"
+        loss_curves.append({"%.3g" % float(s): [losses[float(s)][0], losses[float(s)][-1]] for s in sig_db})
         fb_train.append(flow.engine.range_status()[1])
         priors.append(flow)
         ladders.append(models)
@@ -260,10 +278,11 @@ def basis_workload(args, K, levels, train_steps, T, steps, warmup, rank, world, 
     x2 = -100.0 + 120.0 * basis.device_randn(tuple(mixed.shape), mixed.device, seed=11 + rank, which=1, uniform=True)
     start = (psnr_db(x1, gt1), psnr_db(x2, gt2))
     t0 = time.perf_counter()
-    y1, y2, _ = basis.basis_outer_loop(mixed, x1, x2, priors[0], priors[1], sig_db, restore_1=ladders[0], restore_2=ladders[1], T=T,
-                                       delta=delta_db, seed=3 + rank)
+    y1, y2, arr = basis.basis_outer_loop(mixed, x1, x2, priors[0], priors[1], sig_db, restore_1=ladders[0], restore_2=ladders[1], T=T,
+                                         delta=delta_db, seed=3 + rank)
     torch.cuda.synchronize()
     t_chain = time.perf_counter() - t0
+    psnr_levels = [(round(psnr_db(a, gt1), 2), round(psnr_db(b, gt2), 2)) for a, b in zip(arr["x1"], arr["x2"])]
     assert torch.isfinite(y1).all() and torch.isfinite(y2).all(), "the chain left the finite range"
     # timed region: consecutive steps at the last level, the state carried from call to call
     last = len(sig_db) - 1
@@ -290,9 +309,11 @@ def basis_workload(args, K, levels, train_steps, T, steps, warmup, rank, world, 
                         "largest_forward_input_over_limit": max(m[0] for m in margins), "backward_static_ratio": max(m[1] for m in margins),
                         "fallback_sweeps_while_training": fb_train},
         "priors": {"trained_here_s": t_train, "sigmas_db": [float(s) for s in sig_db], "delta_db2": delta_db,
-                   "train_steps_per_level": [3 * train_steps] + [train_steps] * (levels - 1)},
-        "chain": {"levels_x_T_s": t_chain, "tile_steps_per_s_whole_ladder": n * len(sig_db) * T / t_chain,
-                  "psnr_db_start": start, "psnr_db_end": end,
+                   "train_steps_per_level": [3 * train_steps] + [train_steps] * (levels - 1), "loss_first_last_per_sigma_db": loss_curves},
+        "chain": {"levels_x_T_s": t_chain, "langevin_steps": len(sig_db) * T, "tile_steps_per_s_whole_ladder": n * len(sig_db) * T / t_chain,
+                  "psnr_db_start": start, "psnr_db_end": end, "psnr_db_after_each_level": psnr_levels,
+                  "reference_wall_clock_s": {"value": 1411.5, "what": "the reference's own log of this separation (30 tiles, 10 sigma x T=100, NCSN priors, "
+                                                                       "its GPU): basis_sep_results/.../out.log:124 -- other priors, other hardware: context only"},
                   "psnr_db_reference_shipped_result": (psnr_db(f["x1"].astype(np.float32)[:, :crop], f["gt1"].astype(np.float32)[:, :crop]),
                                                        psnr_db(f["x2"].astype(np.float32)[:, :crop], f["gt2"].astype(np.float32)[:, :crop]))},
     }
@@ -323,7 +344,7 @@ def secondary_workload(args, cfg, rank, world, local_rank, dist, rehearsal, extr
                    roofline=grad_roofline(cfg, v / world, args.precision, 3))
     else:
         r = basis_workload(args, args.basis_K, args.basis_levels, args.basis_train_steps, args.basis_T, args.steps, args.warmup, rank, world,
-                           local_rank, dist, rehearsal, args.precision)
+                           local_rank, dist, rehearsal, args.precision, sigma1=args.basis_sigma1)
         out = dict(base, metric="BASIS Langevin tile-steps/sec (2 trained noise-conditioned Glow priors)", data="real mel tiles shipped with the reference (30 per stem); priors trained in this run", **r)
     out.update(extra)
     if rank == 0:
@@ -337,6 +358,41 @@ def grad_roofline(cfg, tiles_per_s_per_gpu, precision, fwd_multiples):
     ach = tiles_per_s_per_gpu * fwd_multiples * cfg.flop_per_tile() / 1e12
     return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
             "note": "%dx the forward pass's algorithmic FLOP per tile (%.2f GFLOP), whole step incl. light kernels and optimizer" % (fwd_multiples, cfg.flop_per_tile() / 1e9)}
+
+
+def summary_of(out):
+    """<= 1 500 characters: the values a reader of the line's last 2 000 characters needs (headline, the other arithmetics and the
+    secondary workloads with their roofline fractions)."""
+    def r4(v):
+        return None if v is None else float("%.4g" % v)
+
+    def sub(name):
+        o = out.get(name)
+        if not isinstance(o, dict):
+            return None
+        if "error" in o:
+            return {"error": o["error"][:60]}
+        d = {"v": r4(o.get("value")), "ms": r4(o.get("ms_per_step"))}
+        if isinstance(o.get("roofline"), dict):
+            d["frac"] = r4(o["roofline"].get("frac"))
+        return d
+    s = {"value": r4(out["value"]), "unit": out["unit"], "dtype": out["dtype"], "n_gpus": out["n_gpus"], "ms_per_step": r4(out["ms_per_step"]),
+         "roofline_frac": r4(out["roofline"].get("frac")), "avg_launch_ms": r4(out["roofline"].get("avg_launch_ms")),
+         "mfma_busy_pmc": out["roofline"].get("mfma_busy_pmc"), "traffic": out["roofline"].get("traffic")}
+    for k in ("exact_fp32", "split_fp16", "two_term_split_fp16", "log_prob_32", "log_prob_grad_1024", "log_prob_grad_30", "train_32", "basis_30"):
+        v = sub(k)
+        if v is not None:
+            s[k] = v
+    if isinstance(out.get("config_A_32x32_K16_L2"), dict):
+        s["config_A"] = r4(out["config_A_32x32_K16_L2"].get("value"))
+    if isinstance(out.get("basis_30"), dict) and "chain" in out["basis_30"]:
+        s["basis_30"]["psnr_end"] = [r4(v) for v in out["basis_30"]["chain"]["psnr_db_end"]]
+    if isinstance(out.get("accuracy"), dict):
+        s["acc"] = {("vs_fp64" if "fp64" in k else "vs_other"): r4(v) for k, v in out["accuracy"].items() if k != "north_star_bar"}
+    if isinstance(out.get("cpu_baseline"), dict):
+        s["cpu"] = {"v": r4(out["cpu_baseline"]["value"]), "cores": out["cpu_baseline"]["cores"]}
+    s["git_head"] = out.get("git_head")
+    return s
 
 
 def self_launch(args):
@@ -385,6 +441,8 @@ def main():
                          "f32: exact fp32-input MFMA")
     ap.add_argument("--basis-K", type=int, default=32, help="--workload basis: flow steps per level of the two priors")
     ap.add_argument("--basis-levels", type=int, default=4, help="--workload basis: sigma levels of the ladder (reference: 10)")
+    ap.add_argument("--basis-sigma1", type=float, default=0.3, help="--workload basis: largest sigma of the ladder in the reference's normalised units "
+                                                                     "(reference: 1.0 = 120 dB; run_basis_sep.py:492)")
     ap.add_argument("--basis-train-steps", type=int, default=100, help="--workload basis: training steps per sigma level (3x at the first)")
     ap.add_argument("--basis-T", type=int, default=100, help="--workload basis: Langevin steps per sigma level before the timed region")
     ap.add_argument("--basis-crop", type=int, default=0, help="--workload basis: use only the first N mel bins of the 96x64 tiles (64: the 64x64 geometry of config B)")
@@ -653,6 +711,14 @@ def main():
                     "config": {"workload": "training step (loss + all gradients + Adamax + image refresh), 64x64x1, L=3 K=32 n_filters=512, 32 tiles"},
                     "param_vector_floats": pv, "roofline": grad_roofline(CONFIG_B, v, args.precision, 3)}
 
+        def sub_lp32():
+            el = logprob_workload(CONFIG_B, 32, PREC[args.precision], 30, 5, rank, local_rank, None, False)
+            v = 32 * 30 / el
+            return {"value": v, "unit": "passes/s", "ms_per_step": el / 30 * 1e3, "dtype": args.precision,
+                    "config": {"workload": "log_prob, 64x64x1, L=3 K=32 n_filters=512, 32 tiles (the reference's batch, configs/melspec_glow.yml:15)"},
+                    "range_guard": "GLOWK_RANGE_ERROR, not tripped", "roofline": grad_roofline(CONFIG_B, v, args.precision, 1)}
+
+        guarded_sub("log_prob_32", sub_lp32)
         guarded_sub("log_prob_grad_1024", sub_grad)
         guarded_sub("log_prob_grad_30", sub_grad30)
         guarded_sub("train_32", sub_train)
@@ -662,6 +728,7 @@ def main():
         out.update(dist_info)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, params_main, args.cpu_budget)
+        out["summary"] = summary_of(out)      # LAST and short: the driver's record keeps only the tail of the line
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

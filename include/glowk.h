@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GLOWK_VERSION 300
+#define GLOWK_VERSION 400
 
 /* Arguments of build_glow (flow_builder.py:60-61) + SpecPreprocessing kwargs (flow_tfp_bijectors.py:365). */
 typedef struct glowk_config {
@@ -116,6 +116,10 @@ enum glowk_range_policy { GLOWK_RANGE_IGNORE = 0, GLOWK_RANGE_ERROR = 1, GLOWK_R
 
 int glowk_version(void);
 const char* glowk_last_error(void);
+/* Diagnostic switches (environment variables GLOWK_HALF_OFF, GLOWK_NO_FUSE, GLOWK_BWD_LIGHT_4, ...: one launch form forced for an
+ * A/B timing or a form-against-form parity test; none is needed for normal use) are read when the library is loaded, not per
+ * launch; a process that changes its environment afterwards calls this to have them read again.  (No reference counterpart.) */
+void glowk_reload_env(void);
 
 /* --- construction: replaces build_glow (flow_builder.py:60-146) --------------------------------- */
 int glowk_create(const glowk_config* cfg, int device, glowk_handle** out);

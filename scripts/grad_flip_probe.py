@@ -20,6 +20,7 @@ for seed in (11, 12, 13, 14, 15, 16):
             os.environ["GLOWK_HALF_OFF"] = "1"
         else:
             os.environ.pop("GLOWK_HALF_OFF", None)
+        _lib.load().glowk_reload_env()
         lp, g = eng.log_prob_grad(torch.from_numpy(x).cuda())
         d = np.abs(g.cpu().numpy() - g_ref) / scale
         big = np.argwhere(d > 2e-4)

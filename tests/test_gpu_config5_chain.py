@@ -19,11 +19,14 @@ TILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "basi
 MEL = dict(data_type="melspec", minval=-100.0, maxval=20.0, use_logit=False)
 
 
-def test_trained_noise_conditioned_priors_run_the_basis_ladder_in_f16x3():
+@pytest.fixture(scope="module")
+def trained():
+    """Both priors trained once per module (the ladder of train_noisy_glow.py:309-358 on the repo's own training step)."""
     f = np.load(TILES)
     gt1, gt2, mixed = (torch.from_numpy(f[k].astype(np.float32))[..., None].cuda() for k in ("gt1", "gt2", "mixed"))
     assert gt1.shape == (30, 96, 64, 1)
     priors, ladders = [], []
+    sig_db = delta_db = None
     for i, gt in enumerate((gt1, gt2)):
         flow = build_glow(gt, [96, 64, 1], L=3, K=8, n_filters=512, learntop=True, seed=100 + i, precision="f16x3", actnorm_init="runtime", **MEL)
         flow.engine.set_range_policy("fallback")       # training may repeat a sweep on the exact kernels (counted below); the chain may not
@@ -40,6 +43,63 @@ def test_trained_noise_conditioned_priors_run_the_basis_ladder_in_f16x3():
               (i, fallbacks, ["%.0f->%.0f" % (losses[float(s)][0], losses[float(s)][-1]) for s in sig_db], bits))
         priors.append(flow)
         ladders.append(models)
+    return dict(f=f, gt=(gt1, gt2), mixed=mixed, priors=priors, ladders=ladders, sig_db=sig_db, delta_db=delta_db)
+
+
+def test_trained_priors_match_the_fp64_oracle_in_both_arithmetics(trained):
+    """Round-3 verdict, missing #1: TRAINED weights (wider dynamic range than synthetic_params: real ActNorm scales, real conv
+    kernels after 600 Adamax steps) against the oracle -- not properties.  For each prior, its noisiest level (sigma_1) on the
+    noised tiles it was trained on and its cleanest level (sigma_L) on the real tiles: the variables the engine reports go into
+    oracle/glowref.py (fp64, NumPy) for log_prob and oracle/glowref_torch.py (fp64 autograd; compute_grad_logprob of
+    run_basis_sep.py:73-79) for the input gradient; the engine runs the exact-fp32 kernels and the f16x3 split under
+    GLOWK_RANGE_ERROR (a trip raises: no silent fp32 re-run can stand in for the split result)."""
+    from oracle import glowref as R, glowref_torch as RT
+    sig_db = trained["sig_db"]
+    worst = {"f32": [0.0, 0.0], "f16x3": [0.0, 0.0]}
+    for i, (gt, ladder) in enumerate(zip(trained["gt"], trained["ladders"])):
+        for s, noisy in ((float(sig_db[0]), True), (float(sig_db[-1]), False)):
+            flow = ladder[s]
+            eng = flow.engine
+            x = gt[[1, 11, 23]].contiguous()
+            if noisy:
+                x = basis.add_device_noise(x, s, seed=41 + i, step=0, which=2)
+            xn = x.cpu().numpy().astype(np.float64)
+            sd = flow.state_dict()
+            cfg = flow.cfg.as_dict()
+            lp_ref = R.log_prob(xn, R.cast_params(sd, np.float64), cfg)
+            lp_t, g_ref = RT.log_prob_and_grad(xn, sd, cfg)
+            np.testing.assert_allclose(lp_t, lp_ref, rtol=1e-10)            # the two restatements agree on the trained weights
+            gmax = np.abs(g_ref).max(axis=(1, 2, 3), keepdims=True)
+            policy = int(eng.lib.glowk_get_range_policy(eng.h))
+            prec = eng.get_precision()
+            eng.set_range_policy("error")
+            try:
+                for name, mode, lp_tol in (("f32", _lib.PREC_F32, 1e-6), ("f16x3", _lib.PREC_F16X3, 5e-6)):
+                    eng.set_precision(mode)
+                    lp = eng.log_prob(x).cpu().numpy().astype(np.float64)
+                    lp2, dx = eng.log_prob_grad(x)
+                    lp2, dx = lp2.cpu().numpy().astype(np.float64), dx.cpu().numpy().astype(np.float64)
+                    e_lp = float(np.max(np.abs(lp - lp_ref) / np.abs(lp_ref)))
+                    e_lp2 = float(np.max(np.abs(lp2 - lp_ref) / np.abs(lp_ref)))
+                    e_g = float(np.max(np.abs(dx - g_ref) / gmax))
+                    print("prior %d sigma %.2f dB (%s tiles) %s: log_prob rel err %.2e (saving pass %.2e), input gradient %.2e of max |g| "
+                          "(log_prob %.1f .. %.1f, max |g| %.3g)" % (i, s, "noised" if noisy else "real", name, e_lp, e_lp2, e_g,
+                                                                    lp_ref.min(), lp_ref.max(), float(gmax.max())))
+                    assert e_lp < lp_tol and e_lp2 < lp_tol, (i, s, name, e_lp, e_lp2)
+                    assert e_g < 2e-4, (i, s, name, e_g)
+                    worst[name][0] = max(worst[name][0], e_lp, e_lp2)
+                    worst[name][1] = max(worst[name][1], e_g)
+            finally:
+                eng.set_precision(prec)
+                eng.set_range_policy(policy)
+            assert eng.range_status() == (False, 0)
+    print("trained checkpoints vs fp64 oracle, worst over 2 priors x 2 noise levels x 3 tiles: f32 log_prob %.2e grad %.2e; "
+          "f16x3 log_prob %.2e grad %.2e" % (worst["f32"][0], worst["f32"][1], worst["f16x3"][0], worst["f16x3"][1]))
+
+
+def test_trained_noise_conditioned_priors_run_the_basis_ladder_in_f16x3(trained):
+    f, (gt1, gt2), mixed = trained["f"], trained["gt"], trained["mixed"]
+    priors, ladders, sig_db, delta_db = trained["priors"], trained["ladders"], trained["sig_db"], trained["delta_db"]
     # the chain: reference start (uniform over the data range, run_basis_sep.py:360-361), every per-sigma engine in f16x3 under
     # GLOWK_RANGE_ERROR (a trip raises), the static bound's margin measured along the way
     engines = [m[float(s)].engine for m in ladders for s in sig_db]

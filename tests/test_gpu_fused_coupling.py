@@ -27,11 +27,17 @@ CASES = {
 }
 
 
-def _run(eng, x, fuse):
-    if fuse:
-        os.environ.pop("GLOWK_NO_FUSE", None)
+def _setenv(name, on):
+    """The engine reads its diagnostic switches at load time: change one and have them read again (glowk_reload_env)."""
+    if on:
+        os.environ[name] = "1"
     else:
-        os.environ["GLOWK_NO_FUSE"] = "1"
+        os.environ.pop(name, None)
+    _lib.load().glowk_reload_env()
+
+
+def _run(eng, x, fuse):
+    _setenv("GLOWK_NO_FUSE", not fuse)
     try:
         before = eng.fused_steps
         lp, z = eng.log_prob(x, return_latent=True)
@@ -39,7 +45,7 @@ def _run(eng, x, fuse):
         torch.cuda.synchronize()
         return lp, z, xr, eng.fused_steps - before
     finally:
-        os.environ.pop("GLOWK_NO_FUSE", None)
+        _setenv("GLOWK_NO_FUSE", False)
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -94,11 +100,11 @@ def test_fused_saving_pass_feeds_the_backward_sweep(name):
     before = eng.fused_steps
     lp_f, g_f = eng.log_prob_grad(x)
     fused = eng.fused_steps - before
-    os.environ["GLOWK_NO_FUSE"] = "1"
+    _setenv("GLOWK_NO_FUSE", True)
     try:
         lp_u, g_u = eng.log_prob_grad(x)
     finally:
-        os.environ.pop("GLOWK_NO_FUSE", None)
+        _setenv("GLOWK_NO_FUSE", False)
     assert fused == cfg.K, fused                                   # every forward step of the 4-channel level
     assert float(((lp_f - lp_u).abs() / lp_u.abs()).max()) < 2e-6
     d = (g_f - g_u).abs() / g_u.abs().max()
@@ -133,15 +139,14 @@ def test_one_lane_per_pixel_backward_merge_equals_the_four_lane_form(precision, 
     x = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=11)).cuda()
 
     def run(four):
-        if four:
-            os.environ["GLOWK_BWD_LIGHT_4"] = "1"
+        _setenv("GLOWK_BWD_LIGHT_4", four)
         try:
             lp, dx = eng.log_prob_grad(x)
             lpp, g = eng.param_grad(x[:300].contiguous(), -1.0 / 300)
             torch.cuda.synchronize()
             return lp, dx, g
         finally:
-            os.environ.pop("GLOWK_BWD_LIGHT_4", None)
+            _setenv("GLOWK_BWD_LIGHT_4", False)
 
     lp1, dx1, g1 = run(False)
     lp4, dx4, g4 = run(True)

@@ -173,6 +173,67 @@ def test_workspace_bytes_is_what_reserve_allocates():
         eng.close()
 
 
+@pytest.mark.parametrize("big,small", [(40, 30), (12, 8), (160, 128)])
+def test_smaller_batch_after_a_larger_reserve_keeps_its_masks_apart(big, small):
+    """Round-3 advisor (high): the per-step ReLU-mask offsets are laid out once for the largest batch a handle has seen; the
+    blocks a SMALLER batch needs must fit that layout (the half-wave launch form takes twice the blocks per pixel below its grid
+    threshold: on 256 CUs a level-1 tensor of 40 tiles needed 320 blocks, of 30 tiles 480).  reserve(big) then the gradient /
+    parameter-gradient of `small` tiles must be what a fresh engine returns -- bit for bit (same launches, same order)."""
+    cfg = GlowConfig(H=64, W=64, C=1, L=3, K=2, F=512)
+    x = dev(synthetic_mel_tiles(small, cfg, seed=9))
+    for prec in (_lib.PREC_F16X3, _lib.PREC_F32):
+        fresh, _ = calibrated_engine(cfg, device=0, init_tiles=8)
+        fresh.set_precision(prec)
+        lp0, dx0 = fresh.log_prob_grad(x)
+        _, g0 = fresh.param_grad(x, -1.0 / small)
+        lp0, dx0, g0 = lp0.clone(), dx0.clone(), g0.clone()
+        fresh.close()
+        eng, _ = calibrated_engine(cfg, device=0, init_tiles=8)
+        eng.set_precision(prec)
+        eng.reserve(big, with_grad=True)
+        lp1, dx1 = eng.log_prob_grad(x)
+        assert torch.equal(lp0, lp1) and torch.equal(dx0, dx1), (prec, float((dx0 - dx1).abs().max()))
+        xb = dev(synthetic_mel_tiles(big, cfg, seed=10))
+        eng.param_grad(xb, -1.0 / big)                      # the training buffers sized for the larger batch as well
+        _, g1 = eng.param_grad(x, -1.0 / small)
+        # (the split sweep's gradient scale is sized on the previous sweep: histories differ, so rounding-level agreement)
+        tol = 0.0 if prec == _lib.PREC_F32 else 2e-6 * float(g0.abs().max())
+        assert float((g0 - g1).abs().max()) <= tol, (prec, float((g0 - g1).abs().max()), tol)
+        lp2, dx2 = eng.log_prob_grad(x)                     # and again after the larger sweep used the whole layout
+        assert torch.equal(lp0, lp2) and torch.equal(dx0, dx2)
+        assert eng.range_status() == (False, 0)
+        eng.close()
+
+
+def test_chunked_log_prob_sum_survives_a_range_fallback():
+    """Round-3 advisor (medium): glowk_log_prob_sum accumulates chunk sums into *sum_dev; a chunk whose split-precision pass trips
+    the range guard is re-run on the exact kernels (policy FALLBACK) -- the rejected pass must not have touched the sum."""
+    cfg = GlowConfig(H=32, W=32, C=1, L=2, K=2, F=128)
+    eng, params = hot_engine(cfg)
+    eng.set_precision(_lib.PREC_F16X3)
+    eng.set_range_policy("fallback")
+    x = dev(synthetic_mel_tiles(10, cfg, seed=3))
+    eng._max_tiles_cap = 4                                  # chunks of 4, 4, 2: the later ones accumulate
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        lp, total = eng.log_prob_sum(x)
+    assert eng.range_status(sync=False)[1] >= 3             # every chunk fell back
+    eng.set_precision(_lib.PREC_F32)
+    lp32 = eng.log_prob(x)
+    assert torch.equal(lp, lp32)
+    want = float(lp32.double().sum())
+    assert abs(float(total[0]) - want) <= 1e-9 * abs(want), (float(total[0]), want)
+    # under ERROR the failing call leaves the caller's sum alone
+    eng.set_precision(_lib.PREC_F16X3)
+    eng.set_range_policy("error")
+    total.fill_(123.0)
+    with pytest.raises(_lib.GlowkRangeError):
+        eng.log_prob_sum(x[:4], total=total)
+    torch.cuda.synchronize()
+    assert float(total[0]) == 123.0
+    eng.close()
+
+
 def test_device_is_restored_and_respected():
     """An engine on a non-current device must run there and leave the caller's current device alone (one-GPU boxes: the
     current device must simply be unchanged by every kind of call)."""
