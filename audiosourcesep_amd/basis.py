@@ -11,6 +11,11 @@ fresh ``tf.random.normal`` noise, unseeded).  CPU tensors (the host-side tests o
 Convention: ``x1, x2, mixed`` live in the space the two flows were built for -- with
 ``build_glow(..., data_type='melspec')`` that is dB; the flows' own SpecPreprocessing maps it to the network's range.
 Tiles are independent, so ``shard`` splits ``n_mixed`` over the ranks of a process group with no collective in the loop.
+At the reference's 30 mixture tiles that alone cannot scale far (a step is a latency-bound chain of ~400 small launches per prior:
+4 tiles per GPU take almost as long as 30), so the loop also runs PRIOR-PARALLEL (``prior_parallel_layout``): the two priors of a
+tile shard live on two ranks, each evaluates its own prior's gradient, ONE all-gather of the two gradient tensors per Langevin
+step (2 x 737 KB for 30 tiles of 96x64) makes both visible, and both ranks run the identical update kernel (same Philox counters:
+the replicated state stays bit-identical without a broadcast).
 """
 import ctypes
 import math
@@ -84,6 +89,47 @@ def grad_mixing_db(*sources):
     return torch.unbind(torch.softmax(s * (math.log(10.0) / 10.0), dim=0), dim=0)
 
 
+def prior_parallel_layout(n_mixed, world_size, rank):
+    """Prior-parallel BASIS over ``world_size`` = 2 S ranks: rank r holds prior ``r % 2`` (0: model1, 1: model2) of tile shard
+    ``r // 2`` of S.  -> dict(prior, shard, n_shards, bounds=(a, b), pair=(rank of prior 0, rank of prior 1)).  Every rank of the
+    job then creates the pair groups in the same order: ``[dist.new_group(list(p)) for p in all_pairs(world_size)]`` and keeps its own
+    (``make_pair_group``)."""
+    if world_size < 2 or world_size % 2:
+        raise ValueError("prior-parallel BASIS needs an even number of ranks (two priors per tile shard)")
+    shards = world_size // 2
+    s = rank // 2
+    return {"prior": rank % 2, "shard": s, "n_shards": shards, "bounds": shard_bounds(n_mixed, shards, s), "pair": (2 * s, 2 * s + 1)}
+
+
+def make_pair_group(world_size, rank):
+    """The process group of this rank's prior pair.  Collective over the whole job (torch.distributed.new_group must be called by
+    every rank for every group, in the same order)."""
+    import torch.distributed as dist
+    mine = None
+    for s in range(world_size // 2):
+        g = dist.new_group([2 * s, 2 * s + 1])
+        if rank // 2 == s:
+            mine = g
+    return mine
+
+
+def exchange_prior_gradients(g_mine, prior_index, pair_group):
+    """-> (g1, g2): all-gather of the two priors' gradients over the pair (rank order within the pair = prior order).  RCCL over
+    xGMI when the backend is nccl; under gloo (CPU tests, one-GPU rehearsal) device tensors go through the host."""
+    import torch.distributed as dist
+    g_mine = g_mine.contiguous()
+    if g_mine.is_cuda and dist.get_backend(pair_group) == "gloo":
+        mine = g_mine.cpu()
+        parts = [torch.empty_like(mine), torch.empty_like(mine)]
+        dist.all_gather(parts, mine, group=pair_group)
+        parts = [p.to(g_mine.device) for p in parts]
+    else:
+        parts = [torch.empty_like(g_mine), torch.empty_like(g_mine)]
+        dist.all_gather(parts, g_mine, group=pair_group)
+    parts[prior_index] = g_mine
+    return parts[0], parts[1]
+
+
 def compute_grad_logprob(inputs, model):
     """run_basis_sep.py:73-79 -- d log_prob / d inputs through the engine (no autograd tape needed)."""
     _, g = model.engine.log_prob_grad(inputs)
@@ -139,12 +185,21 @@ def _grad_pair(x1, x2, model1, model2, streams):
 
 
 def basis_inner_loop(mixed, x1, x2, model1, model2, sigma_idx, sigmas, delta=2e-5, T=100, noise_fn=None, debug=False,
-                     streams="auto", seed=0, step0=0, offset=0):
+                     streams="auto", seed=0, step0=0, offset=0, prior_group=None, prior_index=None):
     """run_basis_sep.py:152-214 (model_type == 'glow').  ``noise_fn(t, which, shape) -> standard normal tensor`` replays given
     draws; without it the update kernel draws from the device RNG stream (seed, step0 + t), element ``offset`` onwards
     (``offset`` = this shard's first tile * H * W * C: the draws of a tile are the same whatever the sharding).
     ``streams``: "auto" (two side streams when on the GPU and the models are distinct engines), None, or (s1, s2).
-    ``debug``: the reference's NaN asserts (:183-191), from a flag the update kernel raises (one word read back per step)."""
+    ``debug``: the reference's NaN asserts (:183-191), from a flag the update kernel raises (one word read back per step).
+    ``prior_group`` / ``prior_index``: prior-parallel mode -- this rank evaluates the gradient of prior ``prior_index`` only (the
+    other model may be None), the pair exchanges the two gradients (``exchange_prior_gradients``) and both ranks take the same
+    update; the noise must then be the same on both (the device RNG with equal seed / step0 / offset is; an injected ``noise_fn``
+    has to be)."""
+    pp = prior_group is not None
+    if pp and prior_index not in (0, 1):
+        raise ValueError("prior_index must be 0 or 1 in prior-parallel mode")
+    if pp:
+        streams = None
     if streams == "auto":
         streams = None
         if x1.device.type == "cuda" and getattr(model1, "engine", None) is not getattr(model2, "engine", None):
@@ -153,13 +208,19 @@ def basis_inner_loop(mixed, x1, x2, model1, model2, sigma_idx, sigmas, delta=2e-
     sigma_l = float(sigmas[-1])
     eta = float(np.float32(delta * (sigma / sigma_l) ** 2))
     lambda_recon = 1.0 / (sigma ** 2)
+    def grads(a, b):
+        if not pp:
+            return _grad_pair(a, b, model1, model2, streams)
+        mine = compute_grad_logprob(a if prior_index == 0 else b, model1 if prior_index == 0 else model2)
+        return exchange_prior_gradients(mine, prior_index, prior_group)
+
     if x1.device.type != "cuda":
-        return _inner_loop_host(mixed, x1, x2, model1, model2, eta, lambda_recon, T, noise_fn, debug)
+        return _inner_loop_host(mixed, x1, x2, grads, eta, lambda_recon, T, noise_fn, debug)
     mixed = mixed.to(torch.float32).contiguous()
     x1, x2 = x1.to(torch.float32).clone().contiguous(), x2.to(torch.float32).clone().contiguous()   # (the update is in place)
     flag = torch.zeros(1, dtype=torch.int32, device=x1.device) if debug else None
     for t in range(T):
-        g1, g2 = _grad_pair(x1, x2, model1, model2, streams)
+        g1, g2 = grads(x1, x2)
         e1 = noise_fn(t, 0, x1.shape).to(torch.float32).contiguous() if noise_fn is not None else None
         e2 = noise_fn(t, 1, x2.shape).to(torch.float32).contiguous() if noise_fn is not None else None
         langevin_update(mixed, x1, x2, g1, g2, eta, lambda_recon, e1, e2, seed=seed, step=step0 + t, nonfinite=flag, offset=offset)
@@ -168,14 +229,14 @@ def basis_inner_loop(mixed, x1, x2, model1, model2, sigma_idx, sigmas, delta=2e-
     return x1, x2
 
 
-def _inner_loop_host(mixed, x1, x2, model1, model2, eta, lambda_recon, T, noise_fn, debug):
-    """The same loop on torch formulas (CPU tensors: host-side tests with stand-in models)."""
+def _inner_loop_host(mixed, x1, x2, grads, eta, lambda_recon, T, noise_fn, debug):
+    """The same loop on torch formulas (CPU tensors: host-side tests with stand-in models).  ``grads(x1, x2) -> (g1, g2)``."""
     if noise_fn is None:
         noise_fn = lambda t, which, shape: torch.randn(shape, dtype=torch.float32)  # noqa: E731
     for t in range(T):
         eps1 = math.sqrt(2.0 * eta) * noise_fn(t, 0, x1.shape)
         eps2 = math.sqrt(2.0 * eta) * noise_fn(t, 1, x2.shape)
-        g1, g2 = compute_grad_logprob(x1, model1), compute_grad_logprob(x2, model2)
+        g1, g2 = grads(x1, x2)
         mix = mixing_db(x1, x2)
         m1, m2 = grad_mixing_db(x1, x2)
         x1, x2 = x1 + eta * (g1 + lambda_recon * m1 * (mixed - mix)) + eps1, x2 + eta * (g2 + lambda_recon * m2 * (mixed - mix)) + eps2
@@ -185,18 +246,23 @@ def _inner_loop_host(mixed, x1, x2, model1, model2, eta, lambda_recon, T, noise_
 
 
 def basis_outer_loop(mixed, x1, x2, model1, model2, sigmas, restore_1=None, restore_2=None, T=100, delta=2e-5, noise_fn=None,
-                     debug=False, seed=0, tile_offset=0):
+                     debug=False, seed=0, tile_offset=0, prior_group=None, prior_index=None):
     """run_basis_sep.py:217-260.  ``restore_k``: optional ``{sigma: state_dict | path | GlowFlow}`` with the noise-conditioned
     weights of model k for each noise level (the per-sigma checkpoints of train_noisy_glow.py:309-358); a ``GlowFlow`` value is
     used as is (all ten noise levels of both priors resident: 2 x 10 x 0.5 GB of packed weights).
     ``tile_offset``: index of ``mixed[0]`` in the whole set of mixture tiles (``shard_bounds(n_mixed, world, rank)[0]`` on a rank
     that holds a shard): folded into the device RNG's counter, so every tile sees the Langevin noise it would see in a
-    one-process run -- ranks do not repeat each other's draws and the result does not depend on the world size."""
+    one-process run -- ranks do not repeat each other's draws and the result does not depend on the world size.
+    ``prior_group`` / ``prior_index``: prior-parallel mode (``basis_inner_loop``): only the own prior's model and ``restore_k`` are
+    used, the other may be None."""
     elems_per_tile = int(np.prod(mixed.shape[1:]))
     x_arr = {"x1": [x1.cpu().numpy()], "x2": [x2.cpu().numpy()]}
     for sigma_idx, sigma in enumerate(sigmas):
         current = []
-        for model, restore in ((model1, restore_1), (model2, restore_2)):
+        for k, (model, restore) in enumerate(((model1, restore_1), (model2, restore_2))):
+            if prior_group is not None and k != prior_index:
+                current.append(None)          # the pair partner owns this prior
+                continue
             if restore is not None:
                 state = restore[float(sigma)] if float(sigma) in restore else restore[sigma]
                 if hasattr(state, "log_prob"):      # a resident flow for this noise level: no weight swap at all
@@ -209,7 +275,8 @@ def basis_outer_loop(mixed, x1, x2, model1, model2, sigmas, restore_1=None, rest
         model1_s, model2_s = current
         nf = None if noise_fn is None else (lambda t, which, shape, _s=sigma_idx: noise_fn(_s, t, which, shape))
         x1, x2 = basis_inner_loop(mixed, x1, x2, model1_s, model2_s, sigma_idx, sigmas, delta=delta, T=T, noise_fn=nf, debug=debug,
-                                  seed=seed, step0=sigma_idx * T, offset=int(tile_offset) * elems_per_tile)
+                                  seed=seed, step0=sigma_idx * T, offset=int(tile_offset) * elems_per_tile, prior_group=prior_group,
+                                  prior_index=prior_index)
         x_arr["x1"].append(x1.cpu().numpy())
         x_arr["x2"].append(x2.cpu().numpy())
     return x1, x2, x_arr

@@ -62,7 +62,7 @@ struct glowk_handle {
   int precision = GLOWK_PREC_F32;
   int range_policy = GLOWK_RANGE_ERROR;
   int64_t range_fallbacks = 0;
-  int64_t family_launches[5] = {0, 0, 0, 0, 0};   // coupling-network launches by kernel family (glowk_launch.h: note_family)
+  int64_t family_launches[6] = {0, 0, 0, 0, 0, 0};   // coupling-network launches by kernel family (glowk_launch.h: note_family)
   int64_t fused_steps = 0;      // flow steps that ran as ONE network + coupling kernel (net_and_couple)
   int* d_flag = nullptr;        // sticky range flag (device), written by k_couple / k_bwd_light
   int* h_flag = nullptr;        // pinned host word it is read back into
@@ -164,7 +164,9 @@ static EnvSwitches g_env = read_env();
 const EnvSwitches& env() { return g_env; }
 void reload_env() { g_env = read_env(); }
 thread_local int g_family = 0;
-void note_family(int family) { g_family = family; }
+thread_local bool g_co = false;
+void note_family(int family) { g_family = family; g_co = false; }
+void note_co() { g_co = true; }
 // instantiated in glowk_net_inst.hip, one translation unit per (CI, NF)
 #define GLOWK_EXTERN_NET(CI_, NF_) extern template int launch_net_t<CI_, NF_>(const NetArgs&, int, hipStream_t, bool);
 GLOWK_EXTERN_NET(2, 16) GLOWK_EXTERN_NET(4, 16) GLOWK_EXTERN_NET(8, 16) GLOWK_EXTERN_NET(16, 16)
@@ -197,6 +199,7 @@ float bwd_norm_target(float xlim_b) {
 
 int launch_net_raw(int c, int F, const NetArgs& a, int mode, hipStream_t s, bool dry = false) {
   glowk_detail::g_family = 0;     // (the fp32 kernels do not announce themselves)
+  glowk_detail::g_co = false;
 #define NETCASE(CI_, NF_) if (c == 2 * CI_ && F == 32 * NF_) return launch_net_t<CI_, NF_>(a, mode, s, dry);
   NETCASE(2, 16) NETCASE(4, 16) NETCASE(8, 16) NETCASE(16, 16)
   NETCASE(2, 12) NETCASE(4, 12) NETCASE(8, 12) NETCASE(16, 12)
@@ -211,7 +214,7 @@ int launch_net_raw(int c, int F, const NetArgs& a, int mode, hipStream_t s, bool
 int launch_net(glowk_handle* h, int level, int c, int F, const NetArgs& a, hipStream_t s, int mode = NET_FWD, int* np_out = nullptr) {
   if (!h->profiling) {
     const int np = launch_net_raw(c, F, a, mode, s);
-    if (np >= 0) ++h->family_launches[glowk_detail::g_family];
+    if (np >= 0) { ++h->family_launches[glowk_detail::g_family]; if (glowk_detail::g_co) ++h->family_launches[5]; }
     if (np_out) *np_out = np;
     return np < 0 ? 1 : 0;
   }
@@ -223,7 +226,7 @@ int launch_net(glowk_handle* h, int level, int c, int F, const NetArgs& a, hipSt
   hipEvent_t e0 = h->ev_pool[h->ev_used], e1 = h->ev_pool[h->ev_used + 1];
   HIPCHK(hipEventRecord(e0, s));
   const int np = launch_net_raw(c, F, a, mode, s);
-  if (np >= 0) ++h->family_launches[glowk_detail::g_family];
+  if (np >= 0) { ++h->family_launches[glowk_detail::g_family]; if (glowk_detail::g_co) ++h->family_launches[5]; }
   HIPCHK(hipEventRecord(e1, s));
   h->ev_used += 2;
   h->ev_level.push_back(level);
@@ -287,11 +290,11 @@ int launch_couple(int c, const CoupleArgs& a, int N, hipStream_t s, const FlatLd
 // that fills the chip: ONE kernel (k_net_h3s<..., MODE | 16>: the per-tap conv3 outputs never leave the workgroup) plus
 // k_couple_edge for the pixel rows whose 3 x 3 neighbourhood straddles two workgroups and the per-sample log-det; otherwise k_net
 // (P to HBM) + k_couple.  na: the network launch (na.P / pstride as for launch_net); ca: the coupling as k_couple takes it.
-bool fuse_geometry_ok(int h, int w) {
+bool fuse_geometry_ok(int h, int w, int pxw = 256) {     // pxw: pixels per workgroup of the fused kernel
   const int hw = h * w;
-  if (w < 4 || w > FUSE_EW || (w & (w - 1)) || 256 % w) return false;
-  if (hw % 256 == 0) return true;
-  return hw >= 32 && hw < 256 && (hw & (hw - 1)) == 0;
+  if (w < 4 || w > FUSE_EW || (w & (w - 1)) || pxw % w) return false;
+  if (hw % pxw == 0) return true;
+  return hw >= 32 && hw < pxw && (hw & (hw - 1)) == 0;
 }
 
 int net_and_couple(glowk_handle* h, int lvl, int c, int F, NetArgs na, CoupleArgs ca, int N, hipStream_t s, int mode, const FlatLd* fl = nullptr,
@@ -300,9 +303,12 @@ int net_and_couple(glowk_handle* h, int lvl, int c, int F, NetArgs na, CoupleArg
   const int hw = ca.h * ca.w;
   if (!no_fuse && c == 4 && (mode == 3 || mode == 6 || mode == 4) && na.RSp && ca.vin && !ca.log_s_out && ca.out && na.in_stride == 4 &&
       ca.out_stride % 4 == 0 && ca.out_off % 4 == 0 && fuse_geometry_ok(ca.h, ca.w) && na.P == h->bufP) {
-    const size_t wgs = ((size_t)ca.Q + 255) / 256;
+    // (scratch sized for the co-resident form's 128-pixel workgroups when it may be taken: twice the edge slots)
+    const size_t pxw = (na.co && fuse_geometry_ok(ca.h, ca.w, CO_PX)) ? CO_PX : 256;
+    if (pxw == 256) na.co = 0;
+    const size_t wgs = ((size_t)ca.Q + pxw - 1) / pxw;
     const size_t edge_floats = (wgs * 4 * FUSE_EW * 4 + 3) & ~(size_t)3;
-    const size_t nld = wgs * 8;                                          // one fp64 log-det partial per wave (32 pixels)
+    const size_t nld = wgs * (pxw / 32);                                  // one fp64 log-det partial per wave (32 pixels), idle waves of a ragged last workgroup included
     if ((edge_floats + 2 * nld + 4) <= 4 * h->pstride) {                // (the scratch lives in the P buffers the fused launch does not use)
       na.fuse = 1;
       na.fz_b3 = ca.b3; na.fz_A = ca.A; na.fz_b = ca.b; na.fz_out = ca.out; na.fz_out_stride = ca.out_stride; na.fz_out_off = ca.out_off;
@@ -314,15 +320,16 @@ int net_and_couple(glowk_handle* h, int lvl, int c, int F, NetArgs na, CoupleArg
   }
   int np = 1;
   if (int rc = launch_net(h, lvl, c, F, na, s, mode, &np)) return rc;
-  if (np != 100) {
+  if (np != 100 && np != 101) {
     ca.P = na.P; ca.np = np; ca.pstride = na.pstride;
     return launch_couple(c, ca, N, s, fl, flat_used);
   }
   ++h->fused_steps;
-  if (hw > 256 || ca.logdet) {
+  const int pxw = np == 101 ? CO_PX : 256;
+  if (hw > pxw || ca.logdet) {
     EdgeArgs ea;
     ea.vin = ca.vin; ea.edge = na.fz_edge; ea.ldpart = na.fz_ldpart; ea.A = ca.A; ea.b = ca.b; ea.out = ca.out; ea.out_stride = ca.out_stride;
-    ea.out_off = ca.out_off; ea.inverse = ca.inverse; ea.logdet = ca.logdet; ea.osave = ca.o_save; ea.h = ca.h; ea.w = ca.w; ea.flag = ca.flag;
+    ea.out_off = ca.out_off; ea.inverse = ca.inverse; ea.logdet = ca.logdet; ea.osave = ca.o_save; ea.h = ca.h; ea.w = ca.w; ea.flag = ca.flag; ea.pxw = pxw;
     hipLaunchKernelGGL(k_couple_edge, dim3(N), dim3(256), 0, s, ea);
     LAUNCHCHK("k_couple_edge");
   }
@@ -467,7 +474,7 @@ NetArgs net_args(glowk_handle* h, const Level& lv, const StepDev& sd, const floa
   a.RHp = sd.RHp; a.RSp = sd.RSp; a.fam16 = (sd.RSp && sd.RSBp) ? 1 : 0; a.eph = sd.epH; a.pstride = h->pstride; a.max_np = 4; a.sc1 = sd.sc1; a.sc2 = sd.sc2; a.sc3 = sd.sc3;
   a.flag = flagp(h); a.xlim = sd.xlim_f; a.st1 = nullptr; a.st2 = nullptr;
   a.bnorm = 1.0f;
-  a.fuse = 0; a.fz_osave = nullptr; a.fz_b3 = nullptr; a.fz_A = nullptr; a.fz_b = nullptr; a.fz_out = nullptr; a.fz_out_stride = 0; a.fz_out_off = 0; a.fz_inverse = 0;
+  a.fuse = 0; a.co = glowk_detail::env().co_off ? 0 : 1; a.fz_osave = nullptr; a.fz_b3 = nullptr; a.fz_A = nullptr; a.fz_b = nullptr; a.fz_out = nullptr; a.fz_out_stride = 0; a.fz_out_off = 0; a.fz_inverse = 0;
   a.fz_edge = nullptr; a.fz_ldpart = nullptr;
   a.xmax_out = h->d_probe ? h->d_probe + ((&lv - h->levels.data()) * h->cfg.K + (&sd - lv.dev.data())) : nullptr;
   return a;
@@ -1733,9 +1740,9 @@ int glowk_prior_log_prob(glowk_handle* h, const float* z_dev, int N, float* logp
 
 int64_t glowk_fused_steps(const glowk_handle* h) { return h ? h->fused_steps : -1; }
 
-int glowk_kernel_families(const glowk_handle* h, int64_t* out5) {
-  if (!h || !out5) return fail("null argument");
-  for (int i = 0; i < 5; ++i) out5[i] = h->family_launches[i];
+int glowk_kernel_families(const glowk_handle* h, int64_t* out6) {
+  if (!h || !out6) return fail("null argument");
+  for (int i = 0; i < 6; ++i) out6[i] = h->family_launches[i];
   return 0;
 }
 

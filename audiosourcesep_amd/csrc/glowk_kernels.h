@@ -57,7 +57,9 @@ struct NetArgs {
                          // power of two that brings its largest magnitude into [bnorm, 2 bnorm) before the split, and the pixel's outputs
                          // are scaled back (exact): no gradient magnitude can leave the fp16 range, small pixels keep all their bits
   // ---- coupling fused into k_net_h3s<..., MODE | 16> (fused_couple): what k_couple would have been given
-  int fuse;              // host side: ask the launch policy for the fused instance (it answers 100 instead of a number of partials)
+  int fuse;              // host side: ask the launch policy for the fused instance (it answers 100 instead of a number of partials;
+                         // 101: the co-resident form of it, 128-pixel workgroups -- k_couple_edge is told, EdgeArgs::pxw)
+  int co;                // host side: the co-resident form (glowk_co.h) may be taken where it has an instance
   const float* fz_b3;    // [C] conv3 bias
   const float* fz_A;     // post affine [C][C] or null (forward: the NEXT step's ActNorm + 1x1; inverse: this step's inverse 1x1 + ActNorm)
   const float* fz_b;     // [C]
@@ -1403,12 +1405,14 @@ __device__ __forceinline__ void h3s_passes(const NetArgs& a, const H3Ctx& c, con
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool fz_not_finite(float v) { return !(fabsf(v) <= 3.0e38f); }
 
+// PXW = pixels per workgroup (256: k_net_h3s; 128: the co-resident form k_net_h3c, glowk_co.h), PSTR = floats per LDS row of P
+template <int PXW = 256, int PSTR = FUSE_PSTR>
 __device__ __forceinline__ void fused_couple(const NetArgs& a, const float* pl, const float4* vst, int tid) {
   const int wave = tid >> 6, lane = tid & 63;
   const int px = wave * 32 + (lane & 31), k = lane >> 5;
-  const int q = (int)blockIdx.x * 256 + px;
+  const int q = (int)blockIdx.x * PXW + px;
   const bool qok = q < a.Q;
-  const int w = a.w, hw = a.h * a.w, nrows = 256 / w;
+  const int w = a.w, hw = a.h * a.w, nrows = PXW / w;
   const int pp = (qok ? q : 0) % hw;
   const int i = pp / w, j = pp % w, r = px / w;
   float ols = 0.0f, ot = 0.0f;
@@ -1421,15 +1425,19 @@ __device__ __forceinline__ void fused_couple(const NetArgs& a, const float* pl, 
     const int rr = r + dy;
     if (rr < 0 || rr >= nrows) { missing = true; continue; }      // that row belongs to another workgroup
     const int spx = px + dy * w + dx;
-    ols += pl[(tap * 4 + k) * FUSE_PSTR + spx];
-    ot += pl[(tap * 4 + 2 + k) * FUSE_PSTR + spx];
+    ols += pl[(tap * 4 + k) * PSTR + spx];
+    ot += pl[(tap * 4 + 2 + k) * PSTR + spx];
   }
   ols += a.fz_b3[k];
   ot += a.fz_b3[2 + k];
   float lsum = 0.0f;
   // (the partner lane l ^ 32 holds the other channel pair of the SAME pixel: the two take identical branches)
+#ifdef GLOWK_EXP_VGLOBAL   // (diagnostic build: the tail reads the coupling input from global memory, not from the LDS stash)
+  const float4 v4 = qok ? *reinterpret_cast<const float4*>(a.vin + (size_t)q * 4) : float4{0.f, 0.f, 0.f, 0.f};
+#else
   const float4 v4 = vst[px];          // the pixel's four input channels, parked in LDS by the prologue (a global load here would be
                                       // a full memory latency on the workgroup's serial tail: nothing else runs on this CU)
+#endif
   const float vk = k ? v4.y : v4.x;
   const float log_s = tanhf(ols);
   const float sc = expf(log_s);
@@ -1462,15 +1470,15 @@ __device__ __forceinline__ void fused_couple(const NetArgs& a, const float* pl, 
   }
   // what the first row contributes to the row above (slot 2: taps dy = +1 seen from there) and the last row to the row below
   // (slot 3: taps dy = -1): 2 w targets x 4 channels, one thread each
-  if (tid < 2 * w * 4) {
-    const int which = tid / (4 * w), jt = (tid / 4) % w, ch = tid & 3;
+  for (int te = tid; te < 2 * w * 4; te += 2 * PXW) {      // (2 PXW threads per workgroup; w <= 64: at most two rounds)
+    const int which = te / (4 * w), jt = (te / 4) % w, ch = te & 3;
     float hsum = 0.0f;
 #pragma unroll
     for (int dx = -1; dx <= 1; ++dx) {
       const int js = jt + dx;
       if (js < 0 || js >= w) continue;
       const int tap = (which ? 0 : 6) + dx + 1;
-      hsum += pl[(tap * 4 + ch) * FUSE_PSTR + (which ? (nrows - 1) * w : 0) + js];
+      hsum += pl[(tap * 4 + ch) * PSTR + (which ? (nrows - 1) * w : 0) + js];
     }
     a.fz_edge[(((size_t)blockIdx.x * 4 + 2 + which) * FUSE_EW + jt) * 4 + ch] = hsum;
   }
@@ -1480,7 +1488,7 @@ __device__ __forceinline__ void fused_couple(const NetArgs& a, const float* pl, 
     double d = (double)lsum;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o, 64);
-    if (lane == 0) a.fz_ldpart[(size_t)blockIdx.x * 8 + wave] = d;
+    if (lane == 0) a.fz_ldpart[(size_t)blockIdx.x * (PXW / 32) + wave] = d;
   }
 }
 

@@ -4,6 +4,7 @@
 // in parallel; glowk.hip sees extern template declarations.
 #pragma once
 #include "glowk_kernels.h"
+#include "glowk_co.h"
 
 #include <cstdlib>
 #include <string>
@@ -11,6 +12,7 @@
 namespace glowk_detail {
 
 int num_cus();                          // compute units of the current device (queried once); glowk.hip
+void note_co();                         // ... and that it took the co-resident form (after note_family)
 void note_family(int family);           // which kernel family a (non-dry) launch took: 0 k_net_f32, 1 k_net_h3 (32x32x16), 2 k_net_h3s
                                         // (16x16x32), 3 its half-wave form, 4 the fused network + coupling kernel; glowk.hip
 bool h3_shape16();                      // GLOWK_H3_SHAPE=32 keeps the forward pass on the 32x32x16 kernel (A/B timing); glowk.hip
@@ -29,7 +31,7 @@ struct EnvSwitches {
   bool no_fuse;             // GLOWK_NO_FUSE: network + coupling as two kernels at the 4-channel level
   bool wgrad_plain;         // GLOWK_WGRAD_PLAIN: the weight-gradient GEMM's plain (not fenced) round
   bool wgrad_128;           // GLOWK_WGRAD_128: 128 x 128 tiles in the exact weight-gradient GEMM
-  bool co_off;              // GLOWK_CO_OFF: never the co-resident (two workgroups per CU) form of the fused kernel
+  bool co_off;              // GLOWK_CO_OFF: never the co-resident (two workgroups per CU) form of the forward network
 };
 const EnvSwitches& env();
 
@@ -83,6 +85,23 @@ int launch_h3s(const NetArgs& a, hipStream_t s, bool dry) {
     // the coupling fused into the kernel (glowk_kernels.h: fused_couple) where the caller asks for it (NetArgs::fuse: plain forward
     // direction, geometry checked by the host), the level has four channels and both passes run in one workgroup: answers 100 =
     // "no P was written, the step's output is in place (but for the rows k_couple_edge finishes)"
+    // the co-resident form (glowk_co.h: four-wave / 128-pixel workgroups, two to a CU) of the plain forward network, fused (101) or
+    // writing P once (1), where the caller allows it (NetArgs::co) and the grid fills the chip with it
+    if constexpr (RingC<KIN, MOUT, NF, MODE>::FITS) {
+      const int wgc = (a.Q + CO_PX - 1) / CO_PX;
+      if (a.co && !env().co_off && wgc >= 4 * cus) {
+        if constexpr (RingC<KIN, MOUT, NF, MODE | 16>::FITS) {
+          if (a.fuse) {
+            if (!dry) { hipLaunchKernelGGL((k_net_h3c<KIN, MOUT, NF, MODE | 16>), dim3(wgc), dim3(256), 0, s, a); note_family(4); note_co(); }
+            return 101;
+          }
+        }
+        if (!a.fuse) {
+          if (!dry) { hipLaunchKernelGGL((k_net_h3c<KIN, MOUT, NF, MODE>), dim3(wgc), dim3(256), 0, s, a); note_family(2); note_co(); }
+          return 1;
+        }
+      }
+    }
     if constexpr ((MODE == NET_FWD || MODE == NET_FWD2 || MODE == NET_FWD_SAVE) && MOUT == 36) {
       if constexpr (RingS<KIN, MOUT, NF, MODE | 16, 2>::FITS && RingS<KIN, MOUT, NF, MODE | 16, 2>::MERGE) {
         if (a.fuse && !split) {

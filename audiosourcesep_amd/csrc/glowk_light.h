@@ -390,14 +390,16 @@ struct EdgeArgs {
   float* osave;          // saving pass: [Q][2] pre-tanh log_s inputs of the edge pixels (complete sums), or null
   int h, w;
   int* flag;
+  int pxw;               // pixels per workgroup of the fused kernel that left `edge` / `ldpart`: 256 (k_net_h3s) or 128 (k_net_h3c)
 };
 
 __global__ __launch_bounds__(256) void k_couple_edge(EdgeArgs a) {
   __shared__ double red[4];
   const int n = blockIdx.x, w = a.w, hw = a.h * a.w;
-  const int nb = hw >= 256 ? hw / 256 : 1, rows = 256 / w;
+  const int pxw = a.pxw;                                              // pixels per workgroup of the fused kernel (256, or 128: co-resident form)
+  const int nb = hw >= pxw ? hw / pxw : 1, rows = pxw / w;
   float lsum = 0.0f;
-  const int nedge = hw > 256 ? 2 * w * (nb - 1) : 0;
+  const int nedge = hw > pxw ? 2 * w * (nb - 1) : 0;
   for (int t = threadIdx.x; t < nedge; t += 256) {
     const int b = 1 + t / (2 * w), lower = (t / w) & 1, j = t % w;
     const size_t wgA = (size_t)n * nb + b - 1, wgB = wgA + 1;         // the workgroups above and below the boundary

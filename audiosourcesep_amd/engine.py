@@ -222,10 +222,11 @@ class GlowEngine:
         return int(self.lib.glowk_fused_steps(self.h))
 
     def kernel_families(self):
-        """Coupling-network launches so far by kernel family: dict f32 / h3_32x32x16 / h3s_16x16x32 / h3s_half / fused."""
-        out = (ctypes.c_int64 * 5)()
+        """Coupling-network launches so far by kernel family: dict f32 / h3_32x32x16 / h3s_16x16x32 / h3s_half / fused, and
+        "co_resident": how many of the h3s_16x16x32 / fused launches took the four-wave, two-workgroups-per-CU form."""
+        out = (ctypes.c_int64 * 6)()
         _lib.check(self.lib.glowk_kernel_families(self.h, out))
-        return dict(zip(("f32", "h3_32x32x16", "h3s_16x16x32", "h3s_half", "fused"), [int(v) for v in out]))
+        return dict(zip(("f32", "h3_32x32x16", "h3s_16x16x32", "h3s_half", "fused", "co_resident"), [int(v) for v in out]))
 
     def profile_begin(self):
         _lib.check(self.lib.glowk_profile_begin(self.h))

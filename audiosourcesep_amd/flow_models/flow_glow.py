@@ -52,6 +52,21 @@ def _step_variable_shapes(c, F):
     ]
 
 
+def _shard_offset(n_local, device, group=None):
+    """Tiles held by the ranks below this one (exclusive scan of the local batch sizes over ``group``); 0 without a process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world == 1:
+        return 0
+    on_dev = device.type == "cuda" and dist.get_backend(group) != "gloo"
+    mine = torch.tensor([int(n_local)], dtype=torch.int64, device=device if on_dev else "cpu")
+    sizes = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(sizes, mine, group=group)
+    return int(sum(int(t.item()) for t in sizes[:rank]))
+
+
 class _LogProbFn(torch.autograd.Function):
     """``log_prob`` with reverse mode wrt the input: what ``tf.GradientTape`` gives compute_grad_logprob
     (run_basis_sep.py:73-79).  Forward and input gradient both come from ``glowk_log_prob_grad``."""
@@ -225,8 +240,9 @@ class GlowFlow:
         the tiles first (train_noisy_glow.py:31: the noise-conditioned priors of BASIS; fresh noise every step and on every
         replica), drawn by the engine's device RNG: stream ``seed``, step = ``step`` or, when None, this flow's own count of
         noisy steps (so two consecutive calls never reuse a draw), element offset = ``tile_offset`` tiles -- default: this rank's
-        position in the global batch, rank * local batch, so no two ranks draw the same noise and a tile's draw does not depend
-        on the world size.  Returns the global loss (fp64 scalar tensor)."""
+        position in the global batch = the number of tiles the lower ranks hold (an all-gather of the local batch sizes: shards
+        may be uneven, ``distributed.shard_bounds`` gives the first ranks one tile more), so no two ranks draw the same noise and
+        a tile's draw does not depend on the world size.  Returns the global loss (fp64 scalar tensor)."""
         from ..distributed import distributed_train_step
         x = self.engine._in(x, self.engine.data_shape)
         if noise_std:
@@ -236,7 +252,7 @@ class GlowFlow:
                 step = self._noise_step
             self._noise_step = int(step) + 1
             if tile_offset is None:
-                tile_offset = dist.get_rank(group) * x.shape[0] if (dist.is_available() and dist.is_initialized()) else 0
+                tile_offset = _shard_offset(x.shape[0], x.device, group)
             elems = int(np.prod(self.engine.data_shape))
             x = add_device_noise(x, noise_std, seed, step, which=2, offset=int(tile_offset) * elems)
         gb = int(global_batch_size) if global_batch_size else x.shape[0]

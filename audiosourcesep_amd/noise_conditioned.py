@@ -56,8 +56,10 @@ def fine_tune_ladder(flow, tiles, sigmas, steps_per_level, lr=1e-3, optimizer="a
     if len(steps) != len(sigmas):
         raise ValueError("steps_per_level must be an int or one int per sigma")
     world = 1
-    if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         world = torch.distributed.get_world_size(group)
+    elif group is not None:
+        raise ValueError("fine_tune_ladder: a process group was given but torch.distributed is not initialised")
     models, losses = {}, {}
     pos = 0
     for sigma, n_steps in zip(sigmas, steps):

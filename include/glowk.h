@@ -214,10 +214,11 @@ int glowk_profile_begin(glowk_handle* h);
 /* number of flow steps so far that ran as ONE kernel -- coupling network + affine coupling + next step's ActNorm / 1x1 fused
  * (flow_glow.py:21-22 as a single launch) -- rather than as network kernel + coupling kernel */
 int64_t glowk_fused_steps(const glowk_handle* h);
-/* coupling-network launches of the handle so far, by kernel family: out5[0] the exact fp32 kernel (k_net_f32), [1] the split
+/* coupling-network launches of the handle so far, by kernel family: out6[0] the exact fp32 kernel (k_net_f32), [1] the split
  * kernel on v_mfma_f32_32x32x16_f16 (k_net_h3), [2] on 16x16x32 (k_net_h3s), [3] its 128-pixel half-wave form, [4] the fused
- * network + coupling kernel.  A handle in a split arithmetic whose out5[0] stays put ran no level on the exact kernels. */
-int glowk_kernel_families(const glowk_handle* h, int64_t* out5);
+ * network + coupling kernel, [5] of these ([2] or [4]) the launches that took the co-resident form (k_net_h3c: four-wave / 128-pixel
+ * workgroups, two to a CU).  A handle in a split arithmetic whose out6[0] stays put ran no level on the exact kernels. */
+int glowk_kernel_families(const glowk_handle* h, int64_t* out6);
 int glowk_profile_end(glowk_handle* h, glowk_profile* out);
 
 /* --- sub-bijectors, as exercised one by one by unittest_flow_models.py:124-186 --------------------- */

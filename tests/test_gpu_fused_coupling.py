@@ -123,6 +123,68 @@ def test_fused_saving_pass_feeds_the_backward_sweep(name):
     assert eng.range_status() == (False, 0)
 
 
+CO_CASES = {
+    # name: (cfg, tiles) -- grids of >= 4 x CUs 128-pixel workgroups at the 4-channel level, geometries with and without edge rows
+    "64x64_8_wgs_per_tile": (GlowConfig(H=64, W=64, C=1, L=3, K=2, F=512), 160),
+    "96x64_12_wgs_per_tile": (GlowConfig(H=96, W=64, C=1, L=3, K=2, F=512), 100),
+    "128x128_w64_two_rows_per_wg": (GlowConfig(H=128, W=128, C=1, L=3, K=2, F=512), 40),
+    "32x32_two_wgs_per_tile_ragged": (GlowConfig(H=32, W=32, C=1, L=2, K=3, F=512), 555),
+    "16x16_two_tiles_per_wg_ragged": (GlowConfig(H=16, W=16, C=1, L=2, K=2, F=256), 2231),
+    "64x32_w16_F384": (GlowConfig(H=64, W=32, C=1, L=3, K=2, F=384), 301),
+}
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16x2"])
+@pytest.mark.parametrize("name", list(CO_CASES))
+def test_co_resident_form_equals_the_one_workgroup_per_cu_form(name, precision):
+    """k_net_h3c (glowk_co.h: four-wave / 128-pixel workgroups, two to a CU, a ring of 16-KiB units) against k_net_h3s (eight waves /
+    256 pixels, one per CU) on the same weights: the per-pixel arithmetic -- MFMA order, split, epilogues -- is the same, so the
+    network's outputs are bit for bit equal; in the fused form only the set of edge rows k_couple_edge finishes and the order of the
+    log-det partials differ.  Both the fused (GLOWK_NO_FUSE unset) and the P-to-HBM form (set), forward and inverse direction."""
+    cfg, n = CO_CASES[name]
+    eng, _ = calibrated_engine(cfg, device=0, init_tiles=32)
+    eng.set_precision({"f16x3": _lib.PREC_F16X3, "f16x2": _lib.PREC_F16X2}[precision])
+    eng.set_range_policy("error")
+    x = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=8)).cuda()
+    out = {}
+    try:
+        for co in (False, True):
+            for fuse in (True, False):
+                _setenv("GLOWK_CO_OFF", not co)
+                _setenv("GLOWK_NO_FUSE", not fuse)
+                before = eng.kernel_families()
+                lp, z = eng.log_prob(x, return_latent=True)
+                xr = eng.inverse(z)
+                torch.cuda.synchronize()
+                fam = {k: v - before[k] for k, v in eng.kernel_families().items()}
+                out[(co, fuse)] = (lp, z, xr, fam)
+    finally:
+        _setenv("GLOWK_CO_OFF", False)
+        _setenv("GLOWK_NO_FUSE", False)
+    K = cfg.K
+    assert out[(False, True)][3]["co_resident"] == 0 and out[(False, False)][3]["co_resident"] == 0
+    for fuse in (True, False):
+        fam = out[(True, fuse)][3]
+        assert fam["co_resident"] == 2 * K, (fuse, fam)               # every step of the 4-channel level, forward and inverse
+        assert (fam["fused"] == 2 * K) == fuse, (fuse, fam)
+    # P-to-HBM form: the network kernel alone differs, and its outputs are bit for bit equal
+    for i in range(3):
+        assert torch.equal(out[(True, False)][i], out[(False, False)][i]), (name, precision, i)
+    # fused form: edge rows / log-det partials are summed in another order
+    lp_a, z_a, x_a, _ = out[(True, True)]
+    lp_b, z_b, x_b, _ = out[(False, True)]
+    # (two-term mode: activations are ROUNDED to fp16 -- not smooth in their input, so rounding-level differences of one step's edge
+    #  rows are amplified by the next; DESIGN section 5: inverse(forward(x)) returns x to 0.06 dB there, not 2e-4 dB)
+    two = precision == "f16x2"
+    assert float(((lp_a - lp_b).abs() / lp_b.abs()).max()) < (2e-5 if two else 2e-7)
+    assert float((z_a - z_b).abs().max()) < (2e-3 if two else 4e-6)
+    assert float((x_a - x_b).abs().max()) < (0.2 if two else 2e-3)        # (dB; inverse(forward(x)) itself is ~2e-4 dB from x)
+    assert float((x_a - x).abs().max()) < (0.5 if two else 2e-2)
+    lp2, z2 = eng.log_prob(x, return_latent=True)                            # (switches back off: the default form again)
+    assert torch.equal(lp2, lp_b) and torch.equal(z2, z_b)
+    assert eng.range_status() == (False, 0)
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("shape", ["64x64_L3", "32x32_L2_notop", "24x24_L2_ragged"])
 def test_one_lane_per_pixel_backward_merge_equals_the_four_lane_form(precision, shape):
