@@ -180,8 +180,8 @@ def test_co_resident_form_equals_the_one_workgroup_per_cu_form(name, precision):
     assert float((z_a - z_b).abs().max()) < (2e-3 if two else 4e-6)
     assert float((x_a - x_b).abs().max()) < (0.2 if two else 2e-3)        # (dB; inverse(forward(x)) itself is ~2e-4 dB from x)
     assert float((x_a - x).abs().max()) < (0.5 if two else 2e-2)
-    lp2, z2 = eng.log_prob(x, return_latent=True)                            # (switches back off: the default form again)
-    assert torch.equal(lp2, lp_b) and torch.equal(z2, z_b)
+    lp2, z2 = eng.log_prob(x, return_latent=True)                            # (no switch set: the default form -- co-resident -- again,
+    assert torch.equal(lp2, lp_a) and torch.equal(z2, z_a)                   #  bit for bit what it gave before)
     assert eng.range_status() == (False, 0)
 
 
