@@ -549,7 +549,9 @@ def main():
         for _ in range(warmup):
             step()
         res = {"eng": eng, "params": params, "x": x}
+        fam0 = eng.kernel_families()
         res["main"] = timed(steps)
+        res["co"] = eng.kernel_families()["co_resident"] > fam0["co_resident"]     # the level-0 launches took the co-resident form
         assert torch.isfinite(total).all(), "non-finite log-likelihood"
         assert eng.range_status() == (False, 0), "the range guard fired"
         res["lp_main"] = lp.clone()
@@ -571,8 +573,9 @@ def main():
             eng.set_precision(PREC[precision])
         return res
 
-    def roofline_obj(cfg, precision, pr):
+    def roofline_obj(cfg, precision, pr, co=False):
         h0, w0, c0 = cfg.level_shapes()[0]
+        h3name = "k_net_h3c (co-resident: 4 waves / 128 pixels, two workgroups per CU)" if co else "k_net_h3s"
         flop_launch = net_flop_per_pixel(c0, cfg.F) * n * h0 * w0
         ms0, launches0 = pr[0]
         avg_ms = ms0 / max(launches0, 1)
@@ -581,10 +584,10 @@ def main():
             kernel, peak = "k_net_f32<CI=%d,NF=%d> (level 0)" % (c0 // 2, cfg.F // 32), PEAK_F32_MFMA_TFLOPS
             note = "fp32-input MFMA peak"
         elif precision == "f16x2":
-            kernel, peak = "k_net_h3s<CI=%d,NF=%d,two-term%s> (level 0)" % (c0 // 2, cfg.F // 32, ", coupling fused in" if c0 == 4 else ""), PEAK_F16_MFMA_TFLOPS / 2.0
+            kernel, peak = "%s<CI=%d,NF=%d,two-term%s> (level 0)" % (h3name, c0 // 2, cfg.F // 32, ", coupling fused in" if c0 == 4 else ""), PEAK_F16_MFMA_TFLOPS / 2.0
             note = "fp16 dense MFMA peak / 2 (two fp16 MFMAs per product)"
         else:
-            kernel, peak = "k_net_h3s<CI=%d,NF=%d%s> (level 0)" % (c0 // 2, cfg.F // 32, ", coupling fused in" if c0 == 4 else ""), PEAK_F16_MFMA_TFLOPS / 3.0
+            kernel, peak = "%s<CI=%d,NF=%d%s> (level 0)" % (h3name, c0 // 2, cfg.F // 32, ", coupling fused in" if c0 == 4 else ""), PEAK_F16_MFMA_TFLOPS / 3.0
             note = "fp16 dense MFMA peak / 3 (three fp16 MFMAs per fp32-equivalent product)"
         # HBM bytes per launch and MFMA-pipe busy fraction come from separate rocprofv3 --pmc passes of this same command
         # (scripts/final_run.sh, summarised by scripts/pmc_summary.py), committed under profiles/: NOT measured by this process -- the
@@ -636,7 +639,7 @@ def main():
             "whole_path_tflops_fp32_equivalent": value / world * cfg.flop_per_tile() / 1e12,
             "hbm_frac_activations": value / world * cfg.act_bytes_per_tile() / 1e9 / PEAK_HBM_GBS,
             "k_net_share_of_step_time": sum(m for m, _ in prof) * 1e-3 / elapsed,
-            "roofline": roofline_obj(cfg, precision, prof),
+            "roofline": roofline_obj(cfg, precision, prof, res.get("co", False)),
         }
         if "other" in res:
             other, steps_o, elapsed_o, prof_o = res["other"]
@@ -650,7 +653,7 @@ def main():
             out["two_term_split_fp16"] = {
                 "value": n * world * steps_o / el2, "unit": "passes/s", "steps": steps_o, "ms_per_step": el2 / steps_o * 1e3,
                 "dtype": "f16x2", "dtype_note": dtype_note["f16x2"], "max_rel_diff_log_prob_vs_f32_%d_tiles" % n: d2,
-                "roofline": roofline_obj(cfg, "f16x2", pr2) if full else None}
+                "roofline": roofline_obj(cfg, "f16x2", pr2, res.get("co", False)) if full else None}
         return out
 
     res = measure(cfg, args.precision, args.steps, args.warmup, True)

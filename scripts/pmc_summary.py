@@ -14,8 +14,11 @@ from collections import defaultdict
 
 LEVEL0 = {   # config B, level 0 (32x32x4 tensors, n_filters 512): the kernel each arithmetic runs there
     "k_net_f32": "void k_net_f32<2, 36, 16, 0, false>(NetArgs)",
-    "k_net_h3s": "void k_net_h3s<2, 36, 16, 16, 2, false>(NetArgs)",            # round 3: MODE | 16 = the coupling fused into the kernel
-    "k_net_h3s_two_term": "void k_net_h3s<2, 36, 16, 19, 2, false>(NetArgs)",
+    # round 4: the headline launch is the co-resident form k_net_h3c (MODE | 16 = the coupling fused in); the short names stay -- bench.py
+    # reads them -- and take the one-workgroup-per-CU kernel where a trace (GLOWK_CO_OFF=1) holds that one instead
+    "k_net_h3s": ["void k_net_h3c<2, 36, 16, 16>(NetArgs)", "void k_net_h3s<2, 36, 16, 16, 2, false>(NetArgs)"],
+    "k_net_h3s_two_term": ["void k_net_h3c<2, 36, 16, 19>(NetArgs)", "void k_net_h3s<2, 36, 16, 19, 2, false>(NetArgs)"],
+    "k_net_h3s_one_per_cu": "void k_net_h3s<2, 36, 16, 16, 2, false>(NetArgs)",
     "k_net_h3s_unfused": "void k_net_h3s<2, 36, 16, 0, 2, false>(NetArgs)",      # (a GLOWK_NO_FUSE=1 pass, when the csv holds one)
     "k_net_h3s_two_term_unfused": "void k_net_h3s<2, 36, 16, 3, 2, false>(NetArgs)",
 }
@@ -46,9 +49,12 @@ def main():
             wr, nw = w.get(k, {}).get("WRITE_SIZE", (0.0, 0))
             res["kernels"][k] = {"launches": [nf, nw], "FETCH_SIZE_KiB_per_launch": fe, "WRITE_SIZE_KiB_per_launch": wr,
                                  "hbm_bytes_per_launch": (2.0 * fe + wr) * 1024.0}
-        for short, name in LEVEL0.items():
-            if name in res["kernels"]:
-                res["hbm_bytes_per_level0_launch"][short] = res["kernels"][name]["hbm_bytes_per_launch"]
+        for short, names in LEVEL0.items():
+            for name in ([names] if isinstance(names, str) else names):
+                if name in res["kernels"]:
+                    res["hbm_bytes_per_level0_launch"][short] = res["kernels"][name]["hbm_bytes_per_launch"]
+                    res.setdefault("level0_kernel_names", {})[short] = name
+                    break
     else:
         path, commit, out = sys.argv[2:5]
         res = {"build": commit, "simds": 1024, "formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)", "level0": {}, "kernels": {}}
@@ -64,9 +70,11 @@ def main():
                     if c in avg:
                         d[c + "_share_of_wave_cycles"] = avg[c] / avg["SQ_WAVE_CYCLES"]
             res["kernels"][k] = d
-        for short, name in LEVEL0.items():
-            if name in res["kernels"]:
-                res["level0"][short] = {x: y for x, y in res["kernels"][name].items() if x != "per_launch"}
+        for short, names in LEVEL0.items():
+            for name in ([names] if isinstance(names, str) else names):
+                if name in res["kernels"]:
+                    res["level0"][short] = dict({x: y for x, y in res["kernels"][name].items() if x != "per_launch"}, kernel=name)
+                    break
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: v for k, v in res.items() if k != "kernels"}, indent=1))
 
