@@ -2,7 +2,7 @@
 process while the timed workload runs in this one, and prints the distribution per phase: idle, exact-fp32 kernel, f16x3 kernel,
 two-term kernel.  (DESIGN section 5 "power": three builds with different cycle counts took the same time; this is the direct look.)
 
-    python scripts/power_probe.py [tiles=1024] [seconds_per_phase=4]
+    python scripts/power_probe.py [tiles=1024] [seconds_per_phase=4] [grad]        (grad: time log_prob_grad instead of log_prob)
 """
 import glob
 import json
@@ -39,11 +39,14 @@ def read(p):
 
 def sampler(stop, q, period):
     s = sensors()
+    only = os.environ.get("PROBE_CARD")          # e.g. card16: sample that card's sensors only
     rows = []
     while not stop.is_set():
         t = time.time()
         row = {"t": t}
         for hw, d in s.items():
+            if only and only not in hw:
+                continue
             for name, p in d.items():
                 v = read(p)
                 if v is None:
@@ -60,6 +63,7 @@ def sampler(stop, q, period):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     secs = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
+    grad = len(sys.argv) > 3 and sys.argv[3] == "grad"
     print("sensors:", json.dumps({k: sorted(v) for k, v in sensors().items()}))
     stop, q = mp.Event(), mp.Queue()
     proc = mp.Process(target=sampler, args=(stop, q, 0.02))
@@ -77,11 +81,12 @@ def main():
     t0 = time.time(); time.sleep(1.0); phases.append(("idle", t0, time.time(), None))
     for name, prec in (("f32", _lib.PREC_F32), ("f16x3", _lib.PREC_F16X3), ("f16x2", _lib.PREC_F16X2), ("f16x3_again", _lib.PREC_F16X3)):
         eng.set_precision(prec)
-        eng.log_prob(x, out=lp); torch.cuda.synchronize()
+        call = (lambda: eng.log_prob_grad(x)) if grad else (lambda: eng.log_prob(x, out=lp))
+        call(); torch.cuda.synchronize()
         t0 = time.time(); k = 0
         while time.time() - t0 < secs:
             for _ in range(4):
-                eng.log_prob(x, out=lp)
+                call()
             torch.cuda.synchronize(); k += 4
         t1 = time.time()
         phases.append((name, t0, t1, n * k / (t1 - t0)))
