@@ -240,23 +240,37 @@ def train_workload(cfg, n, precision, steps, warmup, rank, world, local_rank, di
     return el, fallbacks, pv
 
 
-def basis_workload(args, K, levels, train_steps, T, steps, warmup, rank, world, local_rank, dist, rehearsal, precision, sigma1=0.3):
+def basis_workload(args, K, levels, train_steps, T, steps, warmup, rank, world, local_rank, dist, rehearsal, precision, sigma1=0.3, parallel="replicas"):
     """BASELINE config 5 as it is meant: two noise-conditioned Glow priors (L = 3, n_filters = 512, K steps per level) are trained
     here with the repo's own training step on the reference's 30 real tiles per stem (tests/golden/basis_real_tiles.npz; the ladder
     of train_noisy_glow.py:309-358), kept resident per sigma, and the BASIS chain (run_basis_sep.py:217-260) runs on the 30 mixture
     tiles from the reference's uniform start in `precision` under GLOWK_RANGE_ERROR.  Timed: `steps` CONSECUTIVE Langevin steps of
     that chain at the last (smallest) sigma, after the chain has run T steps at every level -- no restart, the state carries over.
-    Every rank separates the same 30 tiles with its own noise stream (weak scaling of independent chains)."""
+    parallel = "replicas": every rank separates the same 30 tiles with its own noise stream (weak scaling of independent chains).
+    parallel = "prior": the ONE 30-tile problem over the job (strong scaling): rank r trains and holds only prior r % 2 and the tiles of
+    shard r // 2; per Langevin step it evaluates its own prior's gradient, the pair all-gathers the two gradients (RCCL), both run the
+    identical update (basis.prior_parallel_layout)."""
     from audiosourcesep_amd import basis
     from audiosourcesep_amd.flow_models.flow_builder import build_glow
     from audiosourcesep_amd.noise_conditioned import fine_tune_ladder, psnr_db, db_schedule
     f = np.load(os.path.join(ROOT, "tests", "golden", "basis_real_tiles.npz"))
     crop = getattr(args, "basis_crop", 0) or 96
     gt1, gt2, mixed = (torch.from_numpy(np.ascontiguousarray(f[k].astype(np.float32)[:, :crop]))[..., None].cuda() for k in ("gt1", "gt2", "mixed"))
+    pp = parallel == "prior"
+    lay = pair_group = None
+    if pp:
+        if dist is None or world % 2:
+            raise SystemExit("--basis-parallel prior needs an even number of ranks (--gpus 2, 4, ...)")
+        lay = basis.prior_parallel_layout(mixed.shape[0], world, rank)
+        pair_group = basis.make_pair_group(world, rank)
+        a, b = lay["bounds"]
+        gt1, gt2, mixed = gt1[a:b].contiguous(), gt2[a:b].contiguous(), mixed[a:b].contiguous()
     n = mixed.shape[0]
     t0 = time.perf_counter()
-    priors, ladders, fb_train, loss_curves = [], [], [], []
+    priors, ladders, fb_train, loss_curves = [None, None], [None, None], [], []
     for i, gt in enumerate((gt1, gt2)):
+        if pp and i != lay["prior"]:
+            continue                    # the pair partner owns this prior
         flow = build_glow(gt, [crop, 64, 1], L=3, K=K, n_filters=512, learntop=True, seed=100 + i, precision=precision, actnorm_init="runtime",
                           device=local_rank, data_type="melspec", minval=-100.0, maxval=20.0, use_logit=False)
         flow.engine.set_range_policy("fallback")
@@ -265,46 +279,55 @@ def basis_workload(args, K, levels, train_steps, T, steps, warmup, rank, world, 
         assert all(np.isfinite(losses[float(s)]).all() for s in sig_db), "prior training diverged"
         loss_curves.append({"%.3g" % float(s): [losses[float(s)][0], losses[float(s)][-1]] for s in sig_db})
         fb_train.append(flow.engine.range_status()[1])
-        priors.append(flow)
-        ladders.append(models)
+        priors[i] = flow
+        ladders[i] = models
     torch.cuda.synchronize()
     t_train = time.perf_counter() - t0
-    cfg = priors[0].cfg
-    engines = [m[float(s)].engine for m in ladders for s in sig_db]
+    cfg = [p for p in priors if p is not None][0].cfg
+    engines = [m[float(s)].engine for m in ladders if m is not None for s in sig_db]
+    seed_rank = 0 if pp else rank           # (prior-parallel: the pair shares ONE chain -- same start, same noise stream, tile offsets)
+    t_off = lay["bounds"][0] if pp else 0
+    e_off = t_off * int(np.prod(mixed.shape[1:]))
+    full_shape = (30,) + tuple(mixed.shape[1:])
     for e in engines:
         e.set_range_policy("error")
         e.range_probe_begin()
-    x1 = -100.0 + 120.0 * basis.device_randn(tuple(mixed.shape), mixed.device, seed=11 + rank, which=0, uniform=True)
-    x2 = -100.0 + 120.0 * basis.device_randn(tuple(mixed.shape), mixed.device, seed=11 + rank, which=1, uniform=True)
+    x1 = -100.0 + 120.0 * basis.device_randn(tuple(mixed.shape), mixed.device, seed=11 + seed_rank, which=0, uniform=True, offset=e_off)
+    x2 = -100.0 + 120.0 * basis.device_randn(tuple(mixed.shape), mixed.device, seed=11 + seed_rank, which=1, uniform=True, offset=e_off)
     start = (psnr_db(x1, gt1), psnr_db(x2, gt2))
     t0 = time.perf_counter()
     y1, y2, arr = basis.basis_outer_loop(mixed, x1, x2, priors[0], priors[1], sig_db, restore_1=ladders[0], restore_2=ladders[1], T=T,
-                                         delta=delta_db, seed=3 + rank)
+                                         delta=delta_db, seed=3 + seed_rank, tile_offset=t_off, prior_group=pair_group,
+                                         prior_index=lay["prior"] if pp else None)
     torch.cuda.synchronize()
     t_chain = time.perf_counter() - t0
     psnr_levels = [(round(psnr_db(a, gt1), 2), round(psnr_db(b, gt2), 2)) for a, b in zip(arr["x1"], arr["x2"])]
     assert torch.isfinite(y1).all() and torch.isfinite(y2).all(), "the chain left the finite range"
     # timed region: consecutive steps at the last level, the state carried from call to call
     last = len(sig_db) - 1
-    m1, m2 = ladders[0][float(sig_db[last])], ladders[1][float(sig_db[last])]
+    m1 = ladders[0][float(sig_db[last])] if ladders[0] is not None else None
+    m2 = ladders[1][float(sig_db[last])] if ladders[1] is not None else None
     state = {"x1": y1, "x2": y2, "t": len(sig_db) * T}
 
     def step():
         state["x1"], state["x2"] = basis.basis_inner_loop(mixed, state["x1"], state["x2"], m1, m2, last, sig_db, delta=delta_db, T=1,
-                                                          seed=3 + rank, step0=state["t"])
+                                                          seed=3 + seed_rank, step0=state["t"], offset=e_off, prior_group=pair_group,
+                                                          prior_index=lay["prior"] if pp else None)
         state["t"] += 1
     el = _timed_steps(step, steps, warmup, dist, rehearsal)
     assert torch.isfinite(state["x1"]).all() and torch.isfinite(state["x2"]).all(), "the chain left the finite range"
     margins = [e.range_probe_end() for e in engines]
     trips = sum(int(e.range_status()[0]) + e.range_status(sync=False)[1] for e in engines)
     end = (psnr_db(state["x1"], gt1), psnr_db(state["x2"], gt2))
-    flop_step = 2 * 2 * cfg.flop_per_tile()     # two priors, forward + data gradient (2x forward FLOPs with stored hiddens)
+    flop_step = (1 if pp else 2) * 2 * cfg.flop_per_tile()     # priors on this GPU x (forward + data gradient = 2x forward FLOPs)
     out = {
-        "value": n * world * steps / el, "unit": "tile-steps/s", "ms_per_step": el / steps * 1e3, "dtype": precision, "steps": steps,
+        "value": (30 if pp else n * world) * steps / el, "unit": "tile-steps/s", "ms_per_step": el / steps * 1e3, "dtype": precision, "steps": steps,
+        "parallelism": ("prior-parallel: rank r holds prior r %% 2 of tile shard r // 2 (%d shard(s)); one all-gather of the two gradients per step; "
+                        "STRONG scaling of the one 30-tile problem" % (world // 2)) if pp else "replicas: every rank runs its own 30-tile chain (weak scaling)",
         "config": {"workload": "BASIS Langevin steps, 2 trained noise-conditioned Glow priors, %dx64x1 real mel tiles (30 per GPU), L=3 K=%d "
                                "n_filters=512, %d sigma levels x T=%d then %d timed consecutive steps at sigma_L" % (crop, K, levels, T, steps)},
         "roofline": {"bound": "mfma", "achieved": n * steps / el * flop_step / 1e12, "peak": PEAK_F16_MFMA_TFLOPS / 3.0 if precision != "f32" else PEAK_F32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "note": "2 priors x (forward + data gradient = 2x forward FLOP) per tile-step"},
+                     "unit": "TFLOP/s", "note": "per GPU: %d prior(s) x (forward + data gradient = 2x forward FLOP) per tile-step" % (1 if pp else 2)},
         "range_guard": {"policy": "GLOWK_RANGE_ERROR on every chain step", "trips_or_fallbacks_in_chain": trips,
                         "largest_forward_input_over_limit": max(m[0] for m in margins), "backward_static_ratio": max(m[1] for m in margins),
                         "fallback_sweeps_while_training": fb_train},
@@ -344,7 +367,9 @@ def secondary_workload(args, cfg, rank, world, local_rank, dist, rehearsal, extr
                    roofline=grad_roofline(cfg, v / world, args.precision, 3))
     else:
         r = basis_workload(args, args.basis_K, args.basis_levels, args.basis_train_steps, args.basis_T, args.steps, args.warmup, rank, world,
-                           local_rank, dist, rehearsal, args.precision, sigma1=args.basis_sigma1)
+                           local_rank, dist, rehearsal, args.precision, sigma1=args.basis_sigma1, parallel=args.basis_parallel)
+        if args.basis_parallel == "prior":
+            base = dict(base, scaling="strong")
         out = dict(base, metric="BASIS Langevin tile-steps/sec (2 trained noise-conditioned Glow priors)", data="real mel tiles shipped with the reference (30 per stem); priors trained in this run", **r)
     out.update(extra)
     if rank == 0:
@@ -443,6 +468,9 @@ def main():
     ap.add_argument("--basis-levels", type=int, default=4, help="--workload basis: sigma levels of the ladder (reference: 10)")
     ap.add_argument("--basis-sigma1", type=float, default=0.3, help="--workload basis: largest sigma of the ladder in the reference's normalised units "
                                                                      "(reference: 1.0 = 120 dB; run_basis_sep.py:492)")
+    ap.add_argument("--basis-parallel", default="replicas", choices=["replicas", "prior"],
+                    help="--workload basis with --gpus N > 1: independent 30-tile chains per rank (weak scaling), or the ONE 30-tile problem "
+                         "prior-parallel over rank pairs composed with tile shards (strong scaling; N even)")
     ap.add_argument("--basis-train-steps", type=int, default=100, help="--workload basis: training steps per sigma level (3x at the first)")
     ap.add_argument("--basis-T", type=int, default=100, help="--workload basis: Langevin steps per sigma level before the timed region")
     ap.add_argument("--basis-crop", type=int, default=0, help="--workload basis: use only the first N mel bins of the 96x64 tiles (64: the 64x64 geometry of config B)")
