@@ -61,6 +61,7 @@ SYMBOLS = {
     "glowk_version": (_i, []),
     "glowk_last_error": (ctypes.c_char_p, []),
     "glowk_reload_env": (None, []),
+    "glowk_debug_stamps": (_i, [ctypes.POINTER(ctypes.c_uint64), _i]),
     "glowk_create": (_i, [ctypes.POINTER(GlowkConfigStruct), _i, ctypes.POINTER(_vp)]),
     "glowk_destroy": (_i, [_vp]),
     "glowk_tensor_size": (ctypes.c_size_t, [_vp, _i, _i]),

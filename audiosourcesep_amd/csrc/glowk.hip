@@ -62,7 +62,7 @@ struct glowk_handle {
   int precision = GLOWK_PREC_F32;
   int range_policy = GLOWK_RANGE_ERROR;
   int64_t range_fallbacks = 0;
-  int64_t family_launches[6] = {0, 0, 0, 0, 0, 0};   // coupling-network launches by kernel family (glowk_launch.h: note_family)
+  int64_t family_launches[7] = {0, 0, 0, 0, 0, 0, 0};   // coupling-network launches by kernel family (glowk_launch.h: note_family)
   int64_t fused_steps = 0;      // flow steps that ran as ONE network + coupling kernel (net_and_couple)
   int* d_flag = nullptr;        // sticky range flag (device), written by k_couple / k_bwd_light
   int* h_flag = nullptr;        // pinned host word it is read back into
@@ -155,18 +155,20 @@ bool h3_shape16() {
   return v == 1;
 }
 void launch_fail(const std::string& m) { fail(m); }
+unsigned long long* g_dbg_stamps = nullptr;    // glowk_debug_stamps
 static EnvSwitches read_env() {
   auto on = [](const char* n) { return getenv(n) != nullptr; };
   return EnvSwitches{on("GLOWK_HALF_OFF"), on("GLOWK_HALF_FORCE"), on("GLOWK_FAM16_SMALL"), on("GLOWK_BWD_LIGHT_4"), on("GLOWK_COUPLE_PER_SAMPLE"),
-                     on("GLOWK_COUPLE_4"), on("GLOWK_NO_FUSE"), on("GLOWK_WGRAD_PLAIN"), on("GLOWK_WGRAD_128"), on("GLOWK_CO_OFF")};
+                     on("GLOWK_COUPLE_4"), on("GLOWK_NO_FUSE"), on("GLOWK_WGRAD_PLAIN"), on("GLOWK_WGRAD_128"), on("GLOWK_CO_OFF"), on("GLOWK_Q_OFF")};
 }
 static EnvSwitches g_env = read_env();
 const EnvSwitches& env() { return g_env; }
 void reload_env() { g_env = read_env(); }
 thread_local int g_family = 0;
-thread_local bool g_co = false;
-void note_family(int family) { g_family = family; g_co = false; }
+thread_local bool g_co = false, g_q = false;
+void note_family(int family) { g_family = family; g_co = false; g_q = false; }
 void note_co() { g_co = true; }
+void note_q() { g_q = true; }
 // instantiated in glowk_net_inst.hip, one translation unit per (CI, NF)
 #define GLOWK_EXTERN_NET(CI_, NF_) extern template int launch_net_t<CI_, NF_>(const NetArgs&, int, hipStream_t, bool);
 GLOWK_EXTERN_NET(2, 16) GLOWK_EXTERN_NET(4, 16) GLOWK_EXTERN_NET(8, 16) GLOWK_EXTERN_NET(16, 16)
@@ -200,6 +202,7 @@ float bwd_norm_target(float xlim_b) {
 int launch_net_raw(int c, int F, const NetArgs& a, int mode, hipStream_t s, bool dry = false) {
   glowk_detail::g_family = 0;     // (the fp32 kernels do not announce themselves)
   glowk_detail::g_co = false;
+  glowk_detail::g_q = false;
 #define NETCASE(CI_, NF_) if (c == 2 * CI_ && F == 32 * NF_) return launch_net_t<CI_, NF_>(a, mode, s, dry);
   NETCASE(2, 16) NETCASE(4, 16) NETCASE(8, 16) NETCASE(16, 16)
   NETCASE(2, 12) NETCASE(4, 12) NETCASE(8, 12) NETCASE(16, 12)
@@ -214,7 +217,7 @@ int launch_net_raw(int c, int F, const NetArgs& a, int mode, hipStream_t s, bool
 int launch_net(glowk_handle* h, int level, int c, int F, const NetArgs& a, hipStream_t s, int mode = NET_FWD, int* np_out = nullptr) {
   if (!h->profiling) {
     const int np = launch_net_raw(c, F, a, mode, s);
-    if (np >= 0) { ++h->family_launches[glowk_detail::g_family]; if (glowk_detail::g_co) ++h->family_launches[5]; }
+    if (np >= 0) { ++h->family_launches[glowk_detail::g_family]; if (glowk_detail::g_co) ++h->family_launches[5]; if (glowk_detail::g_q) ++h->family_launches[6]; }
     if (np_out) *np_out = np;
     return np < 0 ? 1 : 0;
   }
@@ -226,7 +229,7 @@ int launch_net(glowk_handle* h, int level, int c, int F, const NetArgs& a, hipSt
   hipEvent_t e0 = h->ev_pool[h->ev_used], e1 = h->ev_pool[h->ev_used + 1];
   HIPCHK(hipEventRecord(e0, s));
   const int np = launch_net_raw(c, F, a, mode, s);
-  if (np >= 0) { ++h->family_launches[glowk_detail::g_family]; if (glowk_detail::g_co) ++h->family_launches[5]; }
+  if (np >= 0) { ++h->family_launches[glowk_detail::g_family]; if (glowk_detail::g_co) ++h->family_launches[5]; if (glowk_detail::g_q) ++h->family_launches[6]; }
   HIPCHK(hipEventRecord(e1, s));
   h->ev_used += 2;
   h->ev_level.push_back(level);
@@ -476,6 +479,7 @@ NetArgs net_args(glowk_handle* h, const Level& lv, const StepDev& sd, const floa
   a.bnorm = 1.0f;
   a.fuse = 0; a.co = glowk_detail::env().co_off ? 0 : 1; a.fz_osave = nullptr; a.fz_b3 = nullptr; a.fz_A = nullptr; a.fz_b = nullptr; a.fz_out = nullptr; a.fz_out_stride = 0; a.fz_out_off = 0; a.fz_inverse = 0;
   a.fz_edge = nullptr; a.fz_ldpart = nullptr;
+  a.dbg = glowk_detail::g_dbg_stamps;
   a.xmax_out = h->d_probe ? h->d_probe + ((&lv - h->levels.data()) * h->cfg.K + (&sd - lv.dev.data())) : nullptr;
   return a;
 }
@@ -1214,6 +1218,17 @@ extern "C" {
 
 int glowk_version(void) { return GLOWK_VERSION; }
 void glowk_reload_env(void) { glowk_detail::reload_env(); }
+
+int glowk_debug_stamps(unsigned long long* out, int n) {
+  if (n < 0 || n > 64 || (n && !out)) return fail("glowk_debug_stamps: n must be in [0, 64]");
+  if (!glowk_detail::g_dbg_stamps) {
+    HIPCHK(hipMalloc(&glowk_detail::g_dbg_stamps, 64 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(glowk_detail::g_dbg_stamps, 0, 64 * sizeof(unsigned long long)));
+  }
+  HIPCHK(hipDeviceSynchronize());
+  if (n) HIPCHK(hipMemcpy(out, glowk_detail::g_dbg_stamps, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return 0;
+}
 const char* glowk_last_error(void) { return g_err.c_str(); }
 
 int glowk_create(const glowk_config* cfg, int device, glowk_handle** out) {
@@ -1740,9 +1755,9 @@ int glowk_prior_log_prob(glowk_handle* h, const float* z_dev, int N, float* logp
 
 int64_t glowk_fused_steps(const glowk_handle* h) { return h ? h->fused_steps : -1; }
 
-int glowk_kernel_families(const glowk_handle* h, int64_t* out6) {
-  if (!h || !out6) return fail("null argument");
-  for (int i = 0; i < 6; ++i) out6[i] = h->family_launches[i];
+int glowk_kernel_families(const glowk_handle* h, int64_t* out7) {
+  if (!h || !out7) return fail("null argument");
+  for (int i = 0; i < 7; ++i) out7[i] = h->family_launches[i];
   return 0;
 }
 

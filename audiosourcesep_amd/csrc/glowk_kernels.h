@@ -75,7 +75,11 @@ struct NetArgs {
   // (before BatchNorm); backward: st1 = mask2 * conv3^T(g_o) (gradient wrt relu2's output), st2 = mask1 * (K2 g_a2) (wrt relu1's)
   float* st1;
   float* st2;
+  unsigned long long* dbg;   // diagnostic (glowk_debug_stamps), normally null: in-kernel time stamps of workgroup (0, 0)'s first lane
 };
+
+// time stamp i of the launch (constant 100 MHz counter): only when the host armed the debug buffer
+#define GLOWK_STAMP(a, i) do { if ((a).dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) (a).dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 // cache modifier of the planar hidden stores: they are streamed (gigabytes per launch, read back by the weight-gradient GEMMs after the
 // level's sweep), so non-temporal -- measured -1.7 % on a 256-tile parameter-gradient sweep against "" on one box, neutral at 32 tiles

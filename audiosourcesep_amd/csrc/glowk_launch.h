@@ -5,6 +5,7 @@
 #pragma once
 #include "glowk_kernels.h"
 #include "glowk_co.h"
+#include "glowk_q.h"
 
 #include <cstdlib>
 #include <string>
@@ -13,6 +14,7 @@ namespace glowk_detail {
 
 int num_cus();                          // compute units of the current device (queried once); glowk.hip
 void note_co();                         // ... and that it took the co-resident form (after note_family)
+void note_q();                          // ... or the small-grid form with all conv1 blocks first (glowk_q.h)
 void note_family(int family);           // which kernel family a (non-dry) launch took: 0 k_net_f32, 1 k_net_h3 (32x32x16), 2 k_net_h3s
                                         // (16x16x32), 3 its half-wave form, 4 the fused network + coupling kernel; glowk.hip
 bool h3_shape16();                      // GLOWK_H3_SHAPE=32 keeps the forward pass on the 32x32x16 kernel (A/B timing); glowk.hip
@@ -32,6 +34,7 @@ struct EnvSwitches {
   bool wgrad_plain;         // GLOWK_WGRAD_PLAIN: the weight-gradient GEMM's plain (not fenced) round
   bool wgrad_128;           // GLOWK_WGRAD_128: 128 x 128 tiles in the exact weight-gradient GEMM
   bool co_off;              // GLOWK_CO_OFF: never the co-resident (two workgroups per CU) form of the forward network
+  bool q_off;               // GLOWK_Q_OFF: never the all-conv1-first small-grid form (glowk_q.h)
 };
 const EnvSwitches& env();
 
@@ -134,6 +137,13 @@ int launch_h3s_half(const NetArgs& a, hipStream_t s, bool dry) {
   if constexpr (RingS<KIN, MOUT, NF, MODE | 32, 4>::FITS) {
     if (a.max_np < 4) return 0;
     const int wgs = (a.Q + 127) / 128;
+    // passes as workgroups of their own, each alone on its CU: the form with all conv1 blocks first (glowk_q.h), where it has an instance
+    if constexpr (RingQ<KIN, MOUT, NF, MODE>::FITS) {
+      if (4 * wgs <= num_cus() && !env().q_off) {
+        if (!dry) { hipLaunchKernelGGL((k_net_h3q<KIN, MOUT, NF, MODE>), dim3(wgs, 4), dim3(512), 0, s, a); note_family(3); note_q(); }
+        return 4;
+      }
+    }
     if (!dry) {
       if (4 * wgs <= num_cus()) hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE | 32, 4, true>), dim3(wgs, 4), dim3(512), 0, s, a);
       else hipLaunchKernelGGL((k_net_h3s<KIN, MOUT, NF, MODE | 32, 4, false>), dim3(wgs), dim3(512), 0, s, a);

@@ -223,10 +223,11 @@ class GlowEngine:
 
     def kernel_families(self):
         """Coupling-network launches so far by kernel family: dict f32 / h3_32x32x16 / h3s_16x16x32 / h3s_half / fused, and
-        "co_resident": how many of the h3s_16x16x32 / fused launches took the four-wave, two-workgroups-per-CU form."""
-        out = (ctypes.c_int64 * 6)()
+        "co_resident": how many of the h3s_16x16x32 / fused launches took the four-wave, two-workgroups-per-CU form; "small_grid_q": how
+        many of the h3s_half launches took the form with all conv1 blocks first (k_net_h3q)."""
+        out = (ctypes.c_int64 * 7)()
         _lib.check(self.lib.glowk_kernel_families(self.h, out))
-        return dict(zip(("f32", "h3_32x32x16", "h3s_16x16x32", "h3s_half", "fused", "co_resident"), [int(v) for v in out]))
+        return dict(zip(("f32", "h3_32x32x16", "h3s_16x16x32", "h3s_half", "fused", "co_resident", "small_grid_q"), [int(v) for v in out]))
 
     def profile_begin(self):
         _lib.check(self.lib.glowk_profile_begin(self.h))

@@ -120,6 +120,10 @@ const char* glowk_last_error(void);
  * A/B timing or a form-against-form parity test; none is needed for normal use) are read when the library is loaded, not per
  * launch; a process that changes its environment afterwards calls this to have them read again.  (No reference counterpart.) */
 void glowk_reload_env(void);
+/* Diagnostic: the first call arms in-kernel time stamps (later coupling-network launches of the instrumented kernels leave the
+ * constant-rate 100 MHz counter of workgroup (0, 0)'s first lane at their phase boundaries); every call waits for the device and
+ * copies the n <= 64 stamp words of the LAST such launch.  Current device.  (No reference counterpart.) */
+int glowk_debug_stamps(unsigned long long* out, int n);
 
 /* --- construction: replaces build_glow (flow_builder.py:60-146) --------------------------------- */
 int glowk_create(const glowk_config* cfg, int device, glowk_handle** out);
@@ -214,11 +218,12 @@ int glowk_profile_begin(glowk_handle* h);
 /* number of flow steps so far that ran as ONE kernel -- coupling network + affine coupling + next step's ActNorm / 1x1 fused
  * (flow_glow.py:21-22 as a single launch) -- rather than as network kernel + coupling kernel */
 int64_t glowk_fused_steps(const glowk_handle* h);
-/* coupling-network launches of the handle so far, by kernel family: out6[0] the exact fp32 kernel (k_net_f32), [1] the split
+/* coupling-network launches of the handle so far, by kernel family: out7[0] the exact fp32 kernel (k_net_f32), [1] the split
  * kernel on v_mfma_f32_32x32x16_f16 (k_net_h3), [2] on 16x16x32 (k_net_h3s), [3] its 128-pixel half-wave form, [4] the fused
  * network + coupling kernel, [5] of these ([2] or [4]) the launches that took the co-resident form (k_net_h3c: four-wave / 128-pixel
- * workgroups, two to a CU).  A handle in a split arithmetic whose out6[0] stays put ran no level on the exact kernels. */
-int glowk_kernel_families(const glowk_handle* h, int64_t* out6);
+ * workgroups, two to a CU), [6] of [3] the launches that took the small-grid form with all conv1 blocks first (k_net_h3q).  A handle
+ * in a split arithmetic whose out7[0] stays put ran no level on the exact kernels. */
+int glowk_kernel_families(const glowk_handle* h, int64_t* out7);
 int glowk_profile_end(glowk_handle* h, glowk_profile* out);
 
 /* --- sub-bijectors, as exercised one by one by unittest_flow_models.py:124-186 --------------------- */
