@@ -207,6 +207,10 @@ class GlowEngine:
                     hi = mid - 1
         else:
             lo = hi
+        # never below a batch this handle has already run through the gradient path: its buffers exist (the training buffers of
+        # glowk_param_grad are not part of `own`, so free memory -- and with it the budget -- drops after the first training step;
+        # round-3 advisor: a batch that ran on step 1 must not be refused on step 2)
+        lo = max(lo, min(getattr(self, "_ran_grad", 0), self.max_tiles))
         self._grad_chunk = (key, lo)
         return lo
 
@@ -332,6 +336,7 @@ class GlowEngine:
             chunk = min(chunk, self.grad_max_tiles)
         for a, b in self._chunks(n, chunk):
             self._compute(self.lib.glowk_log_prob_grad(self.h, _ptr(x[a:b]), b - a, _ptr(lp[a:b]), _ptr(dx[a:b]), self._stream()))
+        self._ran_grad = max(getattr(self, "_ran_grad", 0), min(n, chunk))
         return lp, dx
 
     # ---- training step (train_glow.py:29-44) ------------------------------------------------------------
@@ -358,6 +363,9 @@ class GlowEngine:
         if grad is None:
             grad = self._new(self.param_vector_size)
         self._compute(self.lib.glowk_param_grad(self.h, _ptr(x), n, float(scale), _ptr(lp), _ptr(grad), self._stream()))
+        if n > getattr(self, "_ran_grad", 0):
+            self._ran_grad = n
+            self._grad_chunk = (None, 0)      # (new training buffers changed the memory picture: size the chunk again)
         return lp, grad
 
     def apply_gradients(self, grad, optimizer="adamax", lr=1e-3):
