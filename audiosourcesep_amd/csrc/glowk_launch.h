@@ -68,6 +68,18 @@ int launch_h3(const NetArgs& a, hipStream_t s, bool dry) {
   return 0;
 }
 
+// does the runtime place two workgroups of this co-resident instance on a CU?  (asked once per instance: one device type per process)
+template <class Kernel>
+inline bool co_two_per_cu(Kernel kernel) {
+  static int blocks = -1;
+  if (blocks < 0) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    blocks = n;
+  }
+  return blocks >= 2;
+}
+
 template <int KIN, int MOUT, int NF, int MODE>
 int launch_h3s(const NetArgs& a, hipStream_t s, bool dry) {
   constexpr bool F2 = RingS<KIN, MOUT, NF, MODE, 2>::FITS, F4 = RingS<KIN, MOUT, NF, MODE, 4>::FITS;
@@ -94,12 +106,14 @@ int launch_h3s(const NetArgs& a, hipStream_t s, bool dry) {
       const int wgc = (a.Q + CO_PX - 1) / CO_PX;
       if (a.co && !env().co_off && wgc >= 4 * cus) {
         if constexpr (RingC<KIN, MOUT, NF, MODE | 16>::FITS) {
-          if (a.fuse) {
+          // (the form only pays with TWO workgroups per CU -- 2 x 78.8 KB of LDS, 2 x 4 x 248 VGPRs: ask the runtime once per instance, and
+          //  keep the eight-wave kernel where a driver / device leaves room for one)
+          if (a.fuse && co_two_per_cu(k_net_h3c<KIN, MOUT, NF, MODE | 16>)) {
             if (!dry) { hipLaunchKernelGGL((k_net_h3c<KIN, MOUT, NF, MODE | 16>), dim3(wgc), dim3(256), 0, s, a); note_family(4); note_co(); }
             return 101;
           }
         }
-        if (!a.fuse) {
+        if (!a.fuse && co_two_per_cu(k_net_h3c<KIN, MOUT, NF, MODE>)) {
           if (!dry) { hipLaunchKernelGGL((k_net_h3c<KIN, MOUT, NF, MODE>), dim3(wgc), dim3(256), 0, s, a); note_family(2); note_co(); }
           return 1;
         }
