@@ -21,6 +21,13 @@
 // as "unit 2 NF").  The waits are counted: vmcnt counts in issue order, so "everything but the n youngest DMA instructions of this
 // wave has landed" is exactly what each op boundary needs (4 pieces per wave and unit, 1 per conv1 block); the barrier publishes it.
 // The slots are distinct static __shared__ objects with static roles (glowk_kernels.h, rule 1): M0 always holds the first halves.
+//
+// Modes (MODE & 7): the plain forward network (NET_FWD, NET_FWD2), the forward network of the gradient path (NET_FWD_SAVE: ReLU masks
+// stored from X and Z) and the backward network (NET_BWD, 4-channel level: 18 output rows = two conv3 units; the forward pass's masks
+// of the workgroup's four 32-pixel blocks in LDS; every pixel's gradient normalised by a power of two) -- the mask layout is that of the
+// eight-wave 16x16x32 kernels (one entry per 32-pixel block of a wave), so either form can follow the other.  MODE | 16: the coupling
+// fused in (forward modes).  SPLIT: grid.y = 2 and every workgroup runs ONE pass (small grids: 2 x Q/128 workgroups of four waves,
+// two to a CU; each pass leaves its own partial P).
 #pragma once
 #include "glowk_kernels.h"
 
@@ -29,18 +36,23 @@ constexpr int CO_PSTR = 132;        // fused coupling: floats per LDS row of P (
 
 template <int KIN, int MOUT, int NF, int MODE>
 struct RingC {
-  using S = RingS<KIN, MOUT, NF, (MODE & 7), 2>;       // per-wave tiling, weight image, epilogue constants: those of the two-pass form
+  static constexpr int MODE7 = MODE & 7;
+  using S = RingS<KIN, MOUT, NF, MODE7, 2>;            // per-wave tiling, weight image, epilogue constants: those of the two-pass form
   static constexpr bool FUSE = (MODE & 16) != 0;
+  static constexpr bool SAVE = MODE7 == NET_FWD_SAVE, BWD = MODE7 == NET_BWD;
   static constexpr int NFH = S::NFH, NRB = S::NRB, NMT = S::NMT, KS = S::KS;
   static constexpr int UNITP = S::MAINP / 2;            // 1-KiB pieces per unit
   static constexpr int UNIT4 = S::MAIN4 / 2;            // float4 per unit
   static constexpr int PPW = UNITP / 4;                 // DMA instructions per wave and unit
   static constexpr int NG = NFH / 2;                    // groups of 12 MFMAs (two row blocks x two pixel halves x three terms) per Y half
   static constexpr int K1PW = (S::K1P + 3) / 4;         // DMA instructions per wave and conv1 block
-  static constexpr size_t LDS_BYTES = (size_t)3 * UNIT4 * 16 + (size_t)2 * S::K14 * 16 + (size_t)S::EPN * 4 +
+  static constexpr int EPN = BWD ? 0 : S::EPN;          // (the backward network has no epilogue constants)
+  static constexpr int MASKN = BWD ? 2 * 4 * NF * 64 : 0;   // backward: LDS copy of the masks [mask1 | mask2][wave][hidden block][lane], entries
+  static constexpr size_t LDS_BYTES = (size_t)3 * UNIT4 * 16 + (size_t)2 * S::K14 * 16 + (size_t)EPN * 4 + (size_t)MASKN * 2 +
                                       (FUSE ? (size_t)36 * CO_PSTR * 4 + CO_PX * 16 : 0);
-  static constexpr bool FITS = ((MODE & 7) == NET_FWD || (MODE & 7) == NET_FWD2) && !(MODE & (8 | 32)) && MOUT == 36 && S::NGRP == 1 && NMT == 3 &&
-                               KS <= 3 && NF % 4 == 0 && NFH >= 2 && NFH % 2 == 0 && UNITP % 4 == 0 && PPW == NG && 2 * LDS_BYTES <= 160 * 1024 + 1;   // (diagnostic paddings aside)
+  static constexpr bool FITS = (MODE7 == NET_FWD || MODE7 == NET_FWD2 || SAVE || BWD) && !(MODE & (8 | 32)) && S::NGRP == 1 && (NMT == 2 || NMT == 3) &&
+                               (!FUSE || (MOUT == 36 && !BWD)) && KS <= 3 && NF % 4 == 0 && NFH >= 2 && NFH % 2 == 0 && UNITP % 4 == 0 && PPW == NG &&
+                               2 * LDS_BYTES <= 160 * 1024 + 1;   // (diagnostic paddings aside)
   __device__ static const float4* main_unit(const float4* img, int pass, int i, int half) { return S::main_chunk(img, pass, i) + (size_t)half * UNIT4; }
   __device__ static const float4* out_unit(const float4* img, int pass, int z) { return S::out_chunk(img, pass, 0) + (size_t)z * UNIT4; }
 };
@@ -53,18 +65,26 @@ __device__ __forceinline__ void co_bar() {
   h3_barrier();
 }
 
-// end of an op: all but the n youngest DMA instructions of this wave have landed, then the workgroup barrier
+// end of an op: all but the n youngest vector-memory operations of this wave are done, its LDS reads have retired, then the workgroup
+// barrier.  (lgkmcnt(0): the first build waited on vmcnt alone and lost ~0.2 % of the waves' results under a co-resident partner -- an
+// LDS read still in flight when the wave passed the barrier after which another wave's DMA refills the slot)
 template <int N>
 __device__ __forceinline__ void co_end() {
 #ifdef GLOWK_EXP_CONOLGKM
   __builtin_amdgcn_s_waitcnt((N & 15) | 0x0F70 | ((N >> 4) << 14));   // vmcnt(N); expcnt / lgkmcnt: no wait
 #else
-  __builtin_amdgcn_s_waitcnt((N & 15) | 0x0070 | ((N >> 4) << 14));   // vmcnt(N) and lgkmcnt(0): this wave's LDS reads of the op have retired too
+  __builtin_amdgcn_s_waitcnt((N & 15) | 0x0070 | ((N >> 4) << 14));   // vmcnt(N) and lgkmcnt(0)
 #endif
   h3_barrier();
 #ifdef GLOWK_EXP_COSLEEP   // (diagnostic build: a pause between the publishing barrier and the first read of the published unit)
   __builtin_amdgcn_s_sleep(GLOWK_EXP_COSLEEP);
 #endif
+}
+// ... with `more` extra operations (the op's stores: a saving launch's ReLU mask) allowed to stay in flight, decided per wave at run time
+template <int N>
+__device__ __forceinline__ void co_end_st(bool more) {
+  if (more) co_end<N + 1>();
+  else co_end<N>();
 }
 
 struct CoCtx {
@@ -126,29 +146,42 @@ __device__ __forceinline__ void co_Y(const float4* slot, const h8 (&bh)[2], cons
   }
 }
 
-// Z: conv3 unit z of a pass = NFH tiles (16 rows x one hidden block) in (hidden block, row block) order; pass 0 keeps its sums (bias
-// included) in `keep`, the last pass adds them and writes the rows -- to HBM (P, one buffer) or, fused, to the workgroup's LDS copy
-template <int KIN, int MOUT, int NF, int MODE, int PASS, int Z>
-__device__ __forceinline__ void co_Z(const NetArgs& a, const CoCtx& c, const float* epl, float* pl, f32x4 (&acc2)[(RingC<KIN, MOUT, NF, MODE>::NRB)][2],
-                                     f32x4 (&acc3)[3][2], h8 (&bh)[2], h8 (&bl)[2], const int (&q)[2], const bool (&qok)[2], int lane, int kq,
-                                     f32x4 (&keep)[3][2]) {
+// Z: conv3 unit z of a pass = NFH tiles (16 rows x one hidden block) in (hidden block, row block) order.  Two passes in one workgroup:
+// pass 0 keeps its sums (bias included) in `keep`, the last pass adds them and writes the rows -- to HBM (P, one buffer) or, fused, to
+// the workgroup's LDS copy; SOLO (one pass per workgroup): every pass writes its own partial P.
+// DMA duties with a next pass in the workgroup (NEXT): three units (NMT = 3: D, M0, M1): Z_0 -> conv3 unit 2 into M1 (always), Z_1 -> the
+// next pass's conv3 unit 0 into D, Z_2 -> its unit 0 into M0 (its X_0 then asks for unit 1 -> M1); two units (NMT = 2: D, M0): Z_0 -> the
+// next pass's unit 1 into M1, Z_1 -> its conv3 unit 0 into D (its X_0 asks for unit 0 -> M0 and waits for it).
+template <int KIN, int MOUT, int NF, int MODE, int PASS, bool SOLO, int Z>
+__device__ __forceinline__ void co_Z(const NetArgs& a, const H3Ctx& hc, const CoCtx& c, const float* epl, float* pl,
+                                     f32x4 (&acc2)[(RingC<KIN, MOUT, NF, MODE>::NRB)][2], f32x4 (&acc3)[(RingC<KIN, MOUT, NF, MODE>::NMT)][2], h8 (&bh)[2],
+                                     h8 (&bl)[2], const int (&q)[2], const bool (&qok)[2], int lane, int kq,
+                                     f32x4 (&keep)[(RingC<KIN, MOUT, NF, MODE>::NMT)][2]) {
   using G = RingC<KIN, MOUT, NF, MODE>;
-  constexpr int NFH = G::NFH, M3 = MOUT, MODE7 = MODE & 7;
-  constexpr bool LAST = PASS == 1;
-  // DMA duties (see the header): Z_0 -> conv3 unit 2 into M1; Z_1 -> next pass's conv3 unit 0 into D; Z_2 -> next pass's unit 0 into M0
-  if constexpr (Z == 0) stage4<G::UNITP, 70>(G::out_unit(c.img, PASS, 2), c.m1, c.w4, c.voff);
-  if constexpr (Z == 1 && !LAST) stage4<G::UNITP, 71>(G::out_unit(c.img, PASS + 1, 0), c.d, c.w4, c.voff);
-  if constexpr (Z == 2 && !LAST) stage4<G::UNITP, 72>(G::main_unit(c.img, PASS + 1, 0, 0), c.m0, c.w4, c.voff);
+  constexpr int NFH = G::NFH, NMT = G::NMT, M3 = MOUT, MODE7 = G::MODE7;
+  constexpr bool NEXT = !SOLO && PASS == 0;            // another pass follows in this workgroup
+  constexpr bool LAST = !SOLO && PASS == 1;            // ... this is the second: it completes pass 0's sums
+  if constexpr (NMT == 3) {
+    if constexpr (Z == 0) stage4<G::UNITP, 70>(G::out_unit(c.img, PASS, 2), c.m1, c.w4, c.voff);
+    if constexpr (Z == 1 && NEXT) stage4<G::UNITP, 71>(G::out_unit(c.img, PASS + 1, 0), c.d, c.w4, c.voff);
+    if constexpr (Z == 2 && NEXT) stage4<G::UNITP, 72>(G::main_unit(c.img, PASS + 1, 0, 0), c.m0, c.w4, c.voff);
+  } else {
+    if constexpr (Z == 0 && NEXT) stage4<G::UNITP, 75>(G::main_unit(c.img, PASS + 1, 0, 1), c.m1, c.w4, c.voff);
+    if constexpr (Z == 1 && NEXT) stage4<G::UNITP, 76>(G::out_unit(c.img, PASS + 1, 0), c.d, c.w4, c.voff);
+  }
   const float4* slot = Z == 0 ? c.d : Z == 1 ? c.m0 : c.m1;
   const h8* buf = reinterpret_cast<const h8*>(slot) + lane;
   const float* pb = epl + NF * 32;
 #pragma unroll
   for (int tp = 0; tp < NFH; ++tp) {
     const int t = Z * NFH + tp;
-    const int fo = t / 3, ml = t % 3;
+    const int fo = t / NMT, ml = t % NMT;
     if (ml == 0) {
+      unsigned mask = 0, bits = 0;
+      if (G::BWD) mask = hc.mkl[((size_t)(threadIdx.x >> 6) * NF + PASS * NFH + fo) * 64 + lane];        // mask1: the ReLU after conv1
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) h3s_act<MODE7, false>(acc2[2 * fo][hf], acc2[2 * fo + 1][hf], a.sc2, 0u, bh[hf], bl[hf]);
+      for (int hf = 0; hf < 2; ++hf) bits |= h3s_act<MODE7, false>(acc2[2 * fo][hf], acc2[2 * fo + 1][hf], a.sc2, mask >> (8 * hf), bh[hf], bl[hf]) << (8 * hf);
+      if (G::SAVE && hc.wok) a.mask2[(hc.wblk * NF + PASS * NFH + fo) * 64 + lane] = (unsigned short)bits;
     }
     if (fo == 0) {
 #pragma unroll
@@ -163,58 +196,73 @@ __device__ __forceinline__ void co_Z(const NetArgs& a, const CoCtx& c, const flo
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = ml * 16 + 4 * kq + r;
-          if constexpr (!LAST) { keep[ml][hf][r] = fmaf(acc3[ml][hf][r], a.sc3, pb[m]); continue; }
-          const float val = acc3[ml][hf][r] * a.sc3 + keep[ml][hf][r];
+          const float part = G::BWD ? acc3[ml][hf][r] * (a.sc3 * hc.ub[hf]) : PASS == 0 ? fmaf(acc3[ml][hf][r], a.sc3, pb[m]) : acc3[ml][hf][r] * a.sc3;
+          if constexpr (NEXT) { keep[ml][hf][r] = part; continue; }
+          const float val = LAST ? part + keep[ml][hf][r] : part;
           if constexpr (G::FUSE) {
             if (m < M3) pl[m * CO_PSTR + (int)(threadIdx.x >> 6) * 32 + 16 * hf + (lane & 15)] = val;
 #ifdef GLOWK_EXP_COCHECK
             keep[ml][hf][r] = val;      // (diagnostic build: the kernel re-reads what it wrote)
 #endif
           } else {
-            if (m < M3 && qok[hf]) a.P[(size_t)m * a.Q + q[hf]] = val;
+            float* Pp = a.P + (SOLO ? (size_t)PASS * a.pstride : (size_t)0);
+            if (m < M3 && qok[hf]) Pp[(size_t)m * a.Q + q[hf]] = val;
           }
         }
     }
   }
-  // next op: Z_1 reads conv3 unit 1 (issued by Yb_{NF-1}; younger: this op's unit), Z_2 reads conv3 unit 2 (issued by Z_0; younger: Z_1's unit,
-  // if any), X_0 of the next pass reads conv1 operands that landed long ago -- barrier only
-  if constexpr (Z == 0) co_end<G::PPW>();
-  else if constexpr (Z == 1) co_end<(LAST ? 0 : G::PPW)>();
-  else co_bar();
+  // next op and what it reads: Z_1 <- conv3 unit 1 (issued by Yb_{NF-1}); Z_2 <- conv3 unit 2 (issued by Z_0); X_0 of the next pass <- conv1
+  // operands that landed long ago.  A saving launch's mask stores ride in between: it waits for everything (three short ops per pass).
+  constexpr bool ISSUED = NMT == 3 ? (Z == 0 || NEXT) : (Z <= 1 && NEXT);     // this op issued a unit
+  if constexpr (Z + 1 < NMT) {
+    if constexpr (G::SAVE) co_end<0>();
+    else co_end<(ISSUED ? G::PPW : 0)>();
+  } else co_bar();
 }
 
-template <int KIN, int MOUT, int NF, int MODE, int PASS>
+template <int KIN, int MOUT, int NF, int MODE, int PASS, bool SOLO>
 __device__ __forceinline__ void co_pass(const NetArgs& a, const H3Ctx& hc, const CoCtx& c, const float* epl, float* pl,
                                         const h8 (&xh)[(RingC<KIN, MOUT, NF, MODE>::KS)][2], const h8 (&xl)[(RingC<KIN, MOUT, NF, MODE>::KS)][2],
-                                        const int (&q)[2], const bool (&qok)[2], int lane, int kq, f32x4 (&keep)[3][2]) {
+                                        const int (&q)[2], const bool (&qok)[2], int lane, int kq, f32x4 (&keep)[(RingC<KIN, MOUT, NF, MODE>::NMT)][2]) {
   using G = RingC<KIN, MOUT, NF, MODE>;
   using S = typename G::S;
-  constexpr int NRB = G::NRB, NFH = G::NFH, MODE7 = MODE & 7;
+  constexpr int NRB = G::NRB, NFH = G::NFH, MODE7 = G::MODE7;
   constexpr int f2base = PASS * NFH * 32;
+  constexpr bool SECOND = !SOLO && PASS == 1;          // units 0 / 1 were not loaded by the prologue
   f32x4 acc2[NRB][2];
 #pragma unroll
   for (int ob = 0; ob < NRB; ++ob)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float b = epl[f2base + ob * 16 + 4 * kq + r];   // conv2 bias (scaled)
+      const float b = G::BWD ? 0.0f : epl[f2base + ob * 16 + 4 * kq + r];   // conv2 bias (scaled)
       acc2[ob][0][r] = b;
       acc2[ob][1][r] = b;
     }
+  const bool st = G::SAVE && PASS == 0 && hc.wok;      // this wave stores a ReLU mask from every X of this pass (h3s_X)
   h8 bh[2], bl[2];
 #pragma nounroll
   for (int i0 = 0; i0 < NF; i0 += 2) {
-    // ---- hidden block i0 (conv1 operands in K0)
+    // ---- hidden block i0 (conv1 operands in K0).  Its second unit (-> M1): the prologue's in a first pass' block 0; with two conv3 units
+    //      a second pass' block 0 finds unit 1 requested by Z_0 and asks for unit 0 (-> M0) itself
+    if (i0 > 0 || (SECOND && G::NMT == 3)) {
 #ifdef GLOWK_EXP_COHALFDMA
-    if (PASS > 0 || i0 > 0) stage4<G::UNITP / 2, 73>(G::main_unit(c.img, PASS, i0, 1), c.m1, c.w4, c.voff);
+      stage4<G::UNITP / 2, 73>(G::main_unit(c.img, PASS, i0, 1), c.m1, c.w4, c.voff);
 #else
-    if (PASS > 0 || i0 > 0) stage4<G::UNITP, 73>(G::main_unit(c.img, PASS, i0, 1), c.m1, c.w4, c.voff);     // (pass 0, block 0: the prologue's)
+      stage4<G::UNITP, 73>(G::main_unit(c.img, PASS, i0, 1), c.m1, c.w4, c.voff);
 #endif
+    }
+    if constexpr (SECOND && G::NMT == 2) {
+      if (i0 == 0) stage4<G::UNITP, 77>(G::main_unit(c.img, PASS, 0, 0), c.m0, c.w4, c.voff);
+    }
     h3s_X<KIN, MOUT, NF, MODE7, 2, 0, PASS>(a, hc, i0, xh, xl, lane, bh, bl);
+    if (SECOND && G::NMT == 2 && i0 == 0) co_end<0>();            // (the unit this very op asked for)
+    else {
 #ifdef GLOWK_EXP_COHALFDMA
-    co_end<G::PPW / 2>();
+      co_end_st<G::PPW / 2>(st);
 #else
-    co_end<G::PPW>();                                   // unit 2 i0 (M0) landed; this op's unit may still be in flight
+      co_end_st<G::PPW>(st);                          // unit 2 i0 (M0) landed; this op's unit (and mask store) may still be in flight
 #endif
+    }
     co_Y<NFH, MODE7, 0, 1, S::K1P>(c.m0, bh, bl, acc2, lane, hc.k1img + (size_t)((i0 + 2) % NF) * S::K14, hc.k1s0, c.w4, c.voff);
     co_end<G::K1PW>();                                  // unit 2 i0 + 1 (M1) landed
     co_Y<NFH, MODE7, 1, 2, S::K1P>(c.m1, bh, bl, acc2, lane, G::main_unit(c.img, PASS, i0 + 1, 0), c.m0, c.w4, c.voff);
@@ -227,9 +275,9 @@ __device__ __forceinline__ void co_pass(const NetArgs& a, const H3Ctx& hc, const
 #endif
     h3s_X<KIN, MOUT, NF, MODE7, 2, 1, PASS>(a, hc, i0 + 1, xh, xl, lane, bh, bl);
 #ifdef GLOWK_EXP_COHALFDMA
-    co_end<G::PPW / 2>();
+    co_end_st<G::PPW / 2>(st);
 #else
-    co_end<G::PPW>();
+    co_end_st<G::PPW>(st);
 #endif
     co_Y<NFH, MODE7, 0, 3, S::K1P>(c.m0, bh, bl, acc2, lane, hc.k1img + (size_t)((i0 + 3) % NF) * S::K14, hc.k1s1, c.w4, c.voff);
     co_end<G::K1PW>();
@@ -238,19 +286,22 @@ __device__ __forceinline__ void co_pass(const NetArgs& a, const H3Ctx& hc, const
                                    c.w4, c.voff);
     co_bar();
   }
-  f32x4 acc3[3][2];
-  co_Z<KIN, MOUT, NF, MODE, PASS, 0>(a, c, epl, pl, acc2, acc3, bh, bl, q, qok, lane, kq, keep);
-  co_Z<KIN, MOUT, NF, MODE, PASS, 1>(a, c, epl, pl, acc2, acc3, bh, bl, q, qok, lane, kq, keep);
-  co_Z<KIN, MOUT, NF, MODE, PASS, 2>(a, c, epl, pl, acc2, acc3, bh, bl, q, qok, lane, kq, keep);
+  f32x4 acc3[G::NMT][2];
+  co_Z<KIN, MOUT, NF, MODE, PASS, SOLO, 0>(a, hc, c, epl, pl, acc2, acc3, bh, bl, q, qok, lane, kq, keep);
+  co_Z<KIN, MOUT, NF, MODE, PASS, SOLO, 1>(a, hc, c, epl, pl, acc2, acc3, bh, bl, q, qok, lane, kq, keep);
+  if constexpr (G::NMT == 3) co_Z<KIN, MOUT, NF, MODE, PASS, SOLO, 2>(a, hc, c, epl, pl, acc2, acc3, bh, bl, q, qok, lane, kq, keep);
 }
 
-template <int KIN, int MOUT, int NF, int MODE>
+template <int KIN, int MOUT, int NF, int MODE, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_net_h3c(NetArgs a) {
   using G = RingC<KIN, MOUT, NF, MODE>;
   using S = typename G::S;
   constexpr int KS = G::KS;
+  constexpr int SGN = G::BWD ? -1 : 1;                 // backward gathers at q - d(tap)
   static_assert(G::FITS, "shape");
+  static_assert(!(G::FUSE && SPLIT), "the fused coupling needs both passes in one workgroup");
 
+  const int tid = threadIdx.x;
   // (aligned 1024: the LDS layout is sorted by alignment first, so the DMA targets take the lowest addresses and the fused form's
   //  copy of P the highest)
   __shared__ __attribute__((aligned(1024))) float4 slotM0[G::UNIT4];
@@ -258,11 +309,17 @@ __global__ __launch_bounds__(256, 2) void k_net_h3c(NetArgs a) {
   __shared__ __attribute__((aligned(1024))) float4 slotD[G::UNIT4];
   __shared__ __attribute__((aligned(1024))) float4 k1slot0[S::K14];
   __shared__ __attribute__((aligned(1024))) float4 k1slot1[S::K14];
-  __shared__ float epl[S::EPN];
-  __shared__ float plds[G::FUSE ? 36 * CO_PSTR : 1];     // fused coupling: the workgroup's per-tap outputs
-  __shared__ float4 vstash[G::FUSE ? CO_PX : 1];         // ... and its pixels' four input channels
-
-  const int tid = threadIdx.x;
+  float* epl = nullptr;                                 // conv2 accumulator init | per-row constants of P (forward modes)
+  if constexpr (!G::BWD) { __shared__ float epl_arr[S::EPN]; epl = epl_arr; }
+  unsigned short* mkl = nullptr;                        // backward: the forward pass's ReLU decisions of the workgroup's four 32-pixel blocks
+  if constexpr (G::BWD) { __shared__ __attribute__((aligned(1024))) unsigned short mkl_arr[G::MASKN]; mkl = mkl_arr; }
+  float* plds = nullptr;                                // fused coupling: the workgroup's per-tap outputs ...
+  float4* vstash = nullptr;                             // ... and its pixels' four input channels
+  if constexpr (G::FUSE) {
+    __shared__ float plds_arr[36 * CO_PSTR];
+    __shared__ float4 vstash_arr[CO_PX];
+    plds = plds_arr; vstash = vstash_arr;
+  }
 #ifdef GLOWK_EXP_COPAD     // (diagnostic build: extra LDS per workgroup -- does a failure follow the LDS footprint / the number of resident workgroups?)
   __shared__ float copad[GLOWK_EXP_COPAD];
   if (a.Q < 0) copad[tid] = 1.0f;
@@ -274,21 +331,26 @@ __global__ __launch_bounds__(256, 2) void k_net_h3c(NetArgs a) {
   const int qbase = ((int)blockIdx.x * 4 + wave) * 32;
   const int q[2] = {qbase + n16, qbase + 16 + n16};
   const bool qok[2] = {q[0] < a.Q, q[1] < a.Q};
+  const int pass0 = SPLIT ? (int)blockIdx.y : 0;       // the (first) pass this workgroup runs
 
-  H3Ctx hc;                    // what h3s_X reads: conv1 operand slots and image
+  H3Ctx hc;                    // what h3s_X reads: conv1 operand slots and image, masks
   hc.sA = hc.sB = hc.sD = nullptr; hc.k1s0 = k1slot0; hc.k1s1 = k1slot1;
-  hc.k1img = a.RSp; hc.img = a.RSp; hc.mkl = nullptr; hc.pl = plds;
-  hc.wblk = (size_t)blockIdx.x * 4 + wave;
+  hc.k1img = a.RSp; hc.img = a.RSp; hc.mkl = mkl; hc.mk2off = 4 * NF * 64; hc.pl = plds;
+  hc.wblk = (size_t)blockIdx.x * 4 + wave;             // this wave's 32-pixel block: the unit of the ReLU-mask arrays
   hc.wok = (long)hc.wblk * 32 < a.Q;
   hc.w4 = wave; hc.voff = (unsigned)lane * 16u; hc.ub[0] = hc.ub[1] = 1.0f;
   CoCtx c;
   c.m0 = slotM0; c.m1 = slotM1; c.d = slotD; c.img = a.RSp; c.w4 = wave; c.voff = (unsigned)lane * 16u;
 
-  stage4<G::UNITP, 60>(G::main_unit(c.img, 0, 0, 0), slotM0, c.w4, c.voff);
-  stage4<G::UNITP, 61>(G::main_unit(c.img, 0, 0, 1), slotM1, c.w4, c.voff);
-  stage4<G::UNITP, 62>(G::out_unit(c.img, 0, 0), slotD, c.w4, c.voff);
+  stage4<G::UNITP, 60>(G::main_unit(c.img, pass0, 0, 0), slotM0, c.w4, c.voff);
+  stage4<G::UNITP, 61>(G::main_unit(c.img, pass0, 0, 1), slotM1, c.w4, c.voff);
+  stage4<G::UNITP, 62>(G::out_unit(c.img, pass0, 0), slotD, c.w4, c.voff);
   stage4<S::K1P, 63>(hc.k1img, k1slot0, c.w4, c.voff);
   stage4<S::K1P, 64>(hc.k1img + S::K14, k1slot1, c.w4, c.voff);
+  if constexpr (G::BWD) {      // [mask1 | mask2][wave][hidden block][lane]: 4 NF 64 entries = NF / 2 pieces each
+    stage4<NF / 2, 65>(reinterpret_cast<const float4*>(a.mask1 + (size_t)blockIdx.x * 4 * NF * 64), reinterpret_cast<float4*>(mkl), c.w4, c.voff);
+    stage4<NF / 2, 66>(reinterpret_cast<const float4*>(a.mask2 + (size_t)blockIdx.x * 4 * NF * 64), reinterpret_cast<float4*>(mkl + 4 * NF * 64), c.w4, c.voff);
+  }
 
   // im2col fragments of this lane's two pixels: k-step s holds k = 32 s + 8 kq + j (natural order), scaled and split
   h8 xh[KS][2], xl[KS][2];
@@ -301,12 +363,33 @@ __global__ __launch_bounds__(256, 2) void k_net_h3c(NetArgs a) {
       const int rem = qq % hw;
       const int i = rem / a.w, j0 = rem % a.w;
       const float* base = a.vin + (long)qq * a.in_stride + a.in_off;
+      if constexpr (G::BWD) {
+        // linear network: the pixel's gradient vector (held by its four lanes kq = 0..3) is normalised by a power of two
+        float v[KS][8];
+        float pm = 0.0f;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        float v[8];
-        gather8<KIN, true, 1>(base, i, j0, a.h, a.w, a.in_stride, qok[hf], 32 * s + 8 * kq, v);
-        xmax = range8(xmax, v);
-        split8(v, xh[s][hf], xl[s][hf]);
+        for (int s = 0; s < KS; ++s) {
+          gather8<KIN, false, SGN>(base, i, j0, a.h, a.w, a.in_stride, qok[hf], 32 * s + 8 * kq, v[s]);
+          pm = range8(pm, v[s]);
+        }
+        pm = nan_max(pm, __shfl_xor(pm, 16, 64));
+        pm = nan_max(pm, __shfl_xor(pm, 32, 64));
+        xmax = nan_max(xmax, pm);
+        const float fac = pixel_norm(pm, a.bnorm, hc.ub[hf]);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[s][j] *= fac;
+          split8(v[s], xh[s][hf], xl[s][hf]);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          float v[8];
+          gather8<KIN, true, SGN>(base, i, j0, a.h, a.w, a.in_stride, qok[hf], 32 * s + 8 * kq, v);
+          xmax = range8(xmax, v);
+          split8(v, xh[s][hf], xl[s][hf]);
+        }
       }
     }
   }
@@ -316,8 +399,10 @@ __global__ __launch_bounds__(256, 2) void k_net_h3c(NetArgs a) {
       vstash[tid] = qv < a.Q ? *reinterpret_cast<const float4*>(a.vin + (size_t)qv * 4) : float4{0.f, 0.f, 0.f, 0.f};
     }
   }
-  for (int i = tid; i < S::EPN; i += 256) epl[i] = a.eph[i];
-  if (!(xmax <= a.xlim) && a.flag) *a.flag = 1;
+  if constexpr (!G::BWD)
+    for (int i = tid; i < S::EPN; i += 256) epl[i] = a.eph[i];
+  // forward: the static bound; backward (normalised per pixel): only a non-finite gradient can leave the range
+  if ((G::BWD ? !(xmax <= 3.0e38f) : !(xmax <= a.xlim)) && a.flag) *a.flag = 1;
   if (a.xmax_out) range_probe(a.xmax_out, xmax);
 #ifdef GLOWK_EXP_COPAD
   if (a.Q < -1 && a.flag) *a.flag = (int)copad[tid ^ 1];
@@ -325,9 +410,14 @@ __global__ __launch_bounds__(256, 2) void k_net_h3c(NetArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  f32x4 keep[3][2];
-  co_pass<KIN, MOUT, NF, MODE, 0>(a, hc, c, epl, plds, xh, xl, q, qok, lane, kq, keep);
-  co_pass<KIN, MOUT, NF, MODE, 1>(a, hc, c, epl, plds, xh, xl, q, qok, lane, kq, keep);
+  f32x4 keep[G::NMT][2];
+  if constexpr (SPLIT) {
+    if (pass0 == 0) co_pass<KIN, MOUT, NF, MODE, 0, true>(a, hc, c, epl, plds, xh, xl, q, qok, lane, kq, keep);
+    else co_pass<KIN, MOUT, NF, MODE, 1, true>(a, hc, c, epl, plds, xh, xl, q, qok, lane, kq, keep);
+  } else {
+    co_pass<KIN, MOUT, NF, MODE, 0, false>(a, hc, c, epl, plds, xh, xl, q, qok, lane, kq, keep);
+    co_pass<KIN, MOUT, NF, MODE, 1, false>(a, hc, c, epl, plds, xh, xl, q, qok, lane, kq, keep);
+  }
   if constexpr (G::FUSE) {
     __syncthreads();       // every wave's LDS writes of P are complete and visible (lgkmcnt(0) + barrier)
 #ifdef GLOWK_EXP_COCHECK    // (diagnostic build: does the LDS copy of P still hold what this wave wrote?  A mismatch raises the range flag;

@@ -652,6 +652,7 @@ struct H3Ctx {                      // wave-uniform pointers of the kernel (LDS 
   float4 *sA, *sB, *sD, *k1s0, *k1s1;
   const float4 *k1img, *img;
   const unsigned short* mkl;        // backward: LDS copy of the masks, [mask1 | mask2][wave][hidden block][lane] (the global order)
+  int mk2off;                       // ... and where mask2 starts in it, in entries (8 NF 64 for the eight-wave workgroups, 4 NF 64 for k_net_h3c)
   size_t wblk;                      // 32-pixel column block of this wave
   bool wok;                         // it holds at least one pixel
   int w4;
@@ -1166,7 +1167,7 @@ __device__ __forceinline__ void h3s_X(const NetArgs& a, const H3Ctx& c, int fi, 
                                       const h8 (&xl)[(RingS<KIN, MOUT, NF, MODE, NP>::KS)][2], int lane, h8 (&bh)[2], h8 (&bl)[2]) {
   using G = RingS<KIN, MOUT, NF, MODE, NP>;
   unsigned mask = 0;
-  if ((MODE & 7) == NET_BWD) mask = c.mkl[((size_t)(8 + (threadIdx.x >> 6)) * NF + fi) * 64 + lane];   // mask2: the ReLU after conv2
+  if ((MODE & 7) == NET_BWD) mask = c.mkl[c.mk2off + ((size_t)(threadIdx.x >> 6) * NF + fi) * 64 + lane];   // mask2: the ReLU after conv2
   f32x4 h1[2][2];   // [row block][pixel half]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1532,6 +1533,7 @@ __global__ __launch_bounds__(512, 2) void k_net_h3s(NetArgs a) {
   c.k1img = a.RSp;
   c.img = a.RSp;
   c.mkl = mkl;
+  c.mk2off = 8 * NF * 64;
   c.pl = plds;
   c.wblk = (size_t)blockIdx.x * 8 + wave;      // this wave's pixel block (16 PXH pixels): the unit of the ReLU-mask arrays
   c.wok = (long)c.wblk * (16 * G::PXH) < a.Q;

@@ -35,6 +35,7 @@ struct EnvSwitches {
   bool wgrad_128;           // GLOWK_WGRAD_128: 128 x 128 tiles in the exact weight-gradient GEMM
   bool co_off;              // GLOWK_CO_OFF: never the co-resident (two workgroups per CU) form of the forward network
   bool q_off;               // GLOWK_Q_OFF: never the all-conv1-first small-grid form (glowk_q.h)
+  bool co_split_off;        // GLOWK_CO_SPLIT_OFF: never the one-pass-per-workgroup (small-grid) form of k_net_h3c
 };
 const EnvSwitches& env();
 
@@ -100,23 +101,28 @@ int launch_h3s(const NetArgs& a, hipStream_t s, bool dry) {
     // the coupling fused into the kernel (glowk_kernels.h: fused_couple) where the caller asks for it (NetArgs::fuse: plain forward
     // direction, geometry checked by the host), the level has four channels and both passes run in one workgroup: answers 100 =
     // "no P was written, the step's output is in place (but for the rows k_couple_edge finishes)"
-    // the co-resident form (glowk_co.h: four-wave / 128-pixel workgroups, two to a CU) of the plain forward network, fused (101) or
-    // writing P once (1), where the caller allows it (NetArgs::co) and the grid fills the chip with it
+    // the co-resident form (glowk_co.h: four-wave / 128-pixel workgroups, two to a CU), where the caller allows it (NetArgs::co) and it
+    // has an instance: on grids that fill the chip with it both passes in one workgroup -- fused (101: forward modes at the 4-channel
+    // level) or writing P once (1) --, on small grids (2 x Q/128 workgroups fit two to a CU) one pass per workgroup (2 partial P buffers)
     if constexpr (RingC<KIN, MOUT, NF, MODE>::FITS) {
       const int wgc = (a.Q + CO_PX - 1) / CO_PX;
       if (a.co && !env().co_off && wgc >= 4 * cus) {
         if constexpr (RingC<KIN, MOUT, NF, MODE | 16>::FITS) {
           // (the form only pays with TWO workgroups per CU -- 2 x 78.8 KB of LDS, 2 x 4 x 248 VGPRs: ask the runtime once per instance, and
           //  keep the eight-wave kernel where a driver / device leaves room for one)
-          if (a.fuse && co_two_per_cu(k_net_h3c<KIN, MOUT, NF, MODE | 16>)) {
-            if (!dry) { hipLaunchKernelGGL((k_net_h3c<KIN, MOUT, NF, MODE | 16>), dim3(wgc), dim3(256), 0, s, a); note_family(4); note_co(); }
+          if (a.fuse && co_two_per_cu(k_net_h3c<KIN, MOUT, NF, MODE | 16, false>)) {
+            if (!dry) { hipLaunchKernelGGL((k_net_h3c<KIN, MOUT, NF, MODE | 16, false>), dim3(wgc), dim3(256), 0, s, a); note_family(4); note_co(); }
             return 101;
           }
         }
-        if (!a.fuse && co_two_per_cu(k_net_h3c<KIN, MOUT, NF, MODE>)) {
-          if (!dry) { hipLaunchKernelGGL((k_net_h3c<KIN, MOUT, NF, MODE>), dim3(wgc), dim3(256), 0, s, a); note_family(2); note_co(); }
+        if (!a.fuse && co_two_per_cu(k_net_h3c<KIN, MOUT, NF, MODE, false>)) {
+          if (!dry) { hipLaunchKernelGGL((k_net_h3c<KIN, MOUT, NF, MODE, false>), dim3(wgc), dim3(256), 0, s, a); note_family(2); note_co(); }
           return 1;
         }
+      }
+      if (a.co && !env().co_off && !env().co_split_off && split && wgc <= cus && a.max_np >= 2 && co_two_per_cu(k_net_h3c<KIN, MOUT, NF, MODE, true>)) {
+        if (!dry) { hipLaunchKernelGGL((k_net_h3c<KIN, MOUT, NF, MODE, true>), dim3(wgc, 2), dim3(256), 0, s, a); note_family(2); note_co(); }
+        return 2;
       }
     }
     if constexpr ((MODE == NET_FWD || MODE == NET_FWD2 || MODE == NET_FWD_SAVE) && MOUT == 36) {
@@ -211,6 +217,18 @@ inline bool use_half(const NetArgs& a) {
 //  tiles, within +-1 % at 8 ... 128 tiles: no reason to change the rule the fuzz runs validated)
 inline bool big_grid(const NetArgs& a) { return 2 * ((a.Q + 255) / 256) > num_cus() || env().fam16_small; }
 
+// ... or where both launches take the one-pass-per-workgroup co-resident form (k_net_h3c<..., SPLIT>: four-wave workgroups two to a CU
+// instead of one eight-wave pass-workgroup per CU): the same question for the saving and the backward launch of a level, same answer
+template <int CI, int NF>
+inline bool co_split_grad(const NetArgs& a) {
+  if constexpr (RingC<CI, 18 * CI, NF, NET_FWD_SAVE>::FITS && RingC<2 * CI, 9 * CI, NF, NET_BWD>::FITS) {
+    const int wgc = (a.Q + CO_PX - 1) / CO_PX, cus = num_cus();
+    return a.co && !env().co_off && !env().co_split_off && a.fam16 && h3_shape16() && a.max_np >= 2 && 2 * ((a.Q + 255) / 256) <= cus && wgc <= cus &&
+           co_two_per_cu(k_net_h3c<CI, 18 * CI, NF, NET_FWD_SAVE, true>) && co_two_per_cu(k_net_h3c<2 * CI, 9 * CI, NF, NET_BWD, true>);
+  }
+  return false;
+}
+
 template <int CI, int NF>
 constexpr bool fam16_ok() {
   return RingS<CI, 18 * CI, NF, NET_FWD_SAVE, 2>::FITS && (RingS<2 * CI, 9 * CI, NF, NET_BWD, 2>::FITS || RingS<2 * CI, 9 * CI, NF, NET_BWD, 4>::FITS);
@@ -256,7 +274,7 @@ int launch_net_t(const NetArgs& a, int mode, hipStream_t s, bool dry) {
     case 4:
       if (use_half<CI, NF>(a)) np = launch_h3s_half<CI, 18 * CI, NF, NET_FWD_SAVE>(a, s, dry);
       if constexpr (fam16_ok<CI, NF>()) {
-        if (!np && a.fam16 && h3_shape16() && big_grid(a)) np = launch_h3s<CI, 18 * CI, NF, NET_FWD_SAVE>(a, s, dry);
+        if (!np && a.fam16 && h3_shape16() && (big_grid(a) || co_split_grad<CI, NF>(a))) np = launch_h3s<CI, 18 * CI, NF, NET_FWD_SAVE>(a, s, dry);
       }
       if (!np && a.RHp) np = launch_h3<CI, 18 * CI, NF, NET_FWD_SAVE>(a, s, dry);
       if (!np && !dry) hipLaunchKernelGGL((k_net_f32<CI, 18 * CI, NF, NET_FWD_SAVE>), dim3(ntiles), dim3(256), 0, s, a);
@@ -264,7 +282,7 @@ int launch_net_t(const NetArgs& a, int mode, hipStream_t s, bool dry) {
     case 5:
       if (use_half<CI, NF>(a)) np = launch_h3s_half<2 * CI, 9 * CI, NF, NET_BWD>(a, s, dry);
       if constexpr (fam16_ok<CI, NF>()) {
-        if (!np && a.fam16 && h3_shape16() && big_grid(a)) np = launch_h3s<2 * CI, 9 * CI, NF, NET_BWD>(a, s, dry);
+        if (!np && a.fam16 && h3_shape16() && (big_grid(a) || co_split_grad<CI, NF>(a))) np = launch_h3s<2 * CI, 9 * CI, NF, NET_BWD>(a, s, dry);
       }
       if (!np && a.RHp) np = launch_h3<2 * CI, 9 * CI, NF, NET_BWD>(a, s, dry);
       if (!np && !dry) hipLaunchKernelGGL((k_net_f32<2 * CI, 9 * CI, NF, NET_BWD>), dim3(ntiles), dim3(256), 0, s, a);

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void k_net_h3q(NetArgs a) {
 
   H3Ctx c;
   c.sA = slotA; c.sB = slotB; c.sD = slotD; c.k1s0 = k1e0; c.k1s1 = k1e1;
-  c.k1img = a.RSp; c.img = a.RSp; c.mkl = mkl; c.pl = nullptr;
+  c.k1img = a.RSp; c.img = a.RSp; c.mkl = mkl; c.mk2off = 0; c.pl = nullptr;
   c.wblk = (size_t)blockIdx.x * 8 + wave;
   c.wok = (long)c.wblk * 16 < a.Q;
   c.w4 = wave & 3;

@@ -185,6 +185,54 @@ def test_co_resident_form_equals_the_one_workgroup_per_cu_form(name, precision):
     assert eng.range_status() == (False, 0)
 
 
+@pytest.mark.parametrize("name,n,forms", [("64x64_8_wgs_per_tile", 160, "both passes per workgroup"), ("96x64_12_wgs_per_tile", 100, "both passes per workgroup"),
+                                          ("64x64_8_wgs_per_tile", 30, "one pass per workgroup"), ("32x32_two_wgs_per_tile_ragged", 97, "one pass per workgroup"),
+                                          ("64x64_8_wgs_per_tile", 20, "one pass per workgroup")])
+def test_co_resident_gradient_path(name, n, forms):
+    """The gradient path's level-0 launches in the co-resident form (k_net_h3c in NET_FWD_SAVE and NET_BWD mode): on grids that fill the chip
+    both passes in one workgroup (saving pass fused with the coupling), on small grids one pass per workgroup (2 x Q/128 four-wave
+    workgroups, two to a CU) -- against the eight-wave kernels (GLOWK_CO_OFF=1).  The ReLU-mask layout is shared, the arithmetic per
+    accumulator too where both are 16x16x32 kernels: log_prob to rounding, gradients equal but for isolated ReLU flips, and both
+    against the exact-fp32 kernels; bitwise repeatable."""
+    cfg, _ = CO_CASES[name]
+    eng, _ = calibrated_engine(cfg, device=0, init_tiles=32)
+    eng.set_precision(_lib.PREC_F16X3)
+    eng.set_range_policy("error")
+    x = torch.from_numpy(synthetic_mel_tiles(n, cfg, seed=9)).cuda()
+    out = {}
+    try:
+        for co in (False, True):
+            _setenv("GLOWK_CO_OFF", not co)
+            before = eng.kernel_families()
+            lp, dx = eng.log_prob_grad(x)
+            torch.cuda.synchronize()
+            out[co] = (lp.clone(), dx.clone(), {k: v - before[k] for k, v in eng.kernel_families().items()})
+    finally:
+        _setenv("GLOWK_CO_OFF", False)
+    K = cfg.K
+    assert out[False][2]["co_resident"] == 0
+    assert out[True][2]["co_resident"] == 2 * K, (forms, out[True][2])           # level 0: K saving + K backward launches
+    assert out[True][2]["f32"] == 0
+    lp_a, dx_a, _ = out[True]
+    lp_b, dx_b, _ = out[False]
+    assert torch.isfinite(dx_a).all()
+    assert float(((lp_a - lp_b).abs() / lp_b.abs()).max()) < 2e-6
+    d = (dx_a - dx_b).abs() / dx_b.abs().max()
+    assert float(d.max()) < 2e-2 and float((d > 1e-3).float().mean()) < 5e-4, float(d.max())     # (isolated ReLU flips at most)
+    per_tile = (dx_a - dx_b).flatten(1).norm(dim=1) / dx_b.flatten(1).norm(dim=1)
+    assert float(per_tile.median()) < 3e-6, float(per_tile.median())
+    eng.set_precision(_lib.PREC_F32)
+    lp32, g32 = eng.log_prob_grad(x)
+    np.testing.assert_allclose(lp_a.cpu().numpy(), lp32.cpu().numpy(), rtol=2e-6)
+    per_tile = (dx_a - g32).flatten(1).norm(dim=1) / g32.flatten(1).norm(dim=1)
+    assert float(per_tile.median()) < 3e-6
+    eng.set_precision(_lib.PREC_F16X3)
+    for _ in range(20):
+        lp2, dx2 = eng.log_prob_grad(x)
+        assert torch.equal(lp2, lp_a) and torch.equal(dx2, dx_a)                   # repeatable bit for bit
+    assert eng.range_status() == (False, 0)
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("shape", ["64x64_L3", "32x32_L2_notop", "24x24_L2_ragged"])
 def test_one_lane_per_pixel_backward_merge_equals_the_four_lane_form(precision, shape):

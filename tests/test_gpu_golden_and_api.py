@@ -13,6 +13,7 @@ from audiosourcesep_amd.synthetic import synthetic_params, synthetic_mel_tiles
 from oracle import glowref as R
 
 pytestmark = pytest.mark.gpu
+PRIMARY_FAMILIES = ("f32", "h3_32x32x16", "h3s_16x16x32", "h3s_half", "fused")   # (co_resident / small_grid_q count subsets of these)
 FILES = sorted(f for f in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz"))
                if not os.path.basename(f).startswith(("real_", "basis_real_")))   # (those two hold tiles, not oracle vectors)
 
@@ -294,9 +295,9 @@ def test_input_gradient_four_levels_full_width():
             # round 3: EVERY level of the gradient path on the split kernels -- the 32-channel level's saving forward pass and
             # its K = 288 backward network through the half-wave form of the 16x16x32 family (one 16-pixel half per wave: nine
             # k-steps of fragments fit the registers); not one launch of the exact fp32 kernel (4 levels x 2 steps x 2 directions)
-            assert fam["f32"] == 0 and sum(fam.values()) == 4 * 2 * 2 and fam["h3s_half"] >= 4, fam
+            assert fam["f32"] == 0 and sum(fam[k] for k in PRIMARY_FAMILIES) == 4 * 2 * 2 and fam["h3s_half"] >= 4, fam
         else:
-            assert fam["f32"] == 16 and sum(fam.values()) == 16, fam
+            assert fam["f32"] == 16 and sum(fam[k] for k in PRIMARY_FAMILIES) == 16, fam
     # a larger batch: the 32-channel level still has only its half-wave instances (whatever the grid), the others their usual forms
     eng.set_precision(_lib.PREC_F16X3)
     xm = dev(synthetic_mel_tiles(600, cfg, seed=22))
