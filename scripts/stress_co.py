@@ -3,7 +3,8 @@
 first compared with the one-workgroup-per-CU kernel.  A synchronisation hole in the ring protocol shows as tiles that differ from run to
 run (glowk_co.h: the first build had one -- LDS reads still in flight across the barrier that frees their slot).
 
-    python scripts/stress_co.py [passes=300] [tiles=1024] [precision=f16x3]
+    python scripts/stress_co.py [passes=300] [tiles=1024] [precision=f16x3] [grad]      (grad: log_prob_grad -- the saving and backward modes; at
+                                                                                          30 tiles the one-pass-per-workgroup form)
 """
 import os
 import sys
@@ -19,6 +20,7 @@ from audiosourcesep_amd.synthetic import calibrated_engine, synthetic_mel_tiles 
 passes = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 prec = {"f16x3": _lib.PREC_F16X3, "f16x2": _lib.PREC_F16X2}[sys.argv[3] if len(sys.argv) > 3 else "f16x3"]
+grad = len(sys.argv) > 4 and sys.argv[4] == "grad"
 lib = _lib.load()
 eng, _ = calibrated_engine(CONFIG_B, device=0, init_tiles=min(n, 256))
 eng.set_range_policy("error")
@@ -35,19 +37,22 @@ def setenv(name, on):
 
 
 setenv("GLOWK_CO_OFF", True)
-ref_lp, ref_z = eng.log_prob(x, return_latent=True)
+call = (lambda: eng.log_prob_grad(x)) if grad else (lambda: eng.log_prob(x, return_latent=True))
+ref_lp, ref_z = call()
+ref_lp, ref_z = ref_lp.clone(), ref_z.clone()
 setenv("GLOWK_CO_OFF", False)
 before = eng.kernel_families()
-first_lp, first_z = eng.log_prob(x, return_latent=True)
+first_lp, first_z = call()
+first_lp, first_z = first_lp.clone(), first_z.clone()
 fam = {k: v - before[k] for k, v in eng.kernel_families().items()}
-assert fam["co_resident"] == CONFIG_B.K and fam["fused"] == CONFIG_B.K, fam
+assert fam["co_resident"] == (2 if grad else 1) * CONFIG_B.K, fam
 d = float(((first_lp - ref_lp).abs() / ref_lp.abs()).max())
-print("co-resident vs one-per-CU: max rel diff of log_prob %.2e, max |dz| %.2e" % (d, float((first_z - ref_z).abs().max())), flush=True)
+print("co-resident vs one-per-CU: max rel diff of log_prob %.2e, max |d second output| / max %.2e" % (d, float((first_z - ref_z).abs().max() / ref_z.abs().max())), flush=True)
 assert d < (2e-7 if prec == _lib.PREC_F16X3 else 2e-5), d
 bad = 0
 t0 = time.time()
 for i in range(passes):
-    lp, z = eng.log_prob(x, return_latent=True)
+    lp, z = call()
     if not (torch.equal(lp, first_lp) and torch.equal(z, first_z)):
         bad += 1
         off = torch.nonzero(lp != first_lp).flatten().tolist()
