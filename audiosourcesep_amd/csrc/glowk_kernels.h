@@ -100,6 +100,18 @@ __device__ __forceinline__ void st_tile_planar(float* blk_base, unsigned lane_by
   }
 }
 
+// per-pixel affine y = x A + b (the fused ActNorm + 1x1 of a step, or its inverse): the fma chain every kernel that applies it uses, so that
+// they agree bit for bit (light kernels, fused_couple's variant, the training kernels)
+template <int C>
+__device__ __forceinline__ void affine_cc(const float* __restrict__ A, const float* __restrict__ b, const float (&x)[C], float (&y)[C]) {
+#pragma unroll
+  for (int co = 0; co < C; ++co) y[co] = b[co];
+#pragma unroll
+  for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+    for (int co = 0; co < C; ++co) y[co] = fmaf(x[ci], A[ci * C + co], y[co]);
+}
+
 // one 64-lane LDS-DMA piece: LDS destination = wave-uniform base + lane*16, global source per lane
 __device__ __forceinline__ void glds16(const float4* src_lane, float4* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(GLOWK_GPTR(src_lane), GLOWK_LPTR(lds_wave_base), 16, 0, 0);

@@ -31,15 +31,6 @@ __device__ __forceinline__ double block_sum_256(double v, double* red /* [4] in 
 }
 
 // y[co] = b[co] + sum_ci x[ci] * A[ci][co]   (A row-major [C][C]; uniform addresses -> scalar loads)
-template <int C>
-__device__ __forceinline__ void affine_cc(const float* __restrict__ A, const float* __restrict__ b, const float (&x)[C], float (&y)[C]) {
-#pragma unroll
-  for (int co = 0; co < C; ++co) y[co] = b[co];
-#pragma unroll
-  for (int ci = 0; ci < C; ++ci)
-#pragma unroll
-    for (int co = 0; co < C; ++co) y[co] = fmaf(x[ci], A[ci * C + co], y[co]);
-}
 
 struct PreArgs {
   float minval, maxval, alpha;

@@ -57,6 +57,11 @@ inline float f16_to_f32(uint16_t h) {
   return f;
 }
 
+}  // namespace
+
+// (the two types that appear in signatures shared between the engine's translation units have external linkage)
+namespace glowk_pk {
+
 struct StepDev {            // device pointers into the arena
   const float* K1p = nullptr;
   const float* ep = nullptr;
@@ -83,6 +88,12 @@ struct Level {
   std::vector<std::vector<float>> host[GLOWK_NUM_STEP_TENSORS];  // [tensor][step] -> values
   std::vector<StepDev> dev;
 };
+
+}  // namespace glowk_pk
+using glowk_pk::Level;
+using glowk_pk::StepDev;
+
+namespace {
 
 
 size_t step_tensor_size(const glowk_config& cfg, const Level& lv, int id) {

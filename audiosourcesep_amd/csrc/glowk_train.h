@@ -17,7 +17,6 @@
 // A = diag(e^ls) P L U, b = sh W is c x c algebra done by the host in fp64 (glowk.hip).  Optimizer: one elementwise kernel.
 #pragma once
 #include "glowk_kernels.h"
-#include "glowk_light.h"
 
 // ---- im2col in planar form -------------------------------------------------------------------------------------------
 // out[(tap * CH + ch)][q] = in[q + sgn * d(tap)][in_off + ch] inside the image, 0 outside; row 9 * CH (if ones) = 1

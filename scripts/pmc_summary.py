@@ -16,8 +16,8 @@ LEVEL0 = {   # config B, level 0 (32x32x4 tensors, n_filters 512): the kernel ea
     "k_net_f32": "void k_net_f32<2, 36, 16, 0, false>(NetArgs)",
     # round 4: the headline launch is the co-resident form k_net_h3c (MODE | 16 = the coupling fused in); the short names stay -- bench.py
     # reads them -- and take the one-workgroup-per-CU kernel where a trace (GLOWK_CO_OFF=1) holds that one instead
-    "k_net_h3s": ["void k_net_h3c<2, 36, 16, 16>(NetArgs)", "void k_net_h3s<2, 36, 16, 16, 2, false>(NetArgs)"],
-    "k_net_h3s_two_term": ["void k_net_h3c<2, 36, 16, 19>(NetArgs)", "void k_net_h3s<2, 36, 16, 19, 2, false>(NetArgs)"],
+    "k_net_h3s": ["void k_net_h3c<2, 36, 16, 16, false>(NetArgs)", "void k_net_h3s<2, 36, 16, 16, 2, false>(NetArgs)"],
+    "k_net_h3s_two_term": ["void k_net_h3c<2, 36, 16, 19, false>(NetArgs)", "void k_net_h3s<2, 36, 16, 19, 2, false>(NetArgs)"],
     "k_net_h3s_one_per_cu": "void k_net_h3s<2, 36, 16, 16, 2, false>(NetArgs)",
     "k_net_h3s_unfused": "void k_net_h3s<2, 36, 16, 0, 2, false>(NetArgs)",      # (a GLOWK_NO_FUSE=1 pass, when the csv holds one)
     "k_net_h3s_two_term_unfused": "void k_net_h3s<2, 36, 16, 3, 2, false>(NetArgs)",
