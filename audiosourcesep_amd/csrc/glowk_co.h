@@ -254,7 +254,9 @@ __device__ __forceinline__ void co_pass(const NetArgs& a, const H3Ctx& hc, const
     if constexpr (SECOND && G::NMT == 2) {
       if (i0 == 0) stage4<G::UNITP, 77>(G::main_unit(c.img, PASS, 0, 0), c.m0, c.w4, c.voff);
     }
+    if (PASS == 0 && i0 == 2) GLOWK_STAMP(a, 2);
     h3s_X<KIN, MOUT, NF, MODE7, 2, 0, PASS>(a, hc, i0, xh, xl, lane, bh, bl);
+    if (PASS == 0 && i0 == 2) GLOWK_STAMP(a, 3);
     if (SECOND && G::NMT == 2 && i0 == 0) co_end<0>();            // (the unit this very op asked for)
     else {
 #ifdef GLOWK_EXP_COHALFDMA
@@ -263,10 +265,15 @@ __device__ __forceinline__ void co_pass(const NetArgs& a, const H3Ctx& hc, const
       co_end_st<G::PPW>(st);                          // unit 2 i0 (M0) landed; this op's unit (and mask store) may still be in flight
 #endif
     }
+    if (PASS == 0 && i0 == 2) GLOWK_STAMP(a, 4);
     co_Y<NFH, MODE7, 0, 1, S::K1P>(c.m0, bh, bl, acc2, lane, hc.k1img + (size_t)((i0 + 2) % NF) * S::K14, hc.k1s0, c.w4, c.voff);
+    if (PASS == 0 && i0 == 2) GLOWK_STAMP(a, 5);
     co_end<G::K1PW>();                                  // unit 2 i0 + 1 (M1) landed
+    if (PASS == 0 && i0 == 2) GLOWK_STAMP(a, 6);
     co_Y<NFH, MODE7, 1, 2, S::K1P>(c.m1, bh, bl, acc2, lane, G::main_unit(c.img, PASS, i0 + 1, 0), c.m0, c.w4, c.voff);
+    if (PASS == 0 && i0 == 2) GLOWK_STAMP(a, 7);
     co_bar();                                           // (M1 free for the next X's unit)
+    if (PASS == 0 && i0 == 2) GLOWK_STAMP(a, 8);
     // ---- hidden block i0 + 1 (conv1 operands in K1)
 #ifdef GLOWK_EXP_COHALFDMA
     stage4<G::UNITP / 2, 74>(G::main_unit(c.img, PASS, i0 + 1, 1), c.m1, c.w4, c.voff);
@@ -287,6 +294,7 @@ __device__ __forceinline__ void co_pass(const NetArgs& a, const H3Ctx& hc, const
     co_bar();
   }
   f32x4 acc3[G::NMT][2];
+  GLOWK_STAMP(a, 9 + (PASS == 0 ? 0 : 1));                  // (9: pass 0's blocks done, 10: pass 1's)
   co_Z<KIN, MOUT, NF, MODE, PASS, SOLO, 0>(a, hc, c, epl, pl, acc2, acc3, bh, bl, q, qok, lane, kq, keep);
   co_Z<KIN, MOUT, NF, MODE, PASS, SOLO, 1>(a, hc, c, epl, pl, acc2, acc3, bh, bl, q, qok, lane, kq, keep);
   if constexpr (G::NMT == 3) co_Z<KIN, MOUT, NF, MODE, PASS, SOLO, 2>(a, hc, c, epl, pl, acc2, acc3, bh, bl, q, qok, lane, kq, keep);
@@ -302,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void k_net_h3c(NetArgs a) {
   static_assert(!(G::FUSE && SPLIT), "the fused coupling needs both passes in one workgroup");
 
   const int tid = threadIdx.x;
+  GLOWK_STAMP(a, 0);
   // (aligned 1024: the LDS layout is sorted by alignment first, so the DMA targets take the lowest addresses and the fused form's
   //  copy of P the highest)
   __shared__ __attribute__((aligned(1024))) float4 slotM0[G::UNIT4];
@@ -409,6 +418,7 @@ __global__ __launch_bounds__(256, 2) void k_net_h3c(NetArgs a) {
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  GLOWK_STAMP(a, 1);
 
   f32x4 keep[G::NMT][2];
   if constexpr (SPLIT) {
@@ -418,6 +428,7 @@ __global__ __launch_bounds__(256, 2) void k_net_h3c(NetArgs a) {
     co_pass<KIN, MOUT, NF, MODE, 0, false>(a, hc, c, epl, plds, xh, xl, q, qok, lane, kq, keep);
     co_pass<KIN, MOUT, NF, MODE, 1, false>(a, hc, c, epl, plds, xh, xl, q, qok, lane, kq, keep);
   }
+  GLOWK_STAMP(a, 12);
   if constexpr (G::FUSE) {
     __syncthreads();       // every wave's LDS writes of P are complete and visible (lgkmcnt(0) + barrier)
 #ifdef GLOWK_EXP_COCHECK    // (diagnostic build: does the LDS copy of P still hold what this wave wrote?  A mismatch raises the range flag;
@@ -443,4 +454,5 @@ __global__ __launch_bounds__(256, 2) void k_net_h3c(NetArgs a) {
 #endif
     fused_couple<CO_PX, CO_PSTR>(a, plds, vstash, tid);
   }
+  GLOWK_STAMP(a, 13);
 }

@@ -78,8 +78,13 @@ struct NetArgs {
   unsigned long long* dbg;   // diagnostic (glowk_debug_stamps), normally null: in-kernel time stamps of workgroup (0, 0)'s first lane
 };
 
-// time stamp i of the launch (constant 100 MHz counter): only when the host armed the debug buffer
+// time stamp i of the launch (constant 100 MHz counter), in builds with -DGLOWK_STAMPS (python -c "import __graft_entry__ as g;
+// g.build(tag='stamps', extra_flags=['-DGLOWK_STAMPS'])", then GLOWK_LIB=.../libglowk_stamps.so): the product kernels carry none
+#ifdef GLOWK_STAMPS
 #define GLOWK_STAMP(a, i) do { if ((a).dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) (a).dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GLOWK_STAMP(a, i) do { } while (0)
+#endif
 
 // cache modifier of the planar hidden stores: they are streamed (gigabytes per launch, read back by the weight-gradient GEMMs after the
 // level's sweep), so non-temporal -- measured -1.7 % on a 256-tile parameter-gradient sweep against "" on one box, neutral at 32 tiles

@@ -120,7 +120,8 @@ const char* glowk_last_error(void);
  * A/B timing or a form-against-form parity test; none is needed for normal use) are read when the library is loaded, not per
  * launch; a process that changes its environment afterwards calls this to have them read again.  (No reference counterpart.) */
 void glowk_reload_env(void);
-/* Diagnostic: the first call arms in-kernel time stamps (later coupling-network launches of the instrumented kernels leave the
+/* Diagnostic, builds with -DGLOWK_STAMPS only (the product kernels carry no stamps: the buffer then stays zero): the first call arms
+ * in-kernel time stamps (later coupling-network launches of the instrumented kernels leave the
  * constant-rate 100 MHz counter of workgroup (0, 0)'s first lane at their phase boundaries); every call waits for the device and
  * copies the n <= 64 stamp words of the LAST such launch.  Current device.  (No reference counterpart.) */
 int glowk_debug_stamps(unsigned long long* out, int n);

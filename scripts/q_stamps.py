@@ -1,5 +1,7 @@
 """In-kernel time stamps of one launch of the small-grid form k_net_h3q per level and direction (workgroup (0, 0), first lane; 100 MHz
 counter): prologue / X-all / Y-all / Z, at the reference's 30 tiles.   python scripts/q_stamps.py [tiles=30]"""
+# needs a build with the stamps compiled in:  python -c "import __graft_entry__ as g; g.build(tag='stamps', extra_flags=['-DGLOWK_STAMPS'])"
+#                                            GLOWK_LIB=$PWD/audiosourcesep_amd/libglowk_stamps.so python scripts/...
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
