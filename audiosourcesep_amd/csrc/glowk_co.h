@@ -40,6 +40,8 @@ struct RingC {
   using S = RingS<KIN, MOUT, NF, MODE7, 2>;            // per-wave tiling, weight image, epilogue constants: those of the two-pass form
   static constexpr bool FUSE = (MODE & 16) != 0;
   static constexpr bool SAVE = MODE7 == NET_FWD_SAVE, BWD = MODE7 == NET_BWD;
+  static constexpr bool STORE = (MODE & 8) != 0;       // training: the launch also leaves its hidden tensors planar (NetArgs::st1 / st2)
+  static constexpr int MODEX = MODE & 15;              // what h3s_X sees: the mode and the store bit
   static constexpr int NFH = S::NFH, NRB = S::NRB, NMT = S::NMT, KS = S::KS;
   static constexpr int UNITP = S::MAINP / 2;            // 1-KiB pieces per unit
   static constexpr int UNIT4 = S::MAIN4 / 2;            // float4 per unit
@@ -50,9 +52,15 @@ struct RingC {
   static constexpr int MASKN = BWD ? 2 * 4 * NF * 64 : 0;   // backward: LDS copy of the masks [mask1 | mask2][wave][hidden block][lane], entries
   static constexpr size_t LDS_BYTES = (size_t)3 * UNIT4 * 16 + (size_t)2 * S::K14 * 16 + (size_t)EPN * 4 + (size_t)MASKN * 2 +
                                       (FUSE ? (size_t)36 * CO_PSTR * 4 + CO_PX * 16 : 0);
-  static constexpr bool FITS = (MODE7 == NET_FWD || MODE7 == NET_FWD2 || SAVE || BWD) && !(MODE & (8 | 32)) && S::NGRP == 1 && (NMT == 2 || NMT == 3) &&
+  static constexpr bool FITS = (MODE7 == NET_FWD || MODE7 == NET_FWD2 || SAVE || BWD) && !(MODE & 32) && (!STORE || ((SAVE || BWD) && !FUSE)) && S::NGRP == 1 && (NMT == 2 || NMT == 3) &&
                                (!FUSE || (MOUT == 36 && !BWD)) && KS <= 3 && NF % 4 == 0 && NFH >= 2 && NFH % 2 == 0 && UNITP % 4 == 0 && PPW == NG &&
                                2 * LDS_BYTES <= 160 * 1024 + 1;   // (diagnostic paddings aside)
+  // training: vector-memory stores an op issues per wave (8 pairs of values per activated hidden block from X and from Z; a saving launch adds
+  // the block's ReLU mask).  The host only takes the form where every wave is full (Q % CO_PX == 0), so the counts are static.
+  // (lane n of a wave holds the adjacent pixels 2 n, 2 n + 1 there, and the values leave as 8-byte pairs: full 128-byte lines)
+  static constexpr int XST = STORE ? 8 : 0;
+  static constexpr int z_acts(int z) { int n = 0; for (int t = z * NFH; t < (z + 1) * NFH; ++t) n += (t % NMT == 0) ? 1 : 0; return n; }
+  static constexpr int z_st(int z) { return STORE ? z_acts(z) * (8 + (SAVE ? 1 : 0)) : 0; }
   __device__ static const float4* main_unit(const float4* img, int pass, int i, int half) { return S::main_chunk(img, pass, i) + (size_t)half * UNIT4; }
   __device__ static const float4* out_unit(const float4* img, int pass, int z) { return S::out_chunk(img, pass, 0) + (size_t)z * UNIT4; }
 };
@@ -179,8 +187,14 @@ __device__ __forceinline__ void co_Z(const NetArgs& a, const H3Ctx& hc, const Co
     if (ml == 0) {
       unsigned mask = 0, bits = 0;
       if (G::BWD) mask = hc.mkl[((size_t)(threadIdx.x >> 6) * NF + PASS * NFH + fo) * 64 + lane];        // mask1: the ReLU after conv1
+      if constexpr (G::STORE)
+        bits = h3s_act_pair<MODE7, true>(acc2[2 * fo][0], acc2[2 * fo + 1][0], acc2[2 * fo][1], acc2[2 * fo + 1][1], a.sc2, mask, bh, bl,
+                                         uniform_fptr(a.st2 + (size_t)(PASS * NFH + fo) * 32 * a.Q), ((unsigned)(4 * kq) * (unsigned)a.Q + (unsigned)q[0]) * 4u,
+                                         (unsigned)a.Q * 4u);
+      else {
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) bits |= h3s_act<MODE7, false>(acc2[2 * fo][hf], acc2[2 * fo + 1][hf], a.sc2, mask >> (8 * hf), bh[hf], bl[hf]) << (8 * hf);
+        for (int hf = 0; hf < 2; ++hf) bits |= h3s_act<MODE7, false>(acc2[2 * fo][hf], acc2[2 * fo + 1][hf], a.sc2, mask >> (8 * hf), bh[hf], bl[hf]) << (8 * hf);
+      }
       if (G::SAVE && hc.wok) a.mask2[(hc.wblk * NF + PASS * NFH + fo) * 64 + lane] = (unsigned short)bits;
     }
     if (fo == 0) {
@@ -213,9 +227,14 @@ __device__ __forceinline__ void co_Z(const NetArgs& a, const H3Ctx& hc, const Co
   }
   // next op and what it reads: Z_1 <- conv3 unit 1 (issued by Yb_{NF-1}); Z_2 <- conv3 unit 2 (issued by Z_0); X_0 of the next pass <- conv1
   // operands that landed long ago.  A saving launch's mask stores ride in between: it waits for everything (three short ops per pass).
+  // A training launch's hidden stores stay in flight (vmcnt counts in issue order: what the next op reads is older than the count allowed
+  // to remain -- Z_2's unit was asked for by Z_0, BEFORE Z_0's stores; the counter holds 63).
   constexpr bool ISSUED = NMT == 3 ? (Z == 0 || NEXT) : (Z <= 1 && NEXT);     // this op issued a unit
   if constexpr (Z + 1 < NMT) {
-    if constexpr (G::SAVE) co_end<0>();
+    if constexpr (G::STORE) {
+      constexpr int after = (ISSUED ? G::PPW : 0) + G::z_st(Z) + ((NMT == 3 && Z == 1) ? G::z_st(0) : 0);
+      co_end<(after < 63 ? after : 63)>();
+    } else if constexpr (G::SAVE) co_end<0>();
     else co_end<(ISSUED ? G::PPW : 0)>();
   } else co_bar();
 }
@@ -239,6 +258,7 @@ __device__ __forceinline__ void co_pass(const NetArgs& a, const H3Ctx& hc, const
       acc2[ob][1][r] = b;
     }
   const bool st = G::SAVE && PASS == 0 && hc.wok;      // this wave stores a ReLU mask from every X of this pass (h3s_X)
+  constexpr int XST = PASS == 0 ? G::XST : 0;          // ... and a training launch the block's 16 values per lane
   h8 bh[2], bl[2];
 #pragma nounroll
   for (int i0 = 0; i0 < NF; i0 += 2) {
@@ -255,20 +275,20 @@ __device__ __forceinline__ void co_pass(const NetArgs& a, const H3Ctx& hc, const
       if (i0 == 0) stage4<G::UNITP, 77>(G::main_unit(c.img, PASS, 0, 0), c.m0, c.w4, c.voff);
     }
     if (PASS == 0 && i0 == 2) GLOWK_STAMP(a, 2);
-    h3s_X<KIN, MOUT, NF, MODE7, 2, 0, PASS>(a, hc, i0, xh, xl, lane, bh, bl);
+    h3s_X<KIN, MOUT, NF, G::MODEX, 2, 0, PASS, G::STORE>(a, hc, i0, xh, xl, lane, bh, bl);
     if (PASS == 0 && i0 == 2) GLOWK_STAMP(a, 3);
     if (SECOND && G::NMT == 2 && i0 == 0) co_end<0>();            // (the unit this very op asked for)
     else {
 #ifdef GLOWK_EXP_COHALFDMA
       co_end_st<G::PPW / 2>(st);
 #else
-      co_end_st<G::PPW>(st);                          // unit 2 i0 (M0) landed; this op's unit (and mask store) may still be in flight
+      co_end_st<G::PPW + XST>(st);                    // unit 2 i0 (M0) landed; this op's unit (and its stores) may still be in flight
 #endif
     }
     if (PASS == 0 && i0 == 2) GLOWK_STAMP(a, 4);
     co_Y<NFH, MODE7, 0, 1, S::K1P>(c.m0, bh, bl, acc2, lane, hc.k1img + (size_t)((i0 + 2) % NF) * S::K14, hc.k1s0, c.w4, c.voff);
     if (PASS == 0 && i0 == 2) GLOWK_STAMP(a, 5);
-    co_end<G::K1PW>();                                  // unit 2 i0 + 1 (M1) landed
+    co_end_st<G::K1PW + XST>(st);                       // unit 2 i0 + 1 (M1) landed (asked for before X's stores: they may stay in flight)
     if (PASS == 0 && i0 == 2) GLOWK_STAMP(a, 6);
     co_Y<NFH, MODE7, 1, 2, S::K1P>(c.m1, bh, bl, acc2, lane, G::main_unit(c.img, PASS, i0 + 1, 0), c.m0, c.w4, c.voff);
     if (PASS == 0 && i0 == 2) GLOWK_STAMP(a, 7);
@@ -280,14 +300,14 @@ __device__ __forceinline__ void co_pass(const NetArgs& a, const H3Ctx& hc, const
 #else
     stage4<G::UNITP, 74>(G::main_unit(c.img, PASS, i0 + 1, 1), c.m1, c.w4, c.voff);
 #endif
-    h3s_X<KIN, MOUT, NF, MODE7, 2, 1, PASS>(a, hc, i0 + 1, xh, xl, lane, bh, bl);
+    h3s_X<KIN, MOUT, NF, G::MODEX, 2, 1, PASS, G::STORE>(a, hc, i0 + 1, xh, xl, lane, bh, bl);
 #ifdef GLOWK_EXP_COHALFDMA
     co_end_st<G::PPW / 2>(st);
 #else
-    co_end_st<G::PPW>(st);
+    co_end_st<G::PPW + XST>(st);
 #endif
     co_Y<NFH, MODE7, 0, 3, S::K1P>(c.m0, bh, bl, acc2, lane, hc.k1img + (size_t)((i0 + 3) % NF) * S::K14, hc.k1s1, c.w4, c.voff);
-    co_end<G::K1PW>();
+    co_end_st<G::K1PW + XST>(st);
     // (after the last block: conv3 unit 1 takes the place of "unit 2 NF")
     co_Y<NFH, MODE7, 1, 4, S::K1P>(c.m1, bh, bl, acc2, lane, i0 + 2 < NF ? G::main_unit(c.img, PASS, i0 + 2, 0) : G::out_unit(c.img, PASS, 1), c.m0,
                                    c.w4, c.voff);
@@ -338,7 +358,8 @@ __global__ __launch_bounds__(256, 2) void k_net_h3c(NetArgs a) {
   const int n16 = lane & 15;
   const int kq = lane >> 4;
   const int qbase = ((int)blockIdx.x * 4 + wave) * 32;
-  const int q[2] = {qbase + n16, qbase + 16 + n16};
+  // (training form: adjacent pixels per lane -- its hidden stores are 8-byte pairs; masks and P follow q, so the pair of launches agrees)
+  const int q[2] = {G::STORE ? qbase + 2 * n16 : qbase + n16, G::STORE ? qbase + 2 * n16 + 1 : qbase + 16 + n16};
   const bool qok[2] = {q[0] < a.Q, q[1] < a.Q};
   const int pass0 = SPLIT ? (int)blockIdx.y : 0;       // the (first) pass this workgroup runs
 
@@ -384,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void k_net_h3c(NetArgs a) {
         pm = nan_max(pm, __shfl_xor(pm, 16, 64));
         pm = nan_max(pm, __shfl_xor(pm, 32, 64));
         xmax = nan_max(xmax, pm);
-        const float fac = pixel_norm(pm, a.bnorm, hc.ub[hf]);
+        const float fac = G::STORE ? 1.0f : pixel_norm(pm, a.bnorm, hc.ub[hf]);     // (training: one scale per launch, BwdArgs::go_scale)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
 #pragma unroll
@@ -411,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void k_net_h3c(NetArgs a) {
   if constexpr (!G::BWD)
     for (int i = tid; i < S::EPN; i += 256) epl[i] = a.eph[i];
   // forward: the static bound; backward (normalised per pixel): only a non-finite gradient can leave the range
-  if ((G::BWD ? !(xmax <= 3.0e38f) : !(xmax <= a.xlim)) && a.flag) *a.flag = 1;
+  if (((G::BWD && !G::STORE) ? !(xmax <= 3.0e38f) : !(xmax <= a.xlim)) && a.flag) *a.flag = 1;
   if (a.xmax_out) range_probe(a.xmax_out, xmax);
 #ifdef GLOWK_EXP_COPAD
   if (a.Q < -1 && a.flag) *a.flag = (int)copad[tid ^ 1];

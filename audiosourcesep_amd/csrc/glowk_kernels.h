@@ -704,6 +704,9 @@ __device__ __forceinline__ unsigned h3_act(const f32x16& acc, float sc, unsigned
         }
       }
     }
+#ifdef GLOWK_EXP_NOHST
+    do_st = false;
+#endif
     if ((MODE & 8) && do_st) {
       unsigned off = st_lane + (unsigned)(16 * s) * st_row;      // rows 8 (r >> 2) + (r & 3): registers 8 s .. 8 s + 7 = rows 16 s + {0..3, 8..11}
 #pragma unroll
@@ -1142,10 +1145,9 @@ __device__ __forceinline__ f32x4 mfma3s(const h8& ahi, const h8& alo, const h8& 
 // Forward: ReLU (returns the 8 decisions as bits j = 4 * row block + r); backward: pass where the forward ReLU was open.
 // (ST: training -- the 8 values, in the scaled units they are split in, also go to a planar [F][Q] array: rows 4 kq + r of the two
 //  16-row blocks of the hidden block whose base is st_blk; st_lane = byte offset of (row 4 kq, this lane's pixel), st_row = bytes per row)
-template <int MODE, bool ST = false>
-__device__ __forceinline__ unsigned h3s_act(const f32x4& r0, const f32x4& r1, float sc, unsigned mask8, h8& bh, h8& bl, bool do_st = false,
-                                            float* st_blk = nullptr, unsigned st_lane = 0, unsigned st_row = 0) {
-  float v[8];
+// (the values: v = what the split B fragments are made of; returns the ReLU decisions of a saving launch)
+template <int MODE>
+__device__ __forceinline__ unsigned h3s_act_vals(const f32x4& r0, const f32x4& r1, float sc, unsigned mask8, float (&v)[8]) {
   unsigned bits = 0;
 #pragma unroll
   for (int j = 0; j < 8; j += 2) {
@@ -1161,7 +1163,17 @@ __device__ __forceinline__ unsigned h3s_act(const f32x4& r0, const f32x4& r1, fl
       }
     }
   }
+  return bits;
+}
+template <int MODE, bool ST = false>
+__device__ __forceinline__ unsigned h3s_act(const f32x4& r0, const f32x4& r1, float sc, unsigned mask8, h8& bh, h8& bl, bool do_st = false,
+                                            float* st_blk = nullptr, unsigned st_lane = 0, unsigned st_row = 0) {
+  float v[8];
+  const unsigned bits = h3s_act_vals<MODE>(r0, r1, sc, mask8, v);
   if constexpr (ST) {
+#ifdef GLOWK_EXP_NOHST      // (diagnostic build, wrong weight gradients: the hidden tensors are not stored -- what do the stores cost a training launch?)
+    do_st = false;
+#endif
     if (do_st) {
       const unsigned long long st_base = reinterpret_cast<unsigned long long>(st_blk);
 #pragma unroll
@@ -1177,9 +1189,34 @@ __device__ __forceinline__ unsigned h3s_act(const f32x4& r0, const f32x4& r1, fl
   } else split8(v, bh, bl);
   return bits;
 }
+// ... of BOTH pixel halves of a wave whose lane n holds the ADJACENT pixels 2 n, 2 n + 1 (k_net_h3c's training form): the stored values
+// leave as 8-byte pairs, 16 lanes x 8 B = one full 128-byte line per hidden row and instruction (st_lane: byte offset of (row 4 kq, pixel
+// 2 n)); mask16 / result: bits 8 hf + ..., as the callers of h3s_act assemble them
+template <int MODE, bool ST>
+__device__ __forceinline__ unsigned h3s_act_pair(const f32x4& r00, const f32x4& r10, const f32x4& r01, const f32x4& r11, float sc, unsigned mask16,
+                                                 h8 (&bh)[2], h8 (&bl)[2], float* st_blk, unsigned st_lane, unsigned st_row) {
+  float v0[8], v1[8];
+  unsigned bits = h3s_act_vals<MODE>(r00, r10, sc, mask16, v0);
+  bits |= h3s_act_vals<MODE>(r01, r11, sc, mask16 >> 8, v1) << 8;
+  if constexpr (ST) {
+#ifndef GLOWK_EXP_NOHST
+    const unsigned long long st_base = reinterpret_cast<unsigned long long>(st_blk);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned off = st_lane + (unsigned)((j >> 2) * 16 + (j & 3)) * st_row;
+      const f32x2 pr = {v0[j], v1[j]};
+      asm volatile("global_store_dwordx2 %0, %1, %2" GLOWK_ST_MOD ::"v"(off), "v"(pr), "s"(st_base) : "memory");
+    }
+#endif
+  }
+  split8(v0, bh[0], bl[0]);
+  split8(v1, bh[1], bl[1]);
+  return bits;
+}
 
 // (the ReLU masks of this kernel family: per lane and hidden block 16 bits, bit 8 * pixel half + 4 * row block + r)
-template <int KIN, int MOUT, int NF, int MODE, int NP, int KP, int PASS>
+// (PAIR: lane n of a wave holds the adjacent pixels 2 n, 2 n + 1 instead of n, 16 + n, and a training launch stores pairs)
+template <int KIN, int MOUT, int NF, int MODE, int NP, int KP, int PASS, bool PAIR = false>
 __device__ __forceinline__ void h3s_X(const NetArgs& a, const H3Ctx& c, int fi, const h8 (&xh)[(RingS<KIN, MOUT, NF, MODE, NP>::KS)][2],
                                       const h8 (&xl)[(RingS<KIN, MOUT, NF, MODE, NP>::KS)][2], int lane, h8 (&bh)[2], h8 (&bl)[2]) {
   using G = RingS<KIN, MOUT, NF, MODE, NP>;
@@ -1214,12 +1251,21 @@ __device__ __forceinline__ void h3s_X(const NetArgs& a, const H3Ctx& c, int fi, 
       }
   }
   unsigned bits = 0;
+  if constexpr (PAIR) {      // (every wave full: the host's condition for the form)
+    static_assert(G::PXH == 2, "pairs: two pixel halves per wave");
+    const int stq = (int)c.wblk * 32 + 2 * (lane & 15);
+    if constexpr ((MODE & 8) && PASS == 0)
+      bits = h3s_act_pair<(MODE & 7), true>(h1[0][0], h1[1][0], h1[0][1], h1[1][1], a.sc1, mask, bh, bl, uniform_fptr(a.st1 + (size_t)fi * 32 * a.Q),
+                                            ((unsigned)(4 * (lane >> 4)) * (unsigned)a.Q + (unsigned)stq) * 4u, (unsigned)a.Q * 4u);
+    else bits = h3s_act_pair<(MODE & 7), false>(h1[0][0], h1[1][0], h1[0][1], h1[1][1], a.sc1, mask, bh, bl, nullptr, 0u, 0u);
+  } else {
 #pragma unroll
-  for (int hf = 0; hf < G::PXH; ++hf) {
-    const int stq = (int)c.wblk * (16 * G::PXH) + 16 * hf + (lane & 15);
-    bits |= h3s_act<(MODE & 7), (MODE & 8) != 0>(h1[0][hf], h1[1][hf], a.sc1, mask >> (8 * hf), bh[hf], bl[hf], (MODE & 8) && PASS == 0 && stq < a.Q,
-                                                 (MODE & 8) ? uniform_fptr(a.st1 + (size_t)fi * 32 * a.Q) : nullptr,
-                                                 ((unsigned)(4 * (lane >> 4)) * (unsigned)a.Q + (unsigned)stq) * 4u, (unsigned)a.Q * 4u) << (8 * hf);
+    for (int hf = 0; hf < G::PXH; ++hf) {
+      const int stq = (int)c.wblk * (16 * G::PXH) + 16 * hf + (lane & 15);
+      bits |= h3s_act<(MODE & 7), (MODE & 8) != 0>(h1[0][hf], h1[1][hf], a.sc1, mask >> (8 * hf), bh[hf], bl[hf], (MODE & 8) && PASS == 0 && stq < a.Q,
+                                                   (MODE & 8) ? uniform_fptr(a.st1 + (size_t)fi * 32 * a.Q) : nullptr,
+                                                   ((unsigned)(4 * (lane >> 4)) * (unsigned)a.Q + (unsigned)stq) * 4u, (unsigned)a.Q * 4u) << (8 * hf);
+    }
   }
   if ((MODE & 7) == NET_FWD_SAVE && PASS == 0 && c.wok) a.mask1[(c.wblk * NF + fi) * 64 + lane] = (unsigned short)bits;
 }

@@ -36,6 +36,7 @@ struct EnvSwitches {
   bool co_off;              // GLOWK_CO_OFF: never the co-resident (two workgroups per CU) form of the forward network
   bool q_off;               // GLOWK_Q_OFF: never the all-conv1-first small-grid form (glowk_q.h)
   bool co_split_off;        // GLOWK_CO_SPLIT_OFF: never the one-pass-per-workgroup (small-grid) form of k_net_h3c
+  bool co_train_off;        // GLOWK_CO_TRAIN_OFF: the training sweep stays on the 32x32x16 family (A/B timing)
 };
 const EnvSwitches& env();
 
@@ -229,6 +230,38 @@ inline bool co_split_grad(const NetArgs& a) {
   return false;
 }
 
+// The training sweep of a level in the co-resident form (k_net_h3c<..., MODE | 8>: the launches also store their hidden tensors): where
+// both the saving forward and the backward network have an instance, every workgroup is full (the kernels count their stores: Q % 128
+// == 0) and the grid is one of the two the form is built for -- >= 4 workgroups per CU with both passes in a workgroup, or <= 1 per CU
+// with a workgroup per pass.  Same question, same answer for the two launches of a level (their ReLU-mask layouts must agree).
+template <int CI, int NF>
+inline bool co_train(const NetArgs& a) {
+  if constexpr (RingC<CI, 18 * CI, NF, (NET_FWD_SAVE | 8)>::FITS && RingC<2 * CI, 9 * CI, NF, (NET_BWD | 8)>::FITS) {
+    const int wgc = (a.Q + CO_PX - 1) / CO_PX, cus = num_cus();
+    if (!(a.co && !env().co_off && !env().co_train_off && a.fam16 && h3_shape16() && a.Q % CO_PX == 0 && a.max_np >= 2)) return false;
+    if (wgc >= 4 * cus)
+      return co_two_per_cu(k_net_h3c<CI, 18 * CI, NF, (NET_FWD_SAVE | 8), false>) && co_two_per_cu(k_net_h3c<2 * CI, 9 * CI, NF, (NET_BWD | 8), false>);
+    if (wgc <= cus && !env().co_split_off)
+      return co_two_per_cu(k_net_h3c<CI, 18 * CI, NF, (NET_FWD_SAVE | 8), true>) && co_two_per_cu(k_net_h3c<2 * CI, 9 * CI, NF, (NET_BWD | 8), true>);
+  }
+  return false;
+}
+// (after co_train said yes; returns the number of partial P buffers)
+template <int KIN, int MOUT, int NF, int MODE>
+int launch_co_train(const NetArgs& a, hipStream_t s, bool dry) {
+  if constexpr (RingC<KIN, MOUT, NF, MODE>::FITS) {
+    const int wgc = (a.Q + CO_PX - 1) / CO_PX;
+    const bool split = wgc <= num_cus();
+    if (!dry) {
+      if (split) hipLaunchKernelGGL((k_net_h3c<KIN, MOUT, NF, MODE, true>), dim3(wgc, 2), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((k_net_h3c<KIN, MOUT, NF, MODE, false>), dim3(wgc), dim3(256), 0, s, a);
+      note_family(2); note_co();
+    }
+    return split ? 2 : 1;
+  }
+  return 0;
+}
+
 template <int CI, int NF>
 constexpr bool fam16_ok() {
   return RingS<CI, 18 * CI, NF, NET_FWD_SAVE, 2>::FITS && (RingS<2 * CI, 9 * CI, NF, NET_BWD, 2>::FITS || RingS<2 * CI, 9 * CI, NF, NET_BWD, 4>::FITS);
@@ -249,11 +282,13 @@ int launch_net_t(const NetArgs& a, int mode, hipStream_t s, bool dry) {
     // training in the split arithmetic: the 32x32x16 family's saving forward and backward launches, storing their hiddens (MODE | 8)
     case 10:   // (dry: returns 0 when the shape has no instance -- glowk_param_grad asks before it chooses the arithmetic of the sweep)
       if (use_half_train<CI, NF>(a)) np = launch_h3s_half<CI, 18 * CI, NF, (NET_FWD_SAVE | 8)>(a, s, dry);
+      if (!np && co_train<CI, NF>(a)) np = launch_co_train<CI, 18 * CI, NF, (NET_FWD_SAVE | 8)>(a, s, dry);
       if (!np && a.RHp) np = launch_h3<CI, 18 * CI, NF, (NET_FWD_SAVE | 8)>(a, s, dry);
       if (!np) { if (dry) return 0; launch_fail("no split-arithmetic training instance for this shape"); return -1; }
       break;
     case 11:
       if (use_half_train<CI, NF>(a)) np = launch_h3s_half<2 * CI, 9 * CI, NF, (NET_BWD | 8)>(a, s, dry);
+      if (!np && co_train<CI, NF>(a)) np = launch_co_train<2 * CI, 9 * CI, NF, (NET_BWD | 8)>(a, s, dry);
       if (!np && a.RHp) np = launch_h3<2 * CI, 9 * CI, NF, (NET_BWD | 8)>(a, s, dry);
       if (!np) { if (dry) return 0; launch_fail("no split-arithmetic training instance for this shape"); return -1; }
       break;

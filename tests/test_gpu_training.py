@@ -349,3 +349,40 @@ def test_parameter_gradients_of_the_full_depth_flow():
         assert np.isfinite(flat).all() and eng.range_status() == (False, 0)
         assert np.median(errs) < 3 * np.median(yard) + 1e-6 and np.percentile(errs, 95) < 3 * np.percentile(yard, 95) + 1e-5
         assert vec < 3 * yard_vec + 1e-6 and errs.max() < max(3 * yard.max(), 2e-2)
+
+
+@pytest.mark.parametrize("n", [16, 128])
+def test_training_sweep_in_the_co_resident_form(n, monkeypatch):
+    """Level 0 of the split training sweep runs k_net_h3c<..., MODE | 8> (four-wave workgroups two to a CU, adjacent pixels per lane,
+    hidden tensors stored as 8-byte pairs) where every workgroup is full: one pass per workgroup on small grids (n = 16; below that the half-wave form takes the level), both passes
+    in a workgroup on grids that fill the chip (n = 128).  Against the 32x32x16 family (GLOWK_CO_TRAIN_OFF: same split arithmetic,
+    other summation order) and against itself, bit for bit."""
+    cfg = GlowConfig(H=64, W=64, C=1, L=3, K=2, F=512)
+    eng, params = calibrated_engine(cfg, device=0, init_tiles=8)
+    eng.set_precision(_lib.PREC_F16X3)
+    eng.set_range_policy("error")
+    x = dev(synthetic_mel_tiles(n, cfg, seed=23))
+    lib = _lib.load()
+    try:
+        monkeypatch.setenv("GLOWK_CO_TRAIN_OFF", "1")
+        lib.glowk_reload_env()
+        before = eng.kernel_families()
+        lp0, g0 = eng.param_grad(x, -1.0 / n)
+        mid = eng.kernel_families()
+        assert mid["co_resident"] == before["co_resident"]
+        monkeypatch.delenv("GLOWK_CO_TRAIN_OFF")
+        lib.glowk_reload_env()
+        lp1, g1 = eng.param_grad(x, -1.0 / n)
+        after = eng.kernel_families()
+        assert after["co_resident"] - mid["co_resident"] == 2 * cfg.K        # level 0: K saving forward + K backward launches
+        lp2, g2 = eng.param_grad(x, -1.0 / n)
+    finally:
+        monkeypatch.undo()
+        lib.glowk_reload_env()
+    assert torch.equal(g1, g2) and torch.equal(lp1, lp2)
+    rel = ((g1.double() - g0.double()).norm() / g0.double().norm()).item()
+    print("n = %d: co-resident training sweep vs the 32x32x16 family: relative l2 difference of the gradient vector %.1e" % (n, rel))
+    assert rel < 2e-4
+    np.testing.assert_allclose(lp1.cpu().numpy(), lp0.cpu().numpy(), rtol=2e-6)
+    assert eng.range_status() == (False, 0)
+    eng.close()
