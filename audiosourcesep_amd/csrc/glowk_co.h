@@ -188,9 +188,15 @@ __device__ __forceinline__ void co_Z(const NetArgs& a, const H3Ctx& hc, const Co
       unsigned mask = 0, bits = 0;
       if (G::BWD) mask = hc.mkl[((size_t)(threadIdx.x >> 6) * NF + PASS * NFH + fo) * 64 + lane];        // mask1: the ReLU after conv1
       if constexpr (G::STORE)
+#ifdef GLOWK_EXP_TILEDST
+        bits = h3s_act_pair<MODE7, true>(acc2[2 * fo][0], acc2[2 * fo + 1][0], acc2[2 * fo][1], acc2[2 * fo + 1][1], a.sc2, mask, bh, bl,
+                                         uniform_fptr(a.st2 + ((size_t)blockIdx.x * NF * 32 + (size_t)(PASS * NFH + fo) * 32 * GLOWK_EXP_TILEDST) * 128),
+                                         ((unsigned)(4 * kq) * 128u + (unsigned)(q[0] & 127)) * 4u, 128u * 4u);
+#else
         bits = h3s_act_pair<MODE7, true>(acc2[2 * fo][0], acc2[2 * fo + 1][0], acc2[2 * fo][1], acc2[2 * fo + 1][1], a.sc2, mask, bh, bl,
                                          uniform_fptr(a.st2 + (size_t)(PASS * NFH + fo) * 32 * a.Q), ((unsigned)(4 * kq) * (unsigned)a.Q + (unsigned)q[0]) * 4u,
                                          (unsigned)a.Q * 4u);
+#endif
       else {
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) bits |= h3s_act<MODE7, false>(acc2[2 * fo][hf], acc2[2 * fo + 1][hf], a.sc2, mask >> (8 * hf), bh[hf], bl[hf]) << (8 * hf);

@@ -1198,6 +1198,9 @@ __device__ __forceinline__ unsigned h3s_act_pair(const f32x4& r00, const f32x4& 
   float v0[8], v1[8];
   unsigned bits = h3s_act_vals<MODE>(r00, r10, sc, mask16, v0);
   bits |= h3s_act_vals<MODE>(r01, r11, sc, mask16 >> 8, v1) << 8;
+  // (The CU's vector-store path takes ~24 B/clk into L2 and a single wave ~4.5 B/clk, whatever the width per lane: 21 clk per CU / ~110 clk
+  //  per wave and 8-byte wave store -- scripts/store_rate_probe.hip.  Issuing the stores two at a time between the conversions below
+  //  changed nothing, docs/EXPERIMENTS.md round 4.)
   if constexpr (ST) {
 #ifndef GLOWK_EXP_NOHST
     const unsigned long long st_base = reinterpret_cast<unsigned long long>(st_blk);
@@ -1255,8 +1258,15 @@ __device__ __forceinline__ void h3s_X(const NetArgs& a, const H3Ctx& c, int fi, 
     static_assert(G::PXH == 2, "pairs: two pixel halves per wave");
     const int stq = (int)c.wblk * 32 + 2 * (lane & 15);
     if constexpr ((MODE & 8) && PASS == 0)
+#ifdef GLOWK_EXP_TILEDST   // (diagnostic builds, wrong weight gradients: the stores of a workgroup land in ONE contiguous [F][128] block -- do the 1-MB row
+                           //  strides cost?  GLOWK_EXP_TILEDST = 0: every hidden block of a workgroup lands on the SAME 16 KB -- does the path behind L2?)
+      bits = h3s_act_pair<(MODE & 7), true>(h1[0][0], h1[1][0], h1[0][1], h1[1][1], a.sc1, mask, bh, bl,
+                                            uniform_fptr(a.st1 + ((size_t)blockIdx.x * NF * 32 + (size_t)fi * 32 * GLOWK_EXP_TILEDST) * 128),
+                                            ((unsigned)(4 * (lane >> 4)) * 128u + (unsigned)(stq & 127)) * 4u, 128u * 4u);
+#else
       bits = h3s_act_pair<(MODE & 7), true>(h1[0][0], h1[1][0], h1[0][1], h1[1][1], a.sc1, mask, bh, bl, uniform_fptr(a.st1 + (size_t)fi * 32 * a.Q),
                                             ((unsigned)(4 * (lane >> 4)) * (unsigned)a.Q + (unsigned)stq) * 4u, (unsigned)a.Q * 4u);
+#endif
     else bits = h3s_act_pair<(MODE & 7), false>(h1[0][0], h1[1][0], h1[0][1], h1[1][1], a.sc1, mask, bh, bl, nullptr, 0u, 0u);
   } else {
 #pragma unroll

@@ -37,6 +37,7 @@ struct EnvSwitches {
   bool q_off;               // GLOWK_Q_OFF: never the all-conv1-first small-grid form (glowk_q.h)
   bool co_split_off;        // GLOWK_CO_SPLIT_OFF: never the one-pass-per-workgroup (small-grid) form of k_net_h3c
   bool co_train_off;        // GLOWK_CO_TRAIN_OFF: the training sweep stays on the 32x32x16 family (A/B timing)
+  bool co_mid_off;          // GLOWK_CO_MID_OFF: the co-resident form only on grids of >= 4 workgroups per CU (or <= 1: SPLIT), as first built
 };
 const EnvSwitches& env();
 
@@ -107,7 +108,10 @@ int launch_h3s(const NetArgs& a, hipStream_t s, bool dry) {
     // level) or writing P once (1) --, on small grids (2 x Q/128 workgroups fit two to a CU) one pass per workgroup (2 partial P buffers)
     if constexpr (RingC<KIN, MOUT, NF, MODE>::FITS) {
       const int wgc = (a.Q + CO_PX - 1) / CO_PX;
-      if (a.co && !env().co_off && wgc >= 4 * cus) {
+      // (grids in between -- more 128-pixel workgroups than CUs, fewer than four per CU, e.g. BASIS' 30 mixture tiles at the reference's
+      //  96 x 64: the eight-wave kernel would run one two-pass workgroup on 70 % of the CUs; this form runs its workgroups two to a CU in
+      //  one round up to 2 x CUs, two rounds up to 4 x CUs.  GLOWK_CO_MID_OFF: the round-4 rule "four per CU or none", for A/B timing)
+      if (a.co && !env().co_off && (wgc >= 4 * cus || (wgc > cus && !env().co_mid_off))) {
         if constexpr (RingC<KIN, MOUT, NF, MODE | 16>::FITS) {
           // (the form only pays with TWO workgroups per CU -- 2 x 78.8 KB of LDS, 2 x 4 x 248 VGPRs: ask the runtime once per instance, and
           //  keep the eight-wave kernel where a driver / device leaves room for one)
@@ -239,7 +243,7 @@ inline bool co_train(const NetArgs& a) {
   if constexpr (RingC<CI, 18 * CI, NF, (NET_FWD_SAVE | 8)>::FITS && RingC<2 * CI, 9 * CI, NF, (NET_BWD | 8)>::FITS) {
     const int wgc = (a.Q + CO_PX - 1) / CO_PX, cus = num_cus();
     if (!(a.co && !env().co_off && !env().co_train_off && a.fam16 && h3_shape16() && a.Q % CO_PX == 0 && a.max_np >= 2)) return false;
-    if (wgc >= 4 * cus)
+    if (wgc >= 4 * cus || (wgc > cus && !env().co_mid_off))
       return co_two_per_cu(k_net_h3c<CI, 18 * CI, NF, (NET_FWD_SAVE | 8), false>) && co_two_per_cu(k_net_h3c<2 * CI, 9 * CI, NF, (NET_BWD | 8), false>);
     if (wgc <= cus && !env().co_split_off)
       return co_two_per_cu(k_net_h3c<CI, 18 * CI, NF, (NET_FWD_SAVE | 8), true>) && co_two_per_cu(k_net_h3c<2 * CI, 9 * CI, NF, (NET_BWD | 8), true>);

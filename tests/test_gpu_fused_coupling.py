@@ -124,13 +124,16 @@ def test_fused_saving_pass_feeds_the_backward_sweep(name):
 
 
 CO_CASES = {
-    # name: (cfg, tiles) -- grids of >= 4 x CUs 128-pixel workgroups at the 4-channel level, geometries with and without edge rows
+    # name: (cfg, tiles) -- grids of >= 4 x CUs 128-pixel workgroups at the 4-channel level, geometries with and without edge rows;
+    # and mid-size grids (more workgroups than CUs, fewer than four per CU: one or two rounds of workgroups two to a CU)
     "64x64_8_wgs_per_tile": (GlowConfig(H=64, W=64, C=1, L=3, K=2, F=512), 160),
     "96x64_12_wgs_per_tile": (GlowConfig(H=96, W=64, C=1, L=3, K=2, F=512), 100),
     "128x128_w64_two_rows_per_wg": (GlowConfig(H=128, W=128, C=1, L=3, K=2, F=512), 40),
     "32x32_two_wgs_per_tile_ragged": (GlowConfig(H=32, W=32, C=1, L=2, K=3, F=512), 555),
     "16x16_two_tiles_per_wg_ragged": (GlowConfig(H=16, W=16, C=1, L=2, K=2, F=256), 2231),
     "64x32_w16_F384": (GlowConfig(H=64, W=32, C=1, L=3, K=2, F=384), 301),
+    "96x64_mid_grid_basis_batch": (GlowConfig(H=96, W=64, C=1, L=3, K=2, F=512), 30),
+    "64x64_mid_grid_two_rounds": (GlowConfig(H=64, W=64, C=1, L=3, K=2, F=512), 77),
 }
 
 
@@ -187,7 +190,9 @@ def test_co_resident_form_equals_the_one_workgroup_per_cu_form(name, precision):
 
 @pytest.mark.parametrize("name,n,forms", [("64x64_8_wgs_per_tile", 160, "both passes per workgroup"), ("96x64_12_wgs_per_tile", 100, "both passes per workgroup"),
                                           ("64x64_8_wgs_per_tile", 30, "one pass per workgroup"), ("32x32_two_wgs_per_tile_ragged", 97, "one pass per workgroup"),
-                                          ("64x64_8_wgs_per_tile", 20, "one pass per workgroup")])
+                                          ("64x64_8_wgs_per_tile", 20, "one pass per workgroup"),
+                                          ("96x64_mid_grid_basis_batch", 30, "both passes per workgroup, mid-size grid"),
+                                          ("64x64_mid_grid_two_rounds", 77, "both passes per workgroup, mid-size grid")])
 def test_co_resident_gradient_path(name, n, forms):
     """The gradient path's level-0 launches in the co-resident form (k_net_h3c in NET_FWD_SAVE and NET_BWD mode): on grids that fill the chip
     both passes in one workgroup (saving pass fused with the coupling), on small grids one pass per workgroup (2 x Q/128 four-wave
