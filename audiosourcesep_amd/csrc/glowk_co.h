@@ -27,7 +27,10 @@
 // of the workgroup's four 32-pixel blocks in LDS; every pixel's gradient normalised by a power of two) -- the mask layout is that of the
 // eight-wave 16x16x32 kernels (one entry per 32-pixel block of a wave), so either form can follow the other.  MODE | 16: the coupling
 // fused in (forward modes).  SPLIT: grid.y = 2 and every workgroup runs ONE pass (small grids: 2 x Q/128 workgroups of four waves,
-// two to a CU; each pass leaves its own partial P).
+// two to a CU; each pass leaves its own partial P).  MODE | 8 (NET_FWD_SAVE, NET_BWD): the training sweep's launches, which also store
+// their hidden tensors planar (NetArgs::st1 / st2) -- lane n of a wave then holds the ADJACENT pixels 2 n, 2 n + 1 (not n, 16 + n), so
+// that the values leave as 8-byte pairs, one full 128-byte line per hidden row and instruction; the stores are counted into the op-end
+// waits (they stay in flight across a barrier), which is why the host takes the form only where every wave is full (Q % 128 == 0).
 #pragma once
 #include "glowk_kernels.h"
 
