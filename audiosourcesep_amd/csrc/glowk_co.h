@@ -43,6 +43,9 @@ struct RingC {
   using S = RingS<KIN, MOUT, NF, MODE7, 2>;            // per-wave tiling, weight image, epilogue constants: those of the two-pass form
   static constexpr bool FUSE = (MODE & 16) != 0;
   static constexpr bool SAVE = MODE7 == NET_FWD_SAVE, BWD = MODE7 == NET_BWD;
+  static constexpr bool MERGE = S::NMT <= 3;           // two passes in one workgroup: pass 0's sums of P stay in registers, P is written once
+                                                       // (five row blocks, the 8-channel level: 40 registers the kernel does not have -- two partial buffers)
+  static constexpr bool M0LAST = S::NMT % 3 == 2;      // the pass's last conv3 unit sits in M0 (units cycle D, M0, M1): the next pass asks for its unit 0 itself
   static constexpr bool STORE = (MODE & 8) != 0;       // training: the launch also leaves its hidden tensors planar (NetArgs::st1 / st2)
   static constexpr int MODEX = MODE & 15;              // what h3s_X sees: the mode and the store bit
   static constexpr int NFH = S::NFH, NRB = S::NRB, NMT = S::NMT, KS = S::KS;
@@ -55,7 +58,7 @@ struct RingC {
   static constexpr int MASKN = BWD ? 2 * 4 * NF * 64 : 0;   // backward: LDS copy of the masks [mask1 | mask2][wave][hidden block][lane], entries
   static constexpr size_t LDS_BYTES = (size_t)3 * UNIT4 * 16 + (size_t)2 * S::K14 * 16 + (size_t)EPN * 4 + (size_t)MASKN * 2 +
                                       (FUSE ? (size_t)36 * CO_PSTR * 4 + CO_PX * 16 : 0);
-  static constexpr bool FITS = (MODE7 == NET_FWD || MODE7 == NET_FWD2 || SAVE || BWD) && !(MODE & 32) && (!STORE || ((SAVE || BWD) && !FUSE)) && S::NGRP == 1 && (NMT == 2 || NMT == 3) &&
+  static constexpr bool FITS = (MODE7 == NET_FWD || MODE7 == NET_FWD2 || SAVE || BWD) && !(MODE & 32) && (!STORE || ((SAVE || BWD) && !FUSE)) && S::NGRP == 1 && (NMT == 2 || NMT == 3 || (NMT == 5 && !STORE && !BWD)) &&
                                (!FUSE || (MOUT == 36 && !BWD)) && KS <= 3 && NF % 4 == 0 && NFH >= 2 && NFH % 2 == 0 && UNITP % 4 == 0 && PPW == NG &&
                                2 * LDS_BYTES <= 160 * 1024 + 1;   // (diagnostic paddings aside)
   // training: vector-memory stores an op issues per wave (8 pairs of values per activated hidden block from X and from Z; a saving launch adds
@@ -176,11 +179,18 @@ __device__ __forceinline__ void co_Z(const NetArgs& a, const H3Ctx& hc, const Co
     if constexpr (Z == 0) stage4<G::UNITP, 70>(G::out_unit(c.img, PASS, 2), c.m1, c.w4, c.voff);
     if constexpr (Z == 1 && NEXT) stage4<G::UNITP, 71>(G::out_unit(c.img, PASS + 1, 0), c.d, c.w4, c.voff);
     if constexpr (Z == 2 && NEXT) stage4<G::UNITP, 72>(G::main_unit(c.img, PASS + 1, 0, 0), c.m0, c.w4, c.voff);
-  } else {
+  } else if constexpr (NMT == 2) {
     if constexpr (Z == 0 && NEXT) stage4<G::UNITP, 75>(G::main_unit(c.img, PASS + 1, 0, 1), c.m1, c.w4, c.voff);
     if constexpr (Z == 1 && NEXT) stage4<G::UNITP, 76>(G::out_unit(c.img, PASS + 1, 0), c.d, c.w4, c.voff);
+  } else {      // five units (the 8-channel level): Z_z asks for conv3 unit z + 2 into the slot Z_{z-1} read; then the next pass's unit 1 -> M1, conv3 unit 0 -> D
+    static_assert(NMT == 5, "conv3 units");
+    if constexpr (Z == 0) stage4<G::UNITP, 80>(G::out_unit(c.img, PASS, 2), c.m1, c.w4, c.voff);
+    if constexpr (Z == 1) stage4<G::UNITP, 81>(G::out_unit(c.img, PASS, 3), c.d, c.w4, c.voff);
+    if constexpr (Z == 2) stage4<G::UNITP, 82>(G::out_unit(c.img, PASS, 4), c.m0, c.w4, c.voff);
+    if constexpr (Z == 3 && NEXT) stage4<G::UNITP, 83>(G::main_unit(c.img, PASS + 1, 0, 1), c.m1, c.w4, c.voff);
+    if constexpr (Z == 4 && NEXT) stage4<G::UNITP, 84>(G::out_unit(c.img, PASS + 1, 0), c.d, c.w4, c.voff);
   }
-  const float4* slot = Z == 0 ? c.d : Z == 1 ? c.m0 : c.m1;
+  const float4* slot = Z % 3 == 0 ? c.d : Z % 3 == 1 ? c.m0 : c.m1;
   const h8* buf = reinterpret_cast<const h8*>(slot) + lane;
   const float* pb = epl + NF * 32;
 #pragma unroll
@@ -220,15 +230,15 @@ __device__ __forceinline__ void co_Z(const NetArgs& a, const H3Ctx& hc, const Co
         for (int r = 0; r < 4; ++r) {
           const int m = ml * 16 + 4 * kq + r;
           const float part = G::BWD ? acc3[ml][hf][r] * (a.sc3 * hc.ub[hf]) : PASS == 0 ? fmaf(acc3[ml][hf][r], a.sc3, pb[m]) : acc3[ml][hf][r] * a.sc3;
-          if constexpr (NEXT) { keep[ml][hf][r] = part; continue; }
-          const float val = LAST ? part + keep[ml][hf][r] : part;
+          if constexpr (NEXT && G::MERGE) { keep[ml][hf][r] = part; continue; }
+          const float val = (LAST && G::MERGE) ? part + keep[ml][hf][r] : part;
           if constexpr (G::FUSE) {
             if (m < M3) pl[m * CO_PSTR + (int)(threadIdx.x >> 6) * 32 + 16 * hf + (lane & 15)] = val;
 #ifdef GLOWK_EXP_COCHECK
             keep[ml][hf][r] = val;      // (diagnostic build: the kernel re-reads what it wrote)
 #endif
           } else {
-            float* Pp = a.P + (SOLO ? (size_t)PASS * a.pstride : (size_t)0);
+            float* Pp = a.P + ((SOLO || !G::MERGE) ? (size_t)PASS * a.pstride : (size_t)0);
             if (m < M3 && qok[hf]) Pp[(size_t)m * a.Q + q[hf]] = val;
           }
         }
@@ -238,7 +248,7 @@ __device__ __forceinline__ void co_Z(const NetArgs& a, const H3Ctx& hc, const Co
   // operands that landed long ago.  A saving launch's mask stores ride in between: it waits for everything (three short ops per pass).
   // A training launch's hidden stores stay in flight (vmcnt counts in issue order: what the next op reads is older than the count allowed
   // to remain -- Z_2's unit was asked for by Z_0, BEFORE Z_0's stores; the counter holds 63).
-  constexpr bool ISSUED = NMT == 3 ? (Z == 0 || NEXT) : (Z <= 1 && NEXT);     // this op issued a unit
+  constexpr bool ISSUED = NMT == 3 ? (Z == 0 || NEXT) : NMT == 2 ? (Z <= 1 && NEXT) : (Z <= 2 || NEXT);     // this op issued a unit
   if constexpr (Z + 1 < NMT) {
     if constexpr (G::STORE) {
       constexpr int after = (ISSUED ? G::PPW : 0) + G::z_st(Z) + ((NMT == 3 && Z == 1) ? G::z_st(0) : 0);
@@ -273,20 +283,20 @@ __device__ __forceinline__ void co_pass(const NetArgs& a, const H3Ctx& hc, const
   for (int i0 = 0; i0 < NF; i0 += 2) {
     // ---- hidden block i0 (conv1 operands in K0).  Its second unit (-> M1): the prologue's in a first pass' block 0; with two conv3 units
     //      a second pass' block 0 finds unit 1 requested by Z_0 and asks for unit 0 (-> M0) itself
-    if (i0 > 0 || (SECOND && G::NMT == 3)) {
+    if (i0 > 0 || (SECOND && !G::M0LAST)) {
 #ifdef GLOWK_EXP_COHALFDMA
       stage4<G::UNITP / 2, 73>(G::main_unit(c.img, PASS, i0, 1), c.m1, c.w4, c.voff);
 #else
       stage4<G::UNITP, 73>(G::main_unit(c.img, PASS, i0, 1), c.m1, c.w4, c.voff);
 #endif
     }
-    if constexpr (SECOND && G::NMT == 2) {
+    if constexpr (SECOND && G::M0LAST) {
       if (i0 == 0) stage4<G::UNITP, 77>(G::main_unit(c.img, PASS, 0, 0), c.m0, c.w4, c.voff);
     }
     if (PASS == 0 && i0 == 2) GLOWK_STAMP(a, 2);
     h3s_X<KIN, MOUT, NF, G::MODEX, 2, 0, PASS, G::STORE>(a, hc, i0, xh, xl, lane, bh, bl);
     if (PASS == 0 && i0 == 2) GLOWK_STAMP(a, 3);
-    if (SECOND && G::NMT == 2 && i0 == 0) co_end<0>();            // (the unit this very op asked for)
+    if (SECOND && G::M0LAST && i0 == 0) co_end<0>();            // (the unit this very op asked for)
     else {
 #ifdef GLOWK_EXP_COHALFDMA
       co_end_st<G::PPW / 2>(st);
@@ -326,7 +336,9 @@ __device__ __forceinline__ void co_pass(const NetArgs& a, const H3Ctx& hc, const
   GLOWK_STAMP(a, 9 + (PASS == 0 ? 0 : 1));                  // (9: pass 0's blocks done, 10: pass 1's)
   co_Z<KIN, MOUT, NF, MODE, PASS, SOLO, 0>(a, hc, c, epl, pl, acc2, acc3, bh, bl, q, qok, lane, kq, keep);
   co_Z<KIN, MOUT, NF, MODE, PASS, SOLO, 1>(a, hc, c, epl, pl, acc2, acc3, bh, bl, q, qok, lane, kq, keep);
-  if constexpr (G::NMT == 3) co_Z<KIN, MOUT, NF, MODE, PASS, SOLO, 2>(a, hc, c, epl, pl, acc2, acc3, bh, bl, q, qok, lane, kq, keep);
+  if constexpr (G::NMT >= 3) co_Z<KIN, MOUT, NF, MODE, PASS, SOLO, 2>(a, hc, c, epl, pl, acc2, acc3, bh, bl, q, qok, lane, kq, keep);
+  if constexpr (G::NMT >= 4) co_Z<KIN, MOUT, NF, MODE, PASS, SOLO, 3>(a, hc, c, epl, pl, acc2, acc3, bh, bl, q, qok, lane, kq, keep);
+  if constexpr (G::NMT >= 5) co_Z<KIN, MOUT, NF, MODE, PASS, SOLO, 4>(a, hc, c, epl, pl, acc2, acc3, bh, bl, q, qok, lane, kq, keep);
 }
 
 template <int KIN, int MOUT, int NF, int MODE, bool SPLIT>

@@ -37,6 +37,7 @@ struct EnvSwitches {
   bool q_off;               // GLOWK_Q_OFF: never the all-conv1-first small-grid form (glowk_q.h)
   bool co_split_off;        // GLOWK_CO_SPLIT_OFF: never the one-pass-per-workgroup (small-grid) form of k_net_h3c
   bool co_train_off;        // GLOWK_CO_TRAIN_OFF: the training sweep stays on the 32x32x16 family (A/B timing)
+  bool co8_off;             // GLOWK_CO8_OFF: no co-resident form at the 8-channel level (A/B timing)
   bool co_mid_off;          // GLOWK_CO_MID_OFF: the co-resident form only on grids of >= 4 workgroups per CU (or <= 1: SPLIT), as first built
 };
 const EnvSwitches& env();
@@ -108,10 +109,11 @@ int launch_h3s(const NetArgs& a, hipStream_t s, bool dry) {
     // level) or writing P once (1) --, on small grids (2 x Q/128 workgroups fit two to a CU) one pass per workgroup (2 partial P buffers)
     if constexpr (RingC<KIN, MOUT, NF, MODE>::FITS) {
       const int wgc = (a.Q + CO_PX - 1) / CO_PX;
+      const bool co_ok = a.co && !env().co_off && !(RingC<KIN, MOUT, NF, MODE>::NMT == 5 && env().co8_off);
       // (grids in between -- more 128-pixel workgroups than CUs, fewer than four per CU, e.g. BASIS' 30 mixture tiles at the reference's
       //  96 x 64: the eight-wave kernel would run one two-pass workgroup on 70 % of the CUs; this form runs its workgroups two to a CU in
       //  one round up to 2 x CUs, two rounds up to 4 x CUs.  GLOWK_CO_MID_OFF: the round-4 rule "four per CU or none", for A/B timing)
-      if (a.co && !env().co_off && (wgc >= 4 * cus || (wgc > cus && !env().co_mid_off))) {
+      if (co_ok && (wgc >= 4 * cus || (wgc > cus && !env().co_mid_off))) {
         if constexpr (RingC<KIN, MOUT, NF, MODE | 16>::FITS) {
           // (the form only pays with TWO workgroups per CU -- 2 x 78.8 KB of LDS, 2 x 4 x 248 VGPRs: ask the runtime once per instance, and
           //  keep the eight-wave kernel where a driver / device leaves room for one)
@@ -122,10 +124,10 @@ int launch_h3s(const NetArgs& a, hipStream_t s, bool dry) {
         }
         if (!a.fuse && co_two_per_cu(k_net_h3c<KIN, MOUT, NF, MODE, false>)) {
           if (!dry) { hipLaunchKernelGGL((k_net_h3c<KIN, MOUT, NF, MODE, false>), dim3(wgc), dim3(256), 0, s, a); note_family(2); note_co(); }
-          return 1;
+          return RingC<KIN, MOUT, NF, MODE>::MERGE ? 1 : 2;
         }
       }
-      if (a.co && !env().co_off && !env().co_split_off && split && wgc <= cus && a.max_np >= 2 && co_two_per_cu(k_net_h3c<KIN, MOUT, NF, MODE, true>)) {
+      if (co_ok && !env().co_split_off && split && wgc <= cus && a.max_np >= 2 && co_two_per_cu(k_net_h3c<KIN, MOUT, NF, MODE, true>)) {
         if (!dry) { hipLaunchKernelGGL((k_net_h3c<KIN, MOUT, NF, MODE, true>), dim3(wgc, 2), dim3(256), 0, s, a); note_family(2); note_co(); }
         return 2;
       }

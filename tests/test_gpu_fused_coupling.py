@@ -168,7 +168,9 @@ def test_co_resident_form_equals_the_one_workgroup_per_cu_form(name, precision):
     assert out[(False, True)][3]["co_resident"] == 0 and out[(False, False)][3]["co_resident"] == 0
     for fuse in (True, False):
         fam = out[(True, fuse)][3]
-        assert fam["co_resident"] == 2 * K, (fuse, fam)               # every step of the 4-channel level, forward and inverse
+        # every step of the 4-channel level, forward and inverse -- and of the 8-channel level (five conv3 units, two partial P buffers,
+        # never fused) where its grid has more 128-pixel workgroups than CUs
+        assert fam["co_resident"] in (2 * K, 4 * K), (fuse, fam)
         assert (fam["fused"] == 2 * K) == fuse, (fuse, fam)
     # P-to-HBM form: the network kernel alone differs, and its outputs are bit for bit equal
     for i in range(3):
@@ -216,7 +218,9 @@ def test_co_resident_gradient_path(name, n, forms):
         _setenv("GLOWK_CO_OFF", False)
     K = cfg.K
     assert out[False][2]["co_resident"] == 0
-    assert out[True][2]["co_resident"] == 2 * K, (forms, out[True][2])           # level 0: K saving + K backward launches
+    # level 0: K saving + K backward launches; the 8-channel level's saving launches too where its grid is large enough (its backward
+    # network has no co-resident instance at 512 filters: 88 KB of LDS -- the mask layout is shared, the eight-wave kernel follows)
+    assert out[True][2]["co_resident"] in (2 * K, 3 * K), (forms, out[True][2])
     assert out[True][2]["f32"] == 0
     lp_a, dx_a, _ = out[True]
     lp_b, dx_b, _ = out[False]
