@@ -602,20 +602,24 @@ int glowk_apply_gradients(glowk_handle* h, const float* grad_dev, int optimizer,
   LAUNCHCHK("k_optimizer");
   // ---- refresh what the kernels read: conv images (device permutation), BatchNorm/bias block, fused affines, prior.  The levels are
   //      independent and their kernels small and latency-bound (serial fp64 sums in the host packer's order, so that the images stay
-  //      bit for bit the host-packed ones): each level runs on a stream of its own, the host joins them once for the c x c algebra ----
+  //      bit for bit the host-packed ones): each level runs on a stream of its own (the exact-fp32 image permutation, which nothing in
+  //      the chain of the split images needs, on a second one).  The host's share -- the c x c fp64 fold of ActNorm + 1x1 -- needs only
+  //      the updated small tensors: they come down FIRST, so the fold runs while the device refreshes the images; the split kernels'
+  //      scale arguments (host-side step descriptors) come down before the last, longest kernel of the chain ----
+  const int L = cfg.L;
   if (h->tr_streams.empty()) {
-    h->tr_streams.resize(cfg.L); h->tr_events.resize(cfg.L + 1);
-    for (hipStream_t& t : h->tr_streams) HIPCHK(hipStreamCreateWithFlags(&t, hipStreamNonBlocking));
-    for (hipEvent_t& e : h->tr_events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h->tr_streams.resize(2 * L); h->tr_events.resize(1 + 4 * L);     // streams: [lvl] chain, [L + lvl] side; events: [0] fork, [1 + lvl] chain done,
+    for (hipStream_t& t : h->tr_streams) HIPCHK(hipStreamCreateWithFlags(&t, hipStreamNonBlocking));      // [1 + L + lvl] small tensors down,
+    for (hipEvent_t& e : h->tr_events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));        // [1 + 2L + lvl] scales down, [1 + 3L + lvl] side done
     size_t tot = 0;
-    h->tr_pin_off.assign(cfg.L + 1, 0);
-    for (int lvl = 0; lvl < cfg.L; ++lvl) {
+    h->tr_pin_off.assign(L + 1, 0);
+    for (int lvl = 0; lvl < L; ++lvl) {
       const StepLayout SL = step_layout(h->levels[lvl].c, F);
       const TrainOff t = train_off(h->levels[lvl].c, F);
       h->tr_pin_off[lvl] = tot;
       tot += (size_t)cfg.K * (8 + t.K1 + h->levels[lvl].c + (SL.total - SL.Afwd));
     }
-    h->tr_pin_off[cfg.L] = tot;
+    h->tr_pin_off[L] = tot;
     HIPCHK(hipHostMalloc((void**)&h->tr_pinned, tot * 4, hipHostMallocDefault));
   }
   HIPCHK(hipEventRecord(h->tr_events[0], s));
@@ -624,17 +628,25 @@ int glowk_apply_gradients(glowk_handle* h, const float* grad_dev, int optimizer,
   auto pin_sm = [&](int lvl) { return pin_sc(lvl) + (size_t)cfg.K * 8; };
   auto pin_b3 = [&](int lvl) { return pin_sm(lvl) + (size_t)cfg.K * train_off(h->levels[lvl].c, F).K1; };
   auto pin_blk = [&](int lvl) { return pin_b3(lvl) + (size_t)cfg.K * h->levels[lvl].c; };
-  std::vector<char> refresh16(cfg.L, 0);
-  for (int lvl = 0; lvl < cfg.L; ++lvl) {
+  std::vector<char> refresh16(L, 0);
+  for (int lvl = 0; lvl < L; ++lvl) {
     Level& lv = h->levels[lvl];
-    hipStream_t ls = h->tr_streams[lvl];
+    hipStream_t ls = h->tr_streams[lvl], side = h->tr_streams[L + lvl];
     HIPCHK(hipStreamWaitEvent(ls, h->tr_events[0], 0));
+    HIPCHK(hipStreamWaitEvent(side, h->tr_events[0], 0));
     const StepLayout SL = step_layout(lv.c, F);
     const TrainOff t = train_off(lv.c, F);
     const float* p0 = h->tr_params + h->tr_level_off[lvl];
     float* img0 = h->arena + lv.dev[0].arena_off;
-    hipLaunchKernelGGL(k_repack_f32, dim3((unsigned)((h->tr_map_n[lvl] + 255) / 256), cfg.K), dim3(256), 0, ls, (const int*)h->tr_map[lvl], h->tr_map_n[lvl],
+    // small tensors: down to the host (they parameterise the fp64 fold of ActNorm + 1x1), folded there, back up
+    // (pinned buffers: rewritten by the next call only after it has waited for this level's stream, which the uploads below are on)
+    const size_t small = t.K1;
+    HIPCHK(hipMemcpy2DAsync(pin_sm(lvl), small * 4, p0, t.total * 4, small * 4, cfg.K, hipMemcpyDeviceToHost, ls));
+    HIPCHK(hipMemcpy2DAsync(pin_b3(lvl), (size_t)lv.c * 4, p0 + t.b3, t.total * 4, (size_t)lv.c * 4, cfg.K, hipMemcpyDeviceToHost, ls));
+    HIPCHK(hipEventRecord(h->tr_events[1 + L + lvl], ls));
+    hipLaunchKernelGGL(k_repack_f32, dim3((unsigned)((h->tr_map_n[lvl] + 255) / 256), cfg.K), dim3(256), 0, side, (const int*)h->tr_map[lvl], h->tr_map_n[lvl],
                        p0, t.total, img0 + SL.K1p, SL.total);
+    HIPCHK(hipEventRecord(h->tr_events[1 + 3 * L + lvl], side));
     hipLaunchKernelGGL(k_fold_bn, dim3((F + 255) / 256, cfg.K), dim3(256), 0, ls, p0 + t.b1, p0 + t.b2, p0 + t.bn, t.total, F, cfg.bn_eps, img0 + SL.ep, SL.total);
     LAUNCHCHK("k_repack_f32");
     // the fp16-split images, when the handle is in a split arithmetic (otherwise they are re-packed lazily by the host)
@@ -651,22 +663,19 @@ int glowk_apply_gradients(glowk_handle* h, const float* grad_dev, int optimizer,
       hipLaunchKernelGGL(k_f16_absmax, dim3(6, cfg.K), dim3(1024), 0, ls, fp);
       hipLaunchKernelGGL(k_f16_consts, dim3((F + 32 * NMT + 255) / 256, cfg.K), dim3(256), 0, ls, fp, img0 + SL.epH, NMT);
       hipLaunchKernelGGL(k_f16_limits, dim3(2, cfg.K), dim3(512), 0, ls, fp);
+      HIPCHK(hipMemcpyAsync(pin_sc(lvl), fp.scales, (size_t)cfg.K * 8 * 4, hipMemcpyDeviceToHost, ls));
+      HIPCHK(hipEventRecord(h->tr_events[1 + 2 * L + lvl], ls));
       hipLaunchKernelGGL(k_repack_f16, dim3((unsigned)((h->tr_map16_n[lvl] + 1023) / 1024), cfg.K), dim3(256), 0, ls, (const int*)h->tr_map16[lvl],
                          h->tr_map16_n[lvl], fp, reinterpret_cast<unsigned short*>(img0 + SL.RHp), SL.total * 2);
       LAUNCHCHK("k_repack_f16");
-      HIPCHK(hipMemcpyAsync(pin_sc(lvl), fp.scales, (size_t)cfg.K * 8 * 4, hipMemcpyDeviceToHost, ls));
     } else if (h->tr_map16[lvl]) {
       stale16 = true;
     }
-    // small tensors: down to the host (they parameterise the fp64 fold of ActNorm + 1x1), folded, back up
-    const size_t small = t.K1;
-    HIPCHK(hipMemcpy2DAsync(pin_sm(lvl), small * 4, p0, t.total * 4, small * 4, cfg.K, hipMemcpyDeviceToHost, ls));
-    HIPCHK(hipMemcpy2DAsync(pin_b3(lvl), (size_t)lv.c * 4, p0 + t.b3, t.total * 4, (size_t)lv.c * 4, cfg.K, hipMemcpyDeviceToHost, ls));
   }
-  for (int lvl = 0; lvl < cfg.L; ++lvl) {
+  for (int lvl = 0; lvl < L; ++lvl) {
     Level& lv = h->levels[lvl];
     hipStream_t ls = h->tr_streams[lvl];
-    HIPCHK(hipStreamSynchronize(ls));
+    HIPCHK(hipEventSynchronize(h->tr_events[1 + L + lvl]));      // the small tensors are down
     const StepLayout SL = step_layout(lv.c, F);
     const TrainOff t = train_off(lv.c, F);
     float* img0 = h->arena + lv.dev[0].arena_off;
@@ -687,17 +696,23 @@ int glowk_apply_gradients(glowk_handle* h, const float* grad_dev, int optimizer,
       if (!pack_affine(cfg, lv, k, tmp.data(), &ldc, &err)) return fail("level " + std::to_string(lvl) + " step " + std::to_string(k) + ": " + err);
       h->ld_step[(size_t)lvl * cfg.K + k] = ldc;
       std::memcpy(blocks + (size_t)k * tail, tmp.data() + SL.Afwd, tail * 4);
-      if (refresh16[lvl]) {      // the kernels' scale arguments and range-guard limits live in the host-side step descriptors
-        StepDev& d = lv.dev[k];
-        const float* q8 = pin_sc(lvl) + (size_t)k * 8;
-        if (SL.slotH || SL.slotS) { d.sc1 = q8[0]; d.sc2 = q8[1]; d.sc3 = q8[2]; d.xlim_f = q8[6]; }
-        if (SL.slotHB || SL.slotSB) { d.scb1 = q8[3]; d.scb2 = q8[4]; d.scb3 = q8[5]; d.xlim_b = q8[7]; }
-      }
     }
-    // (pinned source, rewritten only by the next call, which first waits for this level's stream above)
     HIPCHK(hipMemcpy2DAsync(img0 + SL.Afwd, SL.total * 4, blocks, tail * 4, tail * 4, cfg.K, hipMemcpyHostToDevice, ls));
     HIPCHK(hipEventRecord(h->tr_events[1 + lvl], ls));
     HIPCHK(hipStreamWaitEvent(s, h->tr_events[1 + lvl], 0));     // whatever the caller's stream runs next sees the refreshed images
+    HIPCHK(hipStreamWaitEvent(s, h->tr_events[1 + 3 * L + lvl], 0));
+  }
+  for (int lvl = 0; lvl < L; ++lvl) {
+    if (!refresh16[lvl]) continue;      // the kernels' scale arguments and range-guard limits live in the host-side step descriptors
+    Level& lv = h->levels[lvl];
+    const StepLayout SL = step_layout(lv.c, F);
+    HIPCHK(hipEventSynchronize(h->tr_events[1 + 2 * L + lvl]));
+    for (int k = 0; k < cfg.K; ++k) {
+      StepDev& d = lv.dev[k];
+      const float* q8 = pin_sc(lvl) + (size_t)k * 8;
+      if (SL.slotH || SL.slotS) { d.sc1 = q8[0]; d.sc2 = q8[1]; d.sc3 = q8[2]; d.xlim_f = q8[6]; }
+      if (SL.slotHB || SL.slotSB) { d.scb1 = q8[3]; d.scb2 = q8[4]; d.scb3 = q8[5]; d.xlim_b = q8[7]; }
+    }
   }
   h->ld_const = 0.0;
   for (double v : h->ld_step) h->ld_const += v;
