@@ -552,8 +552,11 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       const float* v0 = h->saveV + h->offV[(size_t)lvl * K + (K - 1)];
       const float* R10 = h->trKeep + h->trKeepOff[(size_t)lvl * K + (K - 1)] * (size_t)N;
       const ptrdiff_t r_bs = -(ptrdiff_t)(2 * (size_t)cfg.F * Q);
-      if (int rc = train_network_grads(h, tc, lvl, 0, K, v0, v_bs, h->trGo, (ptrdiff_t)go_slot, R10, r_bs, h->trM1, h->trM2, (ptrdiff_t)m_slot, N, s, bfac)) return rc;
+      // (the ActNorm / 1x1 sums first: after the last level's the host has all it needs for its share of the step, which then runs beside
+      //  this level's GEMMs -- glowk_param_grad)
       if (int rc = train_affine_sums(h, lvl, 0, K, v0, v_bs, h->trGv, (ptrdiff_t)go_slot, N, s)) return rc;
+      if (lvl == 0 && tc->sums_ready) { HIPCHK(hipEventRecord(tc->sums_ready, s)); tc->sums_ready = nullptr; }
+      if (int rc = train_network_grads(h, tc, lvl, 0, K, v0, v_bs, h->trGo, (ptrdiff_t)go_slot, R10, r_bs, h->trM1, h->trM2, (ptrdiff_t)m_slot, N, s, bfac)) return rc;
     }
     if (lvl > 0) {
       const Level& pv = h->levels[lvl - 1];
@@ -566,6 +569,7 @@ int run_backward(glowk_handle* h, const float* x, const float* z, int N, float* 
       LAUNCHCHK("k_bwd_in");
     }
   }
+  if (tc && tc->sums_ready) { HIPCHK(hipEventRecord(tc->sums_ready, s)); tc->sums_ready = nullptr; }     // (step-by-step mode: the sums end the sweep)
   return 0;
 }
 
@@ -721,6 +725,11 @@ int glowk_destroy(glowk_handle* h) {
   for (hipEvent_t e : h->tr_events) hipEventDestroy(e);
   if (h->tr_pinned) hipHostFree(h->tr_pinned);
   for (hipStream_t t : h->tr_streams) hipStreamDestroy(t);
+  if (h->tr_ev_sums) hipEventDestroy(h->tr_ev_sums);
+  if (h->tr_ev_up) hipEventDestroy(h->tr_ev_up);
+  if (h->tr_side) hipStreamDestroy(h->tr_side);
+  if (h->h_sums) hipHostFree(h->h_sums);
+  if (h->h_up) hipHostFree(h->h_up);
   delete h;
   return 0;
 }

@@ -117,6 +117,12 @@ struct glowk_handle {
                                  // sweep from the largest |g_o| it saw (dynamic gradient scaling); 1 until the first sweep has run
   unsigned* tr_gmax = nullptr;   // [L][16] device: that maximum (float bits), per level, spread over 16 words
   float* h_gmax = nullptr;       // pinned host copy (read back with the sweep's one synchronisation)
+  // glowk_param_grad: the host's ActNorm / 1x1 chain rule runs BESIDE the last level's weight-gradient GEMMs: a side stream brings the
+  // per-step sums down as soon as the sweep has produced them and takes the results back up
+  hipStream_t tr_side = nullptr;
+  hipEvent_t tr_ev_sums = nullptr, tr_ev_up = nullptr;    // sums complete (main stream) / results uploaded (side stream)
+  double* h_sums = nullptr;      // pinned [L * K][AFF_NOUT_MAX]
+  float* h_up = nullptr;         // pinned: per level K x (the head of a step block: als | ash | L | logS | U)
   int trN = 0;
   float *trR1 = nullptr, *trR2 = nullptr, *trM1 = nullptr, *trM2 = nullptr, *trXcol = nullptr, *trGcol = nullptr, *trCpart = nullptr;
   float *trC1 = nullptr, *trC2 = nullptr, *trC3 = nullptr, *trGv = nullptr, *trGo = nullptr;
@@ -150,6 +156,7 @@ struct TrainCtx {
   float* grad;     // [tr_n] flat gradient vector (device, caller owned)
   float scale;     // every gradient is scale * d sum_n log_prob / d theta
   bool split;      // the sweep runs the fp16-split kernels (k_net_h3, MODE | 8): planar arrays in scaled units (StepGradArgs::scaled)
+  hipEvent_t sums_ready = nullptr;   // recorded on the sweep's stream once every ActNorm / 1x1 sum (and the range flag, the gradient maxima) is final
 };
 
 // ---- defined in glowk.hip

@@ -2,6 +2,7 @@
 // the device-side refresh of the kernel images -- glowk_param_vector_size / glowk_param_offset / glowk_param_grad / glowk_apply_gradients
 // (train_glow.py:29-44, train_utils.py:23-41).  The sweep itself (run_forward / run_backward) lives in glowk.hip.
 #include "glowk_engine.h"
+#include <chrono>
 #include "glowk_train.h"
 
 using namespace glowk_eng;
@@ -521,20 +522,38 @@ static int param_grad_impl(glowk_handle* h, const float* x_dev, int N, float sca
     h->tr_bfac.assign(4, 1.0f);
   }
   HIPCHK(hipMemsetAsync(h->tr_gmax, 0, sizeof(unsigned) * 64, s));
-  TrainCtx tc{grad_dev, scale, split};
+  const size_t steps = (size_t)cfg.L * cfg.K;
+  if (!h->tr_side) {
+    HIPCHK(hipStreamCreateWithFlags(&h->tr_side, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->tr_ev_sums, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->tr_ev_up, hipEventDisableTiming));
+    HIPCHK(hipHostMalloc((void**)&h->h_sums, steps * AFF_NOUT_MAX * 8, hipHostMallocDefault));
+    size_t up = 0;
+    for (int lvl = 0; lvl < cfg.L; ++lvl) up += (size_t)cfg.K * train_off(h->levels[lvl].c, cfg.F).K1;
+    HIPCHK(hipHostMalloc((void**)&h->h_up, up * 4, hipHostMallocDefault));
+  }
+  TrainCtx tc{grad_dev, scale, split, h->tr_ev_sums};
   // (the input gradient falls out of the sweep as well; the trainer has no use for it: it lands in the block-level scratch,
   //  which is free again by the time the last kernel of the sweep writes it)
   if (int rc = run_backward(h, x_dev, z, N, h->bufZ, s, &tc)) return rc;
-  // ActNorm / 1x1: the per-step sums come back once, the c x c chain rule runs on the host in fp64, the results go up in one copy
-  const size_t steps = (size_t)cfg.L * cfg.K;
-  std::vector<double> sums(steps * AFF_NOUT_MAX);
-  HIPCHK(hipMemcpyAsync(sums.data(), h->trAffSum, sums.size() * 8, hipMemcpyDeviceToHost, s));
-  if (split) HIPCHK(hipMemcpyAsync(h->h_flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(h->h_gmax, h->tr_gmax, sizeof(float) * 64, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  // ActNorm / 1x1: the per-step sums come down once -- on a side stream, as soon as the sweep has produced the last of them, while the
+  // main stream still runs the last level's weight-gradient GEMMs --, the c x c chain rule runs on the host in fp64, the results go up
+  // on the side stream (they land in the heads of the step blocks, which no kernel of the sweep writes after the initial memset), and
+  // the caller's stream waits for that upload: no host join of the caller's stream at all
+  hipStream_t side = h->tr_side;
+  const bool host_times = getenv("GLOWK_HOST_TIMES") != nullptr;      // (diagnostic: what does the host's share of a training step take?)
+  if (getenv("GLOWK_PG_JOIN")) HIPCHK(hipStreamSynchronize(s));       // (A/B timing: the host joins the caller's stream first, as it did before the side stream)
+  HIPCHK(hipStreamWaitEvent(side, h->tr_ev_sums, 0));
+  HIPCHK(hipMemcpyAsync(h->h_sums, h->trAffSum, steps * AFF_NOUT_MAX * 8, hipMemcpyDeviceToHost, side));
+  if (split) HIPCHK(hipMemcpyAsync(h->h_flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, side));
+  HIPCHK(hipMemcpyAsync(h->h_gmax, h->tr_gmax, sizeof(float) * 64, hipMemcpyDeviceToHost, side));
+  HIPCHK(hipStreamSynchronize(side));
+  const auto ht0 = std::chrono::steady_clock::now();
   if (split && h->h_flag[0]) {       // the range guard of the split arithmetic fired somewhere in the sweep: its gradients are not usable
     h->h_flag[0] = 0;
-    HIPCHK(hipMemsetAsync(h->d_flag, 0, sizeof(int), s));
+    HIPCHK(hipMemsetAsync(h->d_flag, 0, sizeof(int), side));
+    HIPCHK(hipEventRecord(h->tr_ev_up, side));
+    HIPCHK(hipStreamWaitEvent(s, h->tr_ev_up, 0));      // (the exact sweep that follows on the caller's stream starts after the reset)
     *tripped = true;
     return 0;
   }
@@ -555,16 +574,21 @@ static int param_grad_impl(glowk_handle* h, const float* x_dev, int N, float sca
       h->tr_bfac[lvl] = std::ldexp(1.0f, std::max(-100, std::min(100, e - 1)));
     }
   }
+  float* out = h->h_up;      // (pinned; rewritten by the next call only after it has waited for the side stream, which these uploads are on)
   for (int lvl = 0; lvl < cfg.L; ++lvl) {
     const Level& lv = h->levels[lvl];
     const TrainOff t = train_off(lv.c, cfg.F);
     const size_t small = t.K1;            // [als | ash | L | logS | U] (padded) sit at the head of the step block
-    std::vector<float> out((size_t)cfg.K * small, 0.0f);
+    std::memset(out, 0, (size_t)cfg.K * small * 4);
     for (int k = 0; k < cfg.K; ++k)
-      affine_chain_rule(lv, k, sums.data() + ((size_t)lvl * cfg.K + k) * AFF_NOUT_MAX, N, (double)scale, out.data() + (size_t)k * small, t);
-    HIPCHK(hipMemcpy2DAsync(grad_dev + h->tr_level_off[lvl], t.total * 4, out.data(), small * 4, small * 4, cfg.K, hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));      // (out is a local)
+      affine_chain_rule(lv, k, h->h_sums + ((size_t)lvl * cfg.K + k) * AFF_NOUT_MAX, N, (double)scale, out + (size_t)k * small, t);
+    HIPCHK(hipMemcpy2DAsync(grad_dev + h->tr_level_off[lvl], t.total * 4, out, small * 4, small * 4, cfg.K, hipMemcpyHostToDevice, side));
+    out += (size_t)cfg.K * small;
   }
+  HIPCHK(hipEventRecord(h->tr_ev_up, side));
+  HIPCHK(hipStreamWaitEvent(s, h->tr_ev_up, 0));
+  if (host_times) fprintf(stderr, "glowk_param_grad: host share (chain rule of %zu steps + uploads) %.0f us\n", steps,
+                          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ht0).count());
   return 0;
 }
 
@@ -672,10 +696,13 @@ int glowk_apply_gradients(glowk_handle* h, const float* grad_dev, int optimizer,
       stale16 = true;
     }
   }
+  const bool host_times = getenv("GLOWK_HOST_TIMES") != nullptr;
+  double fold_us = 0.0;
   for (int lvl = 0; lvl < L; ++lvl) {
     Level& lv = h->levels[lvl];
     hipStream_t ls = h->tr_streams[lvl];
     HIPCHK(hipEventSynchronize(h->tr_events[1 + L + lvl]));      // the small tensors are down
+    const auto ht0 = std::chrono::steady_clock::now();
     const StepLayout SL = step_layout(lv.c, F);
     const TrainOff t = train_off(lv.c, F);
     float* img0 = h->arena + lv.dev[0].arena_off;
@@ -697,6 +724,7 @@ int glowk_apply_gradients(glowk_handle* h, const float* grad_dev, int optimizer,
       h->ld_step[(size_t)lvl * cfg.K + k] = ldc;
       std::memcpy(blocks + (size_t)k * tail, tmp.data() + SL.Afwd, tail * 4);
     }
+    fold_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ht0).count();
     HIPCHK(hipMemcpy2DAsync(img0 + SL.Afwd, SL.total * 4, blocks, tail * 4, tail * 4, cfg.K, hipMemcpyHostToDevice, ls));
     HIPCHK(hipEventRecord(h->tr_events[1 + lvl], ls));
     HIPCHK(hipStreamWaitEvent(s, h->tr_events[1 + lvl], 0));     // whatever the caller's stream runs next sees the refreshed images
@@ -714,6 +742,7 @@ int glowk_apply_gradients(glowk_handle* h, const float* grad_dev, int optimizer,
       if (SL.slotHB || SL.slotSB) { d.scb1 = q8[3]; d.scb2 = q8[4]; d.scb3 = q8[5]; d.xlim_b = q8[7]; }
     }
   }
+  if (host_times) fprintf(stderr, "glowk_apply_gradients: host fold of ActNorm + 1x1 (all levels) %.0f us\n", fold_us);
   h->ld_const = 0.0;
   for (double v : h->ld_step) h->ld_const += v;
   if (cfg.learntop) {
