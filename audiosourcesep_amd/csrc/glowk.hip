@@ -33,7 +33,7 @@ unsigned long long* g_dbg_stamps = nullptr;    // glowk_debug_stamps
 static EnvSwitches read_env() {
   auto on = [](const char* n) { return getenv(n) != nullptr; };
   return EnvSwitches{on("GLOWK_HALF_OFF"), on("GLOWK_HALF_FORCE"), on("GLOWK_FAM16_SMALL"), on("GLOWK_BWD_LIGHT_4"), on("GLOWK_COUPLE_PER_SAMPLE"),
-                     on("GLOWK_COUPLE_4"), on("GLOWK_NO_FUSE"), on("GLOWK_WGRAD_PLAIN"), on("GLOWK_WGRAD_128"), on("GLOWK_CO_OFF"), on("GLOWK_Q_OFF"), on("GLOWK_CO_SPLIT_OFF"), on("GLOWK_CO_TRAIN_OFF"), on("GLOWK_CO8_OFF"), on("GLOWK_CO_MID_OFF")};
+                     on("GLOWK_COUPLE_4"), on("GLOWK_NO_FUSE"), on("GLOWK_WGRAD_PLAIN"), on("GLOWK_WGRAD_128"), on("GLOWK_CO_OFF"), on("GLOWK_Q_OFF"), on("GLOWK_CO_SPLIT_OFF"), on("GLOWK_CO_TRAIN_OFF"), on("GLOWK_WGRAD_16_OFF"), on("GLOWK_CO8_OFF"), on("GLOWK_CO_MID_OFF")};
 }
 static EnvSwitches g_env = read_env();
 const EnvSwitches& env() { return g_env; }

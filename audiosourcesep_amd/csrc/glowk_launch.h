@@ -37,6 +37,7 @@ struct EnvSwitches {
   bool q_off;               // GLOWK_Q_OFF: never the all-conv1-first small-grid form (glowk_q.h)
   bool co_split_off;        // GLOWK_CO_SPLIT_OFF: never the one-pass-per-workgroup (small-grid) form of k_net_h3c
   bool co_train_off;        // GLOWK_CO_TRAIN_OFF: the training sweep stays on the 32x32x16 family (A/B timing)
+  bool wgrad_16_off;        // GLOWK_WGRAD_16_OFF: no 16-wave / 256 x 256 form of the split weight-gradient GEMM (A/B timing)
   bool co8_off;             // GLOWK_CO8_OFF: no co-resident form at the 8-channel level (A/B timing)
   bool co_mid_off;          // GLOWK_CO_MID_OFF: the co-resident form only on grids of >= 4 workgroups per CU (or <= 1: SPLIT), as first built
 };

@@ -215,8 +215,8 @@ struct WgradSplitArgs {
 // VEC: K is a multiple of 4 (float4 loads; a template parameter because a run-time branch around every load makes hipcc wait for
 // each load in turn)
 template <int WTM, int WTN, int WM, int WN, bool VEC>
-__global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void k_wgrad_h3(WgradSplitArgs a) {
-  static_assert(WM * WN == 4 || WM * WN == 8, "four or eight waves");
+__global__ __launch_bounds__(64 * WM * WN, WM * WN >= 8 ? 1 : 2) void k_wgrad_h3(WgradSplitArgs a) {
+  static_assert(WM * WN == 4 || WM * WN == 8 || WM * WN == 16, "four, eight or sixteen waves");
   constexpr int RPP = 8 * WM * WN;     // rows one pass of the loader covers (8 threads per row of 32 k)
   constexpr int TM = 32 * WTM * WM, TN = 32 * WTN * WN;
   constexpr int LDH = 40;              // halves per LDS row: 32 k + 8 of padding
@@ -390,7 +390,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void k_wgrad_h3
     if (k_begin + 32 < k_end) fetch(full_tag, k_begin + 32);
     __syncthreads();
     int buf = 0;
-    if (WTM * WTN != 4 || a.plain) {
+    constexpr bool PLAIN_ONLY = WTM * WTN != 4 || WM * WN == 16;      // (sixteen waves: 128 registers per wave -- one k-step's fragments at a time)
+    if (PLAIN_ONLY || a.plain) {
       // the skinny shapes are bound by streaming A: the plain order (whole staging, all loads, then the MFMAs) keeps their loads earliest
       // (the branch-free, fenced form below: 29 -> 21 TFLOP/s on the conv1 / conv3 shapes)
       for (long k0 = k_begin; k0 < k_end; k0 += 32, buf ^= 1) {
@@ -402,6 +403,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void k_wgrad_h3
       }
       return;
     }
+    if constexpr (!PLAIN_ONLY) {
     long k0 = k_begin;
     // steady state: a round without a branch in its body, written as six groups -- one product of one k-step (WTM x WTN MFMAs) followed
     // by a share of the NEXT round's staging (conversion of one loader unit, its two LDS writes) and the global load that refills the
@@ -419,6 +421,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void k_wgrad_h3
       buf ^= 1;
     }
     compute(buf);
+    }
   };
   const bool sums = a.b_sums && m0 == 0;
   if (k_begin < k_end) {

@@ -152,7 +152,10 @@ int launch_wgrad(glowk_handle* h, bool split, const float* A, ptrdiff_t bsA, int
                  float* C, size_t csC, bool b_sums, hipStream_t s) {
   const bool big = split ? N >= 256 : (M >= 256 && N >= 256 && glowk_detail::env().wgrad_128);   // (fp32: 128 x 128 tiles measured 5 % slower than 64 x 64)
   const bool big8 = split && big && M % 256 == 0;   // 8 waves, 256 x 128: a quarter less staging per MFMA (254 -> 290 TFLOP/s on the level-0 conv2 batch)
-  const int TM = big8 ? 256 : split ? 128 : big ? 128 : 64, TN = split ? (big ? 128 : 64) : TM;
+  // 16 waves, 256 x 256 (square shapes: the conv2 gradient): 2/3 of the 8-wave form's staged bytes per MFMA -- staging is what bounds these
+  // GEMMs --, 128 registers per wave (one k-step's fragments at a time): 332 -> 373 TFLOP/s on the level-0 batch of a 256-tile step
+  const bool big16 = big8 && N % 256 == 0 && (K & 3) == 0 && !glowk_detail::env().wgrad_16_off;
+  const int TM = big8 ? 256 : split ? 128 : big ? 128 : 64, TN = big16 ? 256 : split ? (big ? 128 : 64) : TM;
   const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN, tiles = tm * tn;
   static const int wg_env = getenv("GLOWK_WGRAD_WGS") ? atoi(getenv("GLOWK_WGRAD_WGS")) : 0;   // workgroups per CU the split aims at
   const int wg_per_cu = wg_env > 0 ? wg_env : big8 ? 1 : 2;                                       // (what fits a CU: 1 of the 8-wave form)
@@ -171,7 +174,8 @@ int launch_wgrad(glowk_handle* h, bool split, const float* A, ptrdiff_t bsA, int
     a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.kslice = kslice; a.S = S; a.tm = tm; a.tn = tn; a.bsA = bsA; a.bsB = bsB; a.sa = sa; a.sb = sb;
     a.Cpart = out; a.csz = csz; a.b_sums = b_sums ? 1 : 0; a.plain = glowk_detail::env().wgrad_plain ? 1 : 0;
     const dim3 grid((unsigned)(tiles * S * nb));
-    if (big8 && vec) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 4, 2, true>), grid, dim3(512), 0, s, a);
+    if (big16) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 4, 4, true>), grid, dim3(1024), 0, s, a);
+    else if (big8 && vec) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 4, 2, true>), grid, dim3(512), 0, s, a);
     else if (big8) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 4, 2, false>), grid, dim3(512), 0, s, a);
     else if (big && vec) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, true>), grid, dim3(256), 0, s, a);
     else if (big) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, false>), grid, dim3(256), 0, s, a);

@@ -38,14 +38,15 @@ int main(int argc, char** argv) {
     WgradSplitArgs a; a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.kslice = kslice; a.S = S; a.bsA = hA.size(); a.bsB = hB.size(); a.sa = 1.0f; a.sb = sb; a.Cpart = Cp; a.csz = (size_t)M * N; a.b_sums = 0; a.plain = getenv("PLAIN") ? 1 : 0;
     a.tm = (M + 127) / 128; a.tn = (N + (N >= 256 ? 127 : 63)) / (N >= 256 ? 128 : 64);
     const bool big = N >= 256;
-    const bool w8 = getenv("W8") != nullptr;      // 8 waves, 256 x 128 tiles
-    const int TM = (big && w8) ? 256 : 128, TN = big ? 128 : 64;
-    a.tm = (M + TM - 1) / TM;
+    const bool w16 = getenv("W16") != nullptr;    // 16 waves, 256 x 256 tiles (an experiment: 2/3 of the staged bytes per MFMA)
+    const bool w8 = getenv("W8") != nullptr || w16;      // 8 waves, 256 x 128 tiles
+    const int TM = (big && w8) ? 256 : 128, TN = (big && w16) ? 256 : big ? 128 : 64;
+    a.tm = (M + TM - 1) / TM; a.tn = (N + TN - 1) / TN;
     dim3 grid(((M + TM - 1) / TM) * ((N + TN - 1) / TN) * S * batch);
-    for (int it = 0; it < 3; ++it) { if (big && w8) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 4, 2, true>), grid, dim3(512), 0, 0, a); else if (big) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, true>), grid, dim3(256), 0, 0, a); else hipLaunchKernelGGL((k_wgrad_h3<1, 2, 4, 1, true>), grid, dim3(256), 0, 0, a); }
+    for (int it = 0; it < 3; ++it) { if (big && w16) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 4, 4, true>), grid, dim3(1024), 0, 0, a); else if (big && w8) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 4, 2, true>), grid, dim3(512), 0, 0, a); else if (big) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, true>), grid, dim3(256), 0, 0, a); else hipLaunchKernelGGL((k_wgrad_h3<1, 2, 4, 1, true>), grid, dim3(256), 0, 0, a); }
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int it = 0; it < 20; ++it) { if (big && w8) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 4, 2, true>), grid, dim3(512), 0, 0, a); else if (big) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, true>), grid, dim3(256), 0, 0, a); else hipLaunchKernelGGL((k_wgrad_h3<1, 2, 4, 1, true>), grid, dim3(256), 0, 0, a); }
+    for (int it = 0; it < 20; ++it) { if (big && w16) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 4, 4, true>), grid, dim3(1024), 0, 0, a); else if (big && w8) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 4, 2, true>), grid, dim3(512), 0, 0, a); else if (big) hipLaunchKernelGGL((k_wgrad_h3<2, 2, 2, 2, true>), grid, dim3(256), 0, 0, a); else hipLaunchKernelGGL((k_wgrad_h3<1, 2, 4, 1, true>), grid, dim3(256), 0, 0, a); }
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("M %d N %d K %d S %d batch %d grid %d x %d x %d\n", M, N, K, S, batch, grid.x, grid.y, grid.z);
