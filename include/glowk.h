@@ -263,8 +263,11 @@ int glowk_coupling_net(glowk_handle* h, int level, int step, const float* xb_dev
 size_t glowk_param_vector_size(glowk_handle* h);
 /* where tensor `tensor_id` of (level, step) -- or a prior tensor (level, step ignored) -- sits in the vector */
 int glowk_param_offset(glowk_handle* h, int level, int step, int tensor_id, size_t* offset, size_t* count);
-/* x [N,H,W,C] -> grad_dev [glowk_param_vector_size] (overwritten) and, if logp_dev != NULL, log_prob [N].  Synchronises the
- * stream (the ActNorm / 1x1 chain rule is c x c fp64 algebra on the host). */
+/* x [N,H,W,C] -> grad_dev [glowk_param_vector_size] (overwritten) and, if logp_dev != NULL, log_prob [N].  The results are
+ * ordered on `stream` like those of every other call.  The call returns once the data-gradient sweep has finished on the device (the
+ * host's share -- the c x c fp64 chain rule of ActNorm / 1x1 -- then runs beside the last weight-gradient GEMMs; its results go up on
+ * an internal stream that `stream` waits for by event); since version 400 it does NOT join `stream`: synchronise it before reading
+ * grad_dev from the host. */
 int glowk_param_grad(glowk_handle* h, const float* x_dev, int N, float scale, float* logp_dev, float* grad_dev, void* stream);
 /* one optimizer step: optimizer 0 = Adam, 1 = Adamax (train_utils.py:23-41; Keras defaults beta_1 0.9, beta_2 0.999, epsilon 1e-7).
  * glowk_get_tensor / flow.variables see the new values. */
