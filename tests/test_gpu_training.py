@@ -386,3 +386,44 @@ def test_training_sweep_in_the_co_resident_form(n, monkeypatch):
     np.testing.assert_allclose(lp1.cpu().numpy(), lp0.cpu().numpy(), rtol=2e-6)
     assert eng.range_status() == (False, 0)
     eng.close()
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_training_steps_without_a_host_join_equal_joined_ones(prec, monkeypatch):
+    """glowk_param_grad does not join the caller's stream: the host's ActNorm / 1x1 chain rule runs beside the last level's
+    weight-gradient GEMMs (sums down / results up on a side stream the caller's stream waits for by event), and
+    glowk_apply_gradients folds ActNorm + 1x1 on the host while the device refreshes the images.  Eight back-to-back steps with no
+    synchronisation in between against the same steps with the host joining the stream inside every sweep (GLOWK_PG_JOIN=1) and a
+    device synchronisation after every call: parameters, losses and the final log_prob bit for bit."""
+    cfg = GlowConfig(H=32, W=32, C=1, L=3, K=3, F=256)
+    x = dev(synthetic_mel_tiles(24, cfg, seed=41))
+    out = {}
+    for joined in (False, True):
+        if joined:
+            monkeypatch.setenv("GLOWK_PG_JOIN", "1")
+        else:
+            monkeypatch.delenv("GLOWK_PG_JOIN", raising=False)
+        eng, _ = calibrated_engine(cfg, device=0, init_tiles=16)
+        if prec == "f16x3":
+            eng.set_precision(_lib.PREC_F16X3)
+        g = torch.zeros(eng.param_vector_size, device="cuda")
+        lps = []
+        for it in range(8):
+            lp, _ = eng.param_grad(x, -1.0 / 24.0, g)
+            if joined:
+                torch.cuda.synchronize()
+            lps.append(lp)
+            eng.apply_gradients(g, optimizer="adamax", lr=1e-3)
+            if joined:
+                torch.cuda.synchronize()
+        final = eng.log_prob(x)
+        torch.cuda.synchronize()
+        out[joined] = (torch.stack(lps).cpu(), final.cpu(), {k: np.asarray(v) for k, v in GlowFlow(eng).state_dict().items()}, g.cpu())
+        eng.close()
+    monkeypatch.undo()
+    a, b = out[False], out[True]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
+    assert a[2].keys() == b[2].keys()
+    for k in a[2]:
+        assert np.array_equal(a[2][k], b[2][k]), k
+    assert float(-a[0][-1].mean()) < float(-a[0][0].mean())
