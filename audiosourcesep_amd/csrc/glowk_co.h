@@ -125,6 +125,10 @@ __device__ __forceinline__ void co_Y(const float4* slot, const h8 (&bh)[2], cons
     d[2] = buf[((2 * gi + 1) * 2 + 0) * 64];
     d[3] = buf[((2 * gi + 1) * 2 + 1) * 64];
   };
+#ifdef GLOWK_EXP_COPRIO    // (A/B build: a wave in its matrix ops outranks its SIMD partner -- the other workgroup's wave, possibly in the VALU-heavy X op:
+                           //  62.42 -> 62.74 ms per 1024-tile log_prob, +0.5 %: not kept)
+  __builtin_amdgcn_s_setprio(GLOWK_EXP_COPRIO);
+#endif
   load(A[0], 0);
 #pragma unroll
   for (int gi = 0; gi < NG; ++gi) {
@@ -158,6 +162,9 @@ __device__ __forceinline__ void co_Y(const float4* slot, const h8 (&bh)[2], cons
     acc2[o1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2], bh[1], acc2[o1][1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
+#ifdef GLOWK_EXP_COPRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 // Z: conv3 unit z of a pass = NFH tiles (16 rows x one hidden block) in (hidden block, row block) order.  Two passes in one workgroup:
