@@ -45,7 +45,7 @@ before = eng.kernel_families()
 first_lp, first_z = call()
 first_lp, first_z = first_lp.clone(), first_z.clone()
 fam = {k: v - before[k] for k, v in eng.kernel_families().items()}
-assert fam["co_resident"] == (2 if grad else 1) * CONFIG_B.K, fam
+assert fam["co_resident"] >= (2 if grad else 1) * CONFIG_B.K, fam      # (level 0; the 8-channel level too where its grid is large enough)
 d = float(((first_lp - ref_lp).abs() / ref_lp.abs()).max())
 print("co-resident vs one-per-CU: max rel diff of log_prob %.2e, max |d second output| / max %.2e" % (d, float((first_z - ref_z).abs().max() / ref_z.abs().max())), flush=True)
 assert d < (2e-7 if prec == _lib.PREC_F16X3 else 2e-5), d

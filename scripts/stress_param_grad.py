@@ -1,5 +1,5 @@
 """Bitwise-repeat stress of glowk_param_grad (a race in the storing launches -- e.g. a counted vmcnt that leaves a DMA piece unlanded -- shows as
-a run-to-run difference): REPS repeats x shapes x arithmetics, every gradient vector compared bit for bit with the first."""
+a run-to-run difference): REPS repeats x shapes x arithmetics, every gradient vector compared bit for bit with the second sweep's (the first runs before the dynamic gradient scale has adapted)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,7 +16,8 @@ for cfg, n in shapes:
     for prec, name in ((_lib.PREC_F16X3, "f16x3"), (_lib.PREC_F32, "f32")):
         eng.set_precision(prec)
         eng.set_range_policy("error")
-        lp0, g0 = eng.param_grad(x, -1.0 / n)
+        eng.param_grad(x, -1.0 / n)      # (the first split sweep runs with gradient scale 1; from the second on the scale is the adapted power of two:
+        lp0, g0 = eng.param_grad(x, -1.0 / n)      #  results ~1e-7 apart from the first sweep's, identical among themselves)
         lp0, g0 = lp0.clone(), g0.clone()
         diff = 0
         for r in range(reps):
